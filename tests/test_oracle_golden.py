@@ -1,0 +1,129 @@
+"""CPU: the oracle (oracle/) against the golden vectors generated from the imported reference
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU tests then check HIP vs oracle."""
+import numpy as np
+import pytest
+import torch
+
+from livingscenes_amd import synth
+from oracle import canon, more, net
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol_max=2e-6, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= rtol_max, f"{what}: max-norm relative error {err:.3e} > {rtol_max}"
+
+
+def test_canon_c_equals_numpy_twin():
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((2, 40, 3, 5)).astype(np.float32)
+    s = rng.standard_normal((2, 70, 3, 5)).astype(np.float32)
+    s[0, 11] = s[0, 3]  # exact duplicate -> distance tie, lower index must win
+    assert np.array_equal(canon.knn_c(d, s, 16, contract=0), canon.knn_np(d, s, 16))
+    p = rng.standard_normal((3, 200, 3)).astype(np.float32)
+    p[1, 50] = p[1, 20]
+    assert np.array_equal(canon.fps_c(p, 64, contract=0), canon.fps_np(p, 64))
+    # fused mode differs only in rounding: same neighbour sets on generic data
+    a, b = canon.knn_c(d, s, 16, contract=0), canon.knn_c(d, s, 16, contract=1)
+    assert (np.sort(a, -1) == np.sort(b, -1)).mean() > 0.99
+
+
+def test_canon_edge_cases():
+    rng = np.random.default_rng(1)
+    s = rng.standard_normal((1, 8, 3, 1)).astype(np.float32)
+    idx = canon.knn_c(s, s, 16, contract=0)       # K > Ns -> padded with -1
+    assert (idx[..., :8] >= 0).all() and (idx[..., 8:] == -1).all()
+    assert (idx[0, :, 0] == np.arange(8)).all()   # self is the nearest
+    p = np.zeros((1, 5, 3), np.float32)           # all-duplicate cloud: first arg-max keeps index 0
+    assert (canon.fps_c(p, 4) == 0).all()
+    lens = np.array([3], np.int32)
+    out = canon.fps_c(rng.standard_normal((1, 6, 3)).astype(np.float32), 5, lengths=lens)
+    assert (out[0, 3:] == -1).all() and out[0, 0] == 0
+
+
+def test_vn_layers(golden):
+    g = golden("vn_layers")
+    x = T(g["x"])
+    close(net.vec_linear(x, T(g["lin_w"])), g["lin_y"], what="VecLinear")
+    close(net.vec_lna(x, T(g["lna_w"]), T(g["lna_wd"]), 0.2), g["lna_y"], what="VecLNA")
+    close(net.vec_lna(x, T(g["lnash_w"]), T(g["lnash_wd"]), 0.2), g["lnash_y"], what="VecLNA shared")
+    close(net.channel_equi_vec_normalize(x), g["cevn_y"], what="cevn")
+    w = {k[3:]: T(v) for k, v in g.items() if k.startswith("rb.")}
+    close(net.vec_resblock(x[..., 0], w, "", 0.2), g["rb_y"], what="VecResBlock")
+    # closed forms the HIP kernels rely on
+    y = net.vec_linear(x, T(g["lna_w"]))
+    k = net.vec_linear(y, T(g["lna_wd"]))
+    kh = k / k.norm(dim=2, keepdim=True).clamp_min(1e-12)
+    p = (y * kh).sum(2, keepdim=True)
+    close(y - 0.8 * p.clamp(max=0) * kh, g["lna_y"], what="act closed form")
+    fro = x.pow(2).sum(dim=(1, 2), keepdim=True).sqrt()
+    close(x / fro, g["cevn_y"], what="cevn closed form")
+
+
+def test_encoder_small_trace(golden):
+    g = golden("encoder_small")
+    cfg = synth.small_encoder_cfg()
+    w = synth.make_encoder_weights(cfg, seed=7)
+    tr = {}
+    center, scale, z_so3, z_inv = net.encoder_forward(w, cfg, T(g["x"]), trace=tr)
+    for i in range(cfg["num_layers"]):
+        assert np.array_equal(tr[f"knn_idx_{i}"].numpy(), g[f"knn_idx_{i}"]), f"knn layer {i}"
+    assert np.array_equal(tr["fps_idx_2"].numpy(), g["fps_idx_0"])
+    close(center, g["center"], what="center")
+    close(scale, g["scale"], what="scale")
+    close(z_so3, g["z_so3"], what="z_so3")
+    close(z_inv, g["z_inv"], what="z_inv")
+
+
+def test_shape_prior_full_and_decoder(golden):
+    g = golden("shape_prior_full")
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    ew, dw = synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0)
+    tr = {}
+    emb = net.shape_prior_encode(ew, ecfg, synth.make_instances(2, 1024, seed=0), trace=tr)
+    for i in range(7):
+        assert np.array_equal(tr[f"knn_idx_{i}"].numpy(), g[f"knn_idx_{i}"]), f"knn layer {i}"
+    for j, i in enumerate(ecfg["down_sample_layers"]):
+        assert np.array_equal(tr[f"fps_idx_{i}"].numpy(), g[f"fps_idx_{j}"])
+    for k in ("z_so3", "z_inv", "s", "t"):
+        close(emb[k], g[k], what=k)
+    code = {k: T(g[k]) for k in ("z_so3", "z_inv", "s", "t")}
+    close(net.field_query(dw, dcfg, T(g["query"]), code), g["sdf"], what="sdf")
+
+
+def test_matchers(golden):
+    g = golden("matchers")
+    for name in ("n1", "n2", "n3", "n5", "n32", "neg", "tie"):
+        r = more.sequential_matcher(T(g[f"seq_{name}_a"]), T(g[f"seq_{name}_b"]))
+        assert np.array_equal(r["matches0"].numpy(), g[f"seq_{name}_m0"]), name
+        assert np.array_equal(r["matches1"].numpy(), g[f"seq_{name}_m1"]), name
+    r = more.nn_matcher(T(g["nn_a"]).T[None], T(g["nn_b"]).T[None])
+    assert np.array_equal(r["matches0"].numpy(), g["nn_m0"]) and np.array_equal(r["matches1"].numpy(), g["nn_m1"])
+    src = {"z_inv": T(g["eqsrc_z_inv"]), "z_so3": T(g["eqsrc_z_so3"])}
+    tgt = {"z_inv": T(g["eqtgt_z_inv"]), "z_so3": T(g["eqtgt_z_so3"])}
+    for nm, fn in (("eq", more.eq_seq_matcher), ("sim3", more.sim3_seq_matcher)):
+        r = fn(src, tgt)
+        assert np.array_equal(r["matches0"].numpy(), g[f"{nm}_m0"]) and np.array_equal(r["matches1"].numpy(), g[f"{nm}_m1"])
+
+
+def test_registration(golden):
+    g = golden("registration")
+    x1, x2 = T(g["kab_x1"]), T(g["kab_x2"])
+    R, t, res, flag = more.kabsch_transformation_estimation(x1, x2)
+    close(R, g["kab_R"], 1e-5, "R"), close(t, g["kab_t"], 1e-5, "t"), close(res, g["kab_res"], 1e-5, "res")
+    Rw, tw, resw, _ = more.kabsch_transformation_estimation(x1, x2, T(g["kab_w"]))
+    close(Rw, g["kab_Rw"], 1e-5, "Rw"), close(tw, g["kab_tw"], 1e-5, "tw"), close(resw, g["kab_resw"], 1e-5, "resw")
+    assert (torch.det(R[:16]) > 0.99).all()
+    close(more.rotation_error(T(g["kab_R"]), T(g["kab_Rg"])), g["rot_err"], 1e-6, "rot_err")
+    close(more.translation_error(T(g["kab_t"]), T(g["kab_tg"])), g["trans_err"], 1e-6, "trans_err")
+    T1, T2 = T(g["se3_T1"]), T(g["se3_T2"])
+    close(more.Rt_to_SE3(T(g["kab_R"]), T(g["kab_t"])), g["se3_T1"], 1e-7, "Rt_to_SE3")
+    close(more.se3_inverse(T1), g["se3_inv"], 1e-6, "inverse")
+    close(more.se3_concatenate(T1, T2), g["se3_cat"], 1e-6, "concatenate")
+    close(more.se3_transform(T1, x1), g["se3_tf"], 1e-6, "transform")
+    close(more.compute_transformation_error(x1[:1], x2[:1], T1[:1], T2[:1]), g["rmse"], 1e-6, "rmse")
