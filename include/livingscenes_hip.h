@@ -1,0 +1,184 @@
+/*
+ * livingscenes_hip.h -- C ABI of liblivingscenes_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (GradientSpaces/LivingScenes) is pure Python/PyTorch: it has no FFI of its own.  The
+ * boundary below is what a maintainer binds (ctypes) to replace the ATen /
+ * pytorch3d kernels behind the reference's Python call surface for the per-instance inference path.
+ * Every entry point cites the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller (PyTorch) owns all
+ *     input / output / workspace buffers; the library never frees or retains caller memory.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *     the device.  (ls_encoder_forward additionally forks onto a library-owned side stream and joins
+ *     back with events; the join happens before it returns control of `stream`'s tail.)
+ *   - return value: 0 on success, negative ls_status on failure; text via ls_last_error() (thread-local).
+ *   - feature tensors use the library's point-major layout [B, N, 3, C] ("x-major rows": a point is
+ *     three rows of C contiguous floats).  The reference layout is [B, C, 3, N]; the Python shim
+ *     converts at the API edge only (inputs x[B,3,N], outputs z_so3[B,C,3] keep the reference layout).
+ *   - all floating point is IEEE fp32 (the reference runs fp32: configs/room4cates.yaml:15).
+ */
+#ifndef LIVINGSCENES_HIP_H
+#define LIVINGSCENES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LS_OK = 0,
+    LS_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    LS_ERR_HIP = -2,         /* a HIP runtime call failed */
+    LS_ERR_WORKSPACE = -3,   /* workspace too small */
+    LS_ERR_NO_DEVICE = -4
+} ls_status;
+
+/* flags for the integer-exact ops: how `dist += diff*diff` is rounded (oracle/ls_oracle.c header) */
+#define LS_FLAG_CONTRACT_FMA 1u /* d = fmaf(diff,diff,d); default (0) = separately rounded mul, add */
+
+#define LS_MAX_LAYERS 8
+
+int ls_version(void);
+const char* ls_last_error(void);
+/* number of HIP devices visible, or a negative ls_status */
+int ls_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Leaf operators
+ * ---------------------------------------------------------------------------------------------- */
+
+/* pytorch3d.ops.knn_points(dst, src, K, return_nn=...) as called at
+ * lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:139-141 (feature-space dynamic graph).
+ *   src      [B, Ns, 3, C]   candidate features
+ *   dst      [B, Nd', 3, C]  query features; if dst_rows != NULL the query n of instance b is row
+ *                            dst_rows[b*Nd + n] of `dst` (which then has Nd' = dst_n rows per instance)
+ *   idx_out  [B, Nd, K] int32, ascending (dist, index); -1 padded when Ns < K
+ *   dist_out [B, Nd, K] or NULL
+ * Distance = sum_j (a_j-b_j)^2, j = c*3+x ascending, fp32, rounding per `flags`.  K <= 16.
+ * C must be 1 or a multiple of 32. */
+int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
+               int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* stream);
+
+/* pytorch3d.ops.sample_farthest_points(points, K=..., random_start_point=False) as called at
+ * vec_dgcnn_atten.py:169, model_utils.py:205, lib_more/more_solver.py:107-108.
+ *   pts [B, N, 3]; lengths [B] or NULL; idx_out [B, K] int32 (-1 padded when K > length);
+ *   pts_out [B, K, 3] or NULL (gathered points).  Start index 0, running min, first arg-max. */
+int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out,
+               float* pts_out, void* stream);
+
+/* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) -- the VecLinear channel contraction
+ * (vec_layers.py:121-136, F.linear at :134) on x-major rows, and the DeepSDF linears
+ * (lib_shape_prior/core/lib/implicit_func/deepsdf_decoder.py:98-121).  fp32 MFMA (exact fp32 FMA chains).
+ * K % 4 == 0, lda/ldw/ldc % 4 == 0; bias may be NULL; relu in {0,1}. */
+int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M,
+                int N, int K, int relu, void* stream);
+
+/* Shape_Prior.encode prologue, model_utils.py:166-177: centroid, scale_0 = mean of the 5 largest
+ * entries of the N x N distance matrix, normalised cloud.
+ *   x [B,3,N] (reference layout) -> pts_out [B,N,3], centroid_out [B,3], scale0_out [B] */
+int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out,
+                           void* stream);
+
+/* sequential_matcher's score matrix, lib_more/matcher_new.py:110-120:
+ * S = normalize(m0) @ normalize(m1)^T.   m0 [n,D], m1 [m,D] -> S [n,m] */
+int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* stream);
+
+/* The greedy assignment loop shared by sequential / sim3_seq / eq_seq matchers
+ * (matcher_new.py:121-136, :166-181, :212-227): repeat min(n,m) times { S /= (max(S)+1e-5); take the
+ * first row-major arg-max; record; delete row and column }.  `scores` [n,m] is DESTROYED.
+ * matches0 [n], matches1 [m] int64, -1 = unmatched. */
+int ls_greedy_match_f32(float* scores, int n, int m, int64_t* matches0, int64_t* matches1, void* stream);
+
+/* kabsch_transformation_estimation(x1, x2, weights, normalize_w=True, eps=1e-7),
+ * lib_more/pose_estimation.py:29-102 (+ transformation_residuals :105-121).
+ *   x1,x2 [b,n,3]; weights [b,n] or NULL (ones); R [b,3,3], t [b,3] (the reference's [b,3,1]),
+ *   res [b,n] or NULL, flags_out [b] int32 or NULL (1 = degenerate covariance -> identity pose,
+ *   mirroring the SVD-failure branch at :79-88). */
+int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, float* R, float* t,
+                          float* res, int32_t* flags_out, void* stream);
+
+/* mean Kabsch residual of every (src i, tgt j) pair of equivariant codes: res_mat of
+ * matcher_new.py:150-156 / :196-202.   src [n,P,3], tgt [m,P,3] -> res [n,m] */
+int ls_kabsch_residual_matrix_f32(const float* src, const float* tgt, int n, int m, int P, float* res, void* stream);
+
+/* pytorch3d.ops.iterative_closest_point(X, Y, init_transform=SimilarityTransform(R0,T0,1)) with default
+ * arguments (100 iterations, relative_rmse_thr 1e-6), as called at lib_more/more_solver.py:182-187.
+ * Row-vector convention Xt = X R + T.  X [b,n,3], Y [b,m,3], R0 [b,3,3], T0 [b,3] ->
+ * R [b,3,3], T [b,3], rmse [b], iters_out [1] int32.  workspace >= ls_icp_workspace_bytes(b,n). */
+size_t ls_icp_workspace_bytes(int b, int n);
+int ls_icp_f32(const float* X, const float* Y, const float* R0, const float* T0, int b, int n, int m, int max_iter,
+               float rel_rmse_thr, unsigned flags, float* R, float* T, float* rmse, int32_t* iters_out,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model handle (packed device-resident weights: the library's only allocation)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ls_model ls_model_t;
+
+typedef struct {
+    /* encoder: VecDGCNN_att.__init__ arguments, vec_dgcnn_atten.py:23-45 */
+    int32_t num_layers;
+    int32_t feat_dim[LS_MAX_LAYERS];
+    int32_t down_factor[LS_MAX_LAYERS]; /* 1 = no down-sampling before this layer */
+    int32_t atten_start_layer;
+    int32_t atten_head_c;
+    int32_t res_global_start_layer;     /* >= num_layers disables the residual global conv */
+    int32_t num_knn;
+    int32_t c_dim;
+    int32_t center_pred;
+    int32_t center_pred_scale;
+    float scale_factor;
+    float neg_slope;
+    /* decoder: DeepSDF_Decoder (deepsdf_decoder.py:12-57), decoder_type "inner_deepsdf" */
+    int32_t dec_num_linear;             /* number of linear layers (9), 0 = no decoder packed */
+    int32_t dec_width;                  /* hidden width (768) */
+    int32_t dec_latent_in;              /* layer that re-concatenates the input (4), -1 = none */
+    /* offsets (in floats) into the packed blob; layouts documented in livingscenes_amd/packing.py */
+    int64_t off_l0;                     /* [6][feat_dim[0]] layer-0 folded rows */
+    int64_t off_edge[LS_MAX_LAYERS];    /* layer i>=1: [ncols_i][feat_dim[i-1]] folded per-point weights */
+    int64_t off_glob[LS_MAX_LAYERS];    /* layer i>=g0: [4*C][C] = {Wa;Wd*Wa;Wb;Wd*Wb} */
+    int64_t off_convc;                  /* [c_dim+1 (padded to 4)][feat_dim[-1]] */
+    int64_t off_inv_t;                  /* fc_inv^T [c_dim][c_dim] */
+    int64_t off_c_fc0_t;                /* fc_center.fc0 {lin;dir*lin}^T : [c_dim][2*h] */
+    int64_t off_c_misc;                 /* lin1 [h], shortcut [c_dim], act2 dir scalar [1] */
+    int64_t off_dec_w[12];              /* decoder layer l: folded main weight [out_l][kin_l] */
+    int64_t off_dec_b[12];              /* decoder bias [out_l] */
+    int64_t off_dec_inv_t[12];          /* layers fed by the code (0 and latent_in): Wa^T [latent][out] */
+    int64_t off_dec_so3_t[12];          /*   "    Wb^T [latent][out] */
+    int64_t off_dec_len[12];            /*   "    w_len [out] */
+    int64_t blob_floats;
+} ls_model_desc;
+
+int ls_model_create(const ls_model_desc* desc_host, const float* blob_host, ls_model_t** out);
+void ls_model_destroy(ls_model_t* m);
+
+/* ------------------------------------------------------------------------------------------------
+ * Composite hot path
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Shape_Prior.encode(x), model_utils.py:165-197, = prologue + VecDGCNN_att.forward
+ * (vec_dgcnn_atten.py:177-252) + epilogue (t = center + centroid, s = scale_0 * pred_scale).
+ *   x [B,3,N] -> z_so3 [B,c_dim,3], z_inv [B,c_dim], s [B], t [B,3]
+ * trace_knn / trace_fps (nullable): per-layer k-NN / FPS indices for the parity tests, packed
+ * back to back: knn layer i at offset sum_{j<i} B*Nd_j*K (int32), fps level l at sum B*Nd_l.
+ * If pre_normalised != 0, x is taken as already centred/scaled (prologue skipped, centroid 0, scale_0 1):
+ * this is VecDGCNN_att.forward alone and the outputs are (center, scale, z_so3, z_inv). */
+size_t ls_encoder_workspace_bytes(const ls_model_t* m, int B, int N);
+int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, unsigned flags, float* z_so3,
+              float* z_inv, float* s, float* t, int32_t* trace_knn, int32_t* trace_fps, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* FieldWrapper.forward(query, None, code, return_sdf=True), decoder_type "inner_deepsdf":
+ * model_utils.py:230-263 + DeepSDF_Decoder.forward, deepsdf_decoder.py:78-123.
+ *   query [B,M,3], z_so3 [B,c,3], z_inv [B,c], s [B], t [B,3] -> sdf [B,M] */
+size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M);
+int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s,
+                  const float* t, int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIVINGSCENES_HIP_H */

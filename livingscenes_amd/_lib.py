@@ -1,0 +1,123 @@
+"""ctypes binding of liblivingscenes_hip.so (the C ABI declared in include/livingscenes_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing, or a tensor handed to an operator is not a HIP
+("cuda") tensor, the call raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblivingscenes_hip.so")
+
+LS_MAX_LAYERS = 8
+FLAG_CONTRACT_FMA = 1
+
+
+class LsError(RuntimeError):
+    pass
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [
+        ("num_layers", ctypes.c_int32),
+        ("feat_dim", ctypes.c_int32 * LS_MAX_LAYERS),
+        ("down_factor", ctypes.c_int32 * LS_MAX_LAYERS),
+        ("atten_start_layer", ctypes.c_int32),
+        ("atten_head_c", ctypes.c_int32),
+        ("res_global_start_layer", ctypes.c_int32),
+        ("num_knn", ctypes.c_int32),
+        ("c_dim", ctypes.c_int32),
+        ("center_pred", ctypes.c_int32),
+        ("center_pred_scale", ctypes.c_int32),
+        ("scale_factor", ctypes.c_float),
+        ("neg_slope", ctypes.c_float),
+        ("dec_num_linear", ctypes.c_int32),
+        ("dec_width", ctypes.c_int32),
+        ("dec_latent_in", ctypes.c_int32),
+        ("off_l0", ctypes.c_int64),
+        ("off_edge", ctypes.c_int64 * LS_MAX_LAYERS),
+        ("off_glob", ctypes.c_int64 * LS_MAX_LAYERS),
+        ("off_convc", ctypes.c_int64),
+        ("off_inv_t", ctypes.c_int64),
+        ("off_c_fc0_t", ctypes.c_int64),
+        ("off_c_misc", ctypes.c_int64),
+        ("off_dec_w", ctypes.c_int64 * 12),
+        ("off_dec_b", ctypes.c_int64 * 12),
+        ("off_dec_inv_t", ctypes.c_int64 * 12),
+        ("off_dec_so3_t", ctypes.c_int64 * 12),
+        ("off_dec_len", ctypes.c_int64 * 12),
+        ("blob_floats", ctypes.c_int64),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_U = ctypes.c_uint
+_F = ctypes.c_float
+_SZ = ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/livingscenes_hip.h declares
+SIGNATURES = {
+    "ls_version": (_I, []),
+    "ls_last_error": (ctypes.c_char_p, []),
+    "ls_device_count": (_I, []),
+    "ls_knn_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P, _P, _P]),
+    "ls_fps_f32": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P]),
+    "ls_gemm_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ls_encode_prologue_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "ls_cosine_scores_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "ls_greedy_match_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "ls_kabsch_batched_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "ls_kabsch_residual_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "ls_icp_workspace_bytes": (_SZ, [_I, _I]),
+    "ls_icp_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ls_model_create": (_I, [ctypes.POINTER(ModelDesc), _P, ctypes.POINTER(_P)]),
+    "ls_model_destroy": (None, [_P]),
+    "ls_encoder_workspace_bytes": (_SZ, [_P, _I, _I]),
+    "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ls_sdf_workspace_bytes": (_SZ, [_P, _I, _I]),
+    "ls_sdf_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises LsError if it has not been built -- no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LsError(f"{LIB_PATH} is missing: run `python -m livingscenes_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback for the HIP operators.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ls_last_error().decode(errors="replace")
+        raise LsError(f"{what} failed (status {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        raise LsError("expected a torch tensor")
+    if t.device.type != "cuda":
+        raise LsError(f"HIP operator called with a {t.device.type} tensor: the MI355X path has no CPU fallback")
+    if not t.is_contiguous():
+        raise LsError("HIP operators need contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

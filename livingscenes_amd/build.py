@@ -1,0 +1,62 @@
+"""Build liblivingscenes_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m livingscenes_amd.build [--force]
+
+The library is built IN-TREE (livingscenes_amd/lib/) so that it travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "liblivingscenes_hip.so")
+SOURCES = ["model.hip", "knn.hip", "fps.hip", "gemm.hip", "edge.hip", "pointwise.hip", "sdf.hip", "match.hip", "icp.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
+         "-ffp-contract=fast-honor-pragmas"]
+
+
+def _newest_src():
+    t = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            t = max(t, os.path.getmtime(os.path.join(root, f)))
+    return t
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    if (not force) and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "livingscenes_hip.h")))
+    procs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+            continue
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = []
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed.append((s, out.decode(errors="replace")))
+        elif verbose and out:
+            print(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {s}\n{o}" for s, o in failed))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

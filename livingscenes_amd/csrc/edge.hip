@@ -1,0 +1,253 @@
+// edge.hip -- the VN-DGCNN edge-conv message passing, fused: neighbour gather -> VN-Linear (as pre-computed
+// per-point tables) -> VN-LeakyReLU -> mean-pool  OR  K/Q/V + head soft-max + weighted sum.
+//
+// Replaces, per layer i of VecDGCNN_att.forward
+// (/root/reference/lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:196-219):
+//   get_graph_feature's cat([nbr - ctr, ctr]) (:160; + cross term at layer 0, :154-158),
+//   V_list[i] / K_list[i] / Q_list[i]  VecLNA (vec_layers.py:523-534 = VecLinear :121-136 + VecActivation :241-268),
+//   mean pool (:204) or channel_equi_vec_normalize + QK soft-max attention (:209-219; vec_layers.py:24-31).
+//
+// The reference materialises E[n,k] = [src[nbr]-dst[n] ; dst[n]] as a [B,2C,3,N,K] tensor and runs two dense
+// channel contractions (lin: 2C->Co, lin_dir: Co->Co) on every one of the N*K edges.  Both are linear, so
+//     lin(E)[n,k]     = W1 src[nbr] + (W2-W1) dst[n]            =: P_lin[nbr] + Q_lin[n]
+//     lin_dir(lin(E)) = (Wd W1) src[nbr] + (Wd (W2-W1)) dst[n]  =: P_dir[nbr] + Q_dir[n]
+// i.e. ONE per-point GEMM (gemm.hip, folded weights from packing.py) produces a table T[b, point, xyz, cols]
+// and the per-edge work that remains is a gather plus ~35 VALU ops per (edge, channel): K=16x fewer MFMA FLOPs
+// and an HBM/L2-gather-bound kernel.  Nothing of size N*K is ever written to memory.
+//
+// Table columns (Co = layer width):  pool layers  [PV_lin | PV_dir | QV_lin | QV_dir]
+//                                    attn layers  [PV_lin | PV_dir | PK_lin | PK_dir | QV_lin | QV_dir | QK_lin | QK_dir | Qq_lin | Qq_dir]
+// Thread mapping: one wave per destination point, lanes = channels (coalesced 256-B row segments per
+// neighbour and xyz component), channel chunks of 64; attention heads are 16 consecutive channels = one
+// 16-lane DPP row, so head sums / soft-max reductions are 4-step row shuffles.
+#include "ls_common.h"
+
+namespace ls {
+
+constexpr int EK = 16;  // neighbours per point (num_knn)
+
+// ---------------------------------------------------------------------------------------------- layer 0
+// pts [B,N,3]; w0 [6][Co] = {W[:,0], W[:,1], W[:,2], (Wd W)[:,0], (Wd W)[:,1], (Wd W)[:,2]}; out [B,N,3,Co]
+__global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ pts, const int32_t* __restrict__ knn,
+                                                      const float* __restrict__ w0, int N, int Co, float oms,
+                                                      float* __restrict__ out, int total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 5, o = lane & 31;  // two points per wave, 32 lanes each (Co <= 32 per pass)
+    int pid = (blockIdx.x * 4 + wave) * 2 + sub;
+    const bool live = pid < total;
+    if (!live) pid = total - 1;
+    const int b = pid / N;
+    const float* P = pts + (size_t)b * N * 3;
+    const float cx = pts[(size_t)pid * 3 + 0], cy = pts[(size_t)pid * 3 + 1], cz = pts[(size_t)pid * 3 + 2];
+    const float inv = 1.0f / fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-12f);
+    const float ax = cx * inv, ay = cy * inv, az = cz * inv;
+    const int32_t* ki = knn + (size_t)pid * EK;
+    for (int c0 = 0; c0 < Co; c0 += 32) {
+        const int oc = c0 + o;
+        const bool on = oc < Co;
+        const int ow = on ? oc : 0;
+        const float a0 = w0[0 * Co + ow], a1 = w0[1 * Co + ow], a2 = w0[2 * Co + ow];
+        const float d0 = w0[3 * Co + ow], d1 = w0[4 * Co + ow], d2 = w0[5 * Co + ow];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < EK; ++k) {
+            const int r = ki[k];
+            const float nx = P[(size_t)r * 3 + 0], ny = P[(size_t)r * 3 + 1], nz = P[(size_t)r * 3 + 2];
+            const float crx = ay * nz - az * ny, cry = az * nx - ax * nz, crz = ax * ny - ay * nx;
+            const float dx = nx - cx, dy = ny - cy, dz = nz - cz;
+            float y0 = a0 * crx + a1 * dx + a2 * cx, y1 = a0 * cry + a1 * dy + a2 * cy, y2 = a0 * crz + a1 * dz + a2 * cz;
+            const float k0 = d0 * crx + d1 * dx + d2 * cx, k1 = d0 * cry + d1 * dy + d2 * cy, k2 = d0 * crz + d1 * dz + d2 * cz;
+            vn_act(y0, y1, y2, k0, k1, k2, oms);
+            s0 += y0; s1 += y1; s2 += y2;
+        }
+        if (live && on) {
+            float* op = out + (size_t)pid * 3 * Co + oc;
+            op[0] = s0 * (1.0f / EK); op[Co] = s1 * (1.0f / EK); op[2 * Co] = s2 * (1.0f / EK);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- pool layers (i >= 1)
+__global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict__ T, int ldt, const int32_t* __restrict__ knn,
+                                                        const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
+                                                        float oms, float* __restrict__ out, int total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lpp = Co <= 32 ? 32 : 64;         // lanes per point
+    const int ppw = 64 / lpp;                   // points per wave
+    const int sub = lane / lpp, ol = lane % lpp;
+    int pid = (blockIdx.x * 4 + wave) * ppw + sub;
+    const bool live = pid < total;
+    if (!live) pid = total - 1;
+    const int b = pid / Nd;
+    const int drow = dst_rows ? dst_rows[pid] : (pid % Nd);
+    const float* Tb = T + (size_t)b * Ns * 3 * ldt;
+    const float* Td = Tb + (size_t)drow * 3 * ldt;
+    const int32_t* ki = knn + (size_t)pid * EK;
+    for (int c0 = 0; c0 < Co; c0 += lpp) {
+        const int oc = c0 + ol;
+        const bool on = oc < Co;
+        const int ow = on ? oc : 0;
+        float ql[3], qd[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { ql[x] = Td[x * ldt + 2 * Co + ow]; qd[x] = Td[x * ldt + 3 * Co + ow]; }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < EK; ++k) {
+            const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
+            float y0 = Tr[ow] + ql[0], y1 = Tr[ldt + ow] + ql[1], y2 = Tr[2 * ldt + ow] + ql[2];
+            const float k0 = Tr[Co + ow] + qd[0], k1 = Tr[ldt + Co + ow] + qd[1], k2 = Tr[2 * ldt + Co + ow] + qd[2];
+            vn_act(y0, y1, y2, k0, k1, k2, oms);
+            s0 += y0; s1 += y1; s2 += y2;
+        }
+        if (live && on) {
+            float* op = out + (size_t)pid * 3 * Co + oc;
+            op[0] = s0 * (1.0f / EK); op[Co] = s1 * (1.0f / EK); op[2 * Co] = s2 * (1.0f / EK);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- attention layers
+// dynamic LDS per wave: q feature [3][Co] | head scores [Co/16][16] | attention weights [Co/16][16]
+__global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict__ T, int ldt, const int32_t* __restrict__ knn,
+                                                        const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
+                                                        float oms, float inv_sqrt_dk, float* __restrict__ out, int total) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nh = Co / 16;
+    const int per_wave = 3 * Co + 2 * nh * EK;
+    float* lq = smem + (size_t)wave * per_wave;
+    float* lscore = lq + 3 * Co;
+    float* latt = lscore + nh * EK;
+    int pid = blockIdx.x * 4 + wave;
+    const bool live = pid < total;
+    if (!live) pid = total - 1;
+    const int b = pid / Nd;
+    const int drow = dst_rows ? dst_rows[pid] : (pid % Nd);
+    const float* Tb = T + (size_t)b * Ns * 3 * ldt;
+    const float* Td = Tb + (size_t)drow * 3 * ldt;
+    const int32_t* ki = knn + (size_t)pid * EK;
+    int nbr[EK];
+#pragma unroll
+    for (int k = 0; k < EK; ++k) nbr[k] = ki[k];
+
+    // ---- A: q = cevn(VecLNA_Q(dst_f[n]))  (vec_dgcnn_atten.py:207,210)
+    float ssq = 0.f;
+    for (int c0 = 0; c0 < Co; c0 += 64) {
+        const int oc = c0 + lane;
+        if (oc < Co) {
+            float y0 = Td[8 * Co + oc], y1 = Td[ldt + 8 * Co + oc], y2 = Td[2 * ldt + 8 * Co + oc];
+            const float k0 = Td[9 * Co + oc], k1 = Td[ldt + 9 * Co + oc], k2 = Td[2 * ldt + 9 * Co + oc];
+            vn_act(y0, y1, y2, k0, k1, k2, oms);
+            lq[oc] = y0; lq[Co + oc] = y1; lq[2 * Co + oc] = y2;
+            ssq += y0 * y0 + y1 * y1 + y2 * y2;
+        }
+    }
+    const float inv_q = 1.0f / fmaxf(sqrtf(wave_sum(ssq)), 1e-12f);
+    __syncthreads();
+
+    // ---- B: k = cevn(VecLNA_K(E)),  head scores  sum_{c in head} <k_c, q_c>  (:206,209,211-215)
+    float ssk[EK];
+#pragma unroll
+    for (int k = 0; k < EK; ++k) ssk[k] = 0.f;
+    for (int c0 = 0; c0 < Co; c0 += 64) {
+        const int oc = c0 + lane;
+        const bool on = oc < Co;
+        const int ow = on ? oc : 0;
+        float ql[3], qd[3], qv[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            ql[x] = Td[x * ldt + 6 * Co + ow];
+            qd[x] = Td[x * ldt + 7 * Co + ow];
+            qv[x] = lq[x * Co + ow];
+        }
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            const float* Tr = Tb + (size_t)nbr[k] * 3 * ldt;
+            float y0 = Tr[2 * Co + ow] + ql[0], y1 = Tr[ldt + 2 * Co + ow] + ql[1], y2 = Tr[2 * ldt + 2 * Co + ow] + ql[2];
+            const float k0 = Tr[3 * Co + ow] + qd[0], k1 = Tr[ldt + 3 * Co + ow] + qd[1], k2 = Tr[2 * ldt + 3 * Co + ow] + qd[2];
+            vn_act(y0, y1, y2, k0, k1, k2, oms);
+            float a = y0 * qv[0] + y1 * qv[1] + y2 * qv[2];
+            float s2 = y0 * y0 + y1 * y1 + y2 * y2;
+            if (!on) { a = 0.f; s2 = 0.f; }
+            ssk[k] += s2;
+            const float hs = row16_sum(a);
+            if (on && (lane & 15) == 0) lscore[(oc >> 4) * EK + k] = hs;
+        }
+    }
+    // Frobenius norm of the K feature at every neighbour; lane l keeps the one for k = l & 15
+    float my_invk = 0.f;
+#pragma unroll
+    for (int k = 0; k < EK; ++k) {
+        const float f = 1.0f / fmaxf(sqrtf(wave_sum(ssk[k])), 1e-12f);
+        if ((lane & 15) == k) my_invk = f;
+    }
+    __syncthreads();
+    // soft-max over the K neighbours per head (:214-215)
+    for (int e0 = 0; e0 < nh * EK; e0 += 64) {
+        const int e = e0 + lane;
+        const bool on = e < nh * EK;
+        float v = on ? lscore[e] * inv_q * my_invk * inv_sqrt_dk : -INFINITY;
+        const float m = row16_max(v);
+        const float ex = on ? expf(v - m) : 0.f;
+        const float s = row16_sum(ex);
+        if (on) latt[e] = ex / s;
+    }
+    __syncthreads();
+
+    // ---- C: out = sum_k atten * VecLNA_V(E)  (:208,216-219)
+    for (int c0 = 0; c0 < Co; c0 += 64) {
+        const int oc = c0 + lane;
+        const bool on = oc < Co;
+        const int ow = on ? oc : 0;
+        float ql[3], qd[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { ql[x] = Td[x * ldt + 4 * Co + ow]; qd[x] = Td[x * ldt + 5 * Co + ow]; }
+        const float* aw = latt + (ow >> 4) * EK;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            const float* Tr = Tb + (size_t)nbr[k] * 3 * ldt;
+            float y0 = Tr[ow] + ql[0], y1 = Tr[ldt + ow] + ql[1], y2 = Tr[2 * ldt + ow] + ql[2];
+            const float k0 = Tr[Co + ow] + qd[0], k1 = Tr[ldt + Co + ow] + qd[1], k2 = Tr[2 * ldt + Co + ow] + qd[2];
+            vn_act(y0, y1, y2, k0, k1, k2, oms);
+            const float w = aw[k];
+            s0 += w * y0; s1 += w * y1; s2 += w * y2;
+        }
+        if (live && on) {
+            float* op = out + (size_t)pid * 3 * Co + oc;
+            op[0] = s0; op[Co] = s1; op[2 * Co] = s2;
+        }
+    }
+}
+
+int edge_l0_launch(const float* pts, const int32_t* knn, const float* w0, int B, int N, int Co, float neg_slope, float* out,
+                   hipStream_t st) {
+    const int total = B * N;
+    hipLaunchKernelGGL(edge_l0_kernel, dim3(cdiv(total, 8)), dim3(256), 0, st, pts, knn, w0, N, Co, 1.0f - neg_slope, out, total);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+int edge_pool_launch(const float* T, int ldt, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns, int Co,
+                     float neg_slope, float* out, hipStream_t st) {
+    const int total = B * Nd;
+    const int ppb = (Co <= 32) ? 8 : 4;
+    hipLaunchKernelGGL(edge_pool_kernel, dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, knn, dst_rows, Nd, Ns, Co,
+                       1.0f - neg_slope, out, total);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+int edge_attn_launch(const float* T, int ldt, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns, int Co,
+                     int head_c, float neg_slope, float* out, hipStream_t st) {
+    LS_REQUIRE(head_c == 16 && Co % 16 == 0, "edge_attn: head width must be 16 and divide Co (head_c=%d Co=%d)", head_c, Co);
+    const int total = B * Nd;
+    const size_t smem = (size_t)4 * (3 * Co + 2 * (Co / 16) * EK) * sizeof(float);
+    LS_REQUIRE(smem <= 64 * 1024, "edge_attn: Co=%d too wide", Co);
+    hipLaunchKernelGGL(edge_attn_kernel, dim3(cdiv(total, 4)), dim3(256), smem, st, T, ldt, knn, dst_rows, Nd, Ns, Co,
+                       1.0f - neg_slope, 1.0f / sqrtf(3.0f * head_c), out, total);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+}  // namespace ls

@@ -1,0 +1,182 @@
+// fps.hip -- farthest point sampling, bit-exact w.r.t. oracle/ls_oracle.c (lso_fps).
+//
+// Replaces pytorch3d.ops.sample_farthest_points(points, K=.., random_start_point=False) as called at
+//   /root/reference/lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:169   (1024->512->128->32 inside the encoder)
+//   /root/reference/model_utils.py:205, lib_more/more_solver.py:67,107,108      (raw instance cloud -> 1024)
+//
+// FPS is a chain of K dependent arg-max steps: latency-bound, no data reuse to exploit.  Two shapes:
+//   * fps_wave_kernel: ONE WAVE per instance, the cloud and its running min-distance live in VGPRs
+//     (<= 64 points per lane), so a step is ~PPL*8 VALU ops + a 6-stage shuffle arg-max + one broadcast
+//     LDS read and needs NO barrier at all.  Four instances share a CU (one per SIMD).  Used for N <= 4096.
+//   * fps_block_kernel: 1024 threads per instance, min-distances in VGPRs (<= 64 per thread), points
+//     re-read from L2 each step, two-level (wave shuffle + LDS) arg-max.  Used for raw clouds up to 65536 pts.
+// Tie rule everywhere: larger value wins, equal values -> smaller index wins (== first arg-max).
+#include "ls_common.h"
+
+namespace ls {
+
+template <bool FMA>
+__device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    float d = 0.0f;
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    if constexpr (FMA) {
+        d = __builtin_fmaf(dx, dx, d); d = __builtin_fmaf(dy, dy, d); d = __builtin_fmaf(dz, dz, d);
+    } else {
+        float p = dx * dx; d = d + p;
+        p = dy * dy; d = d + p;
+        p = dz * dz; d = d + p;
+    }
+    return d;
+}
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+template <int PPL, bool FMA>
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
+                                                      int N, int K, int32_t* __restrict__ idx_out,
+                                                      float* __restrict__ pts_out) {
+    extern __shared__ __attribute__((aligned(16))) float lp[];  // [N][3]
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* p = pts + (size_t)b * N * 3;
+    const int n = lengths ? min(lengths[b], N) : N;
+    for (int t = lane; t < N * 3; t += 64) lp[t] = p[t];
+    __syncthreads();
+    float px[PPL], py[PPL], pz[PPL], md[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int j = i * 64 + lane;
+        const bool ok = j < n;
+        px[i] = ok ? lp[j * 3 + 0] : 0.f;
+        py[i] = ok ? lp[j * 3 + 1] : 0.f;
+        pz[i] = ok ? lp[j * 3 + 2] : 0.f;
+        md[i] = ok ? INFINITY : -INFINITY;  // padding can never win an arg-max
+    }
+    int32_t* out = idx_out + (size_t)b * K;
+    float* po = pts_out ? pts_out + (size_t)b * K * 3 : nullptr;
+    int last = 0;
+    const int kk = min(K, n);
+    if (lane == 0 && n > 0) {
+        out[0] = 0;
+        if (po) { po[0] = lp[0]; po[1] = lp[1]; po[2] = lp[2]; }
+    }
+    for (int k = 1; k < kk; ++k) {
+        const float lx = lp[last * 3 + 0], ly = lp[last * 3 + 1], lz = lp[last * 3 + 2];
+        float bv = -INFINITY;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const float d = dist3<FMA>(lx, ly, lz, px[i], py[i], pz[i]);
+            const float m = fminf(md[i], d);
+            md[i] = (md[i] == -INFINITY) ? md[i] : m;
+            if (md[i] > bv) { bv = md[i]; bi = i * 64 + lane; }  // ascending index inside the lane: strict '>'
+        }
+        wave_argmax(bv, bi);
+        last = bi;
+        if (lane == 0) {
+            out[k] = bi;
+            if (po) { po[k * 3 + 0] = lp[bi * 3 + 0]; po[k * 3 + 1] = lp[bi * 3 + 1]; po[k * 3 + 2] = lp[bi * 3 + 2]; }
+        }
+    }
+    for (int k = max(kk, 0) + lane; k < K; k += 64) {
+        out[k] = -1;
+        if (po) { po[k * 3 + 0] = 0.f; po[k * 3 + 1] = 0.f; po[k * 3 + 2] = 0.f; }
+    }
+}
+
+template <int PPT, bool FMA>
+__global__ __launch_bounds__(1024) void fps_block_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
+                                                         int N, int K, int32_t* __restrict__ idx_out,
+                                                         float* __restrict__ pts_out) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int s_last;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = pts + (size_t)b * N * 3;
+    const int n = lengths ? min(lengths[b], N) : N;
+    float md[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) md[i] = (i * 1024 + tid) < n ? INFINITY : -INFINITY;
+    int32_t* out = idx_out + (size_t)b * K;
+    float* po = pts_out ? pts_out + (size_t)b * K * 3 : nullptr;
+    const int kk = min(K, n);
+    if (tid == 0 && n > 0) {
+        out[0] = 0;
+        if (po) { po[0] = p[0]; po[1] = p[1]; po[2] = p[2]; }
+    }
+    int last = 0;
+    for (int k = 1; k < kk; ++k) {
+        const float lx = p[(size_t)last * 3 + 0], ly = p[(size_t)last * 3 + 1], lz = p[(size_t)last * 3 + 2];
+        float bv = -INFINITY;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int j = i * 1024 + tid;
+            if (j < n) {
+                const float d = dist3<FMA>(lx, ly, lz, p[(size_t)j * 3 + 0], p[(size_t)j * 3 + 1], p[(size_t)j * 3 + 2]);
+                md[i] = fminf(md[i], d);
+                if (md[i] > bv) { bv = md[i]; bi = j; }
+            }
+        }
+        wave_argmax(bv, bi);
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+        __syncthreads();
+        if (wave == 0) {
+            float v = lane < 16 ? sv[lane] : -INFINITY;
+            int i2 = lane < 16 ? si[lane] : INT_MAX;
+            wave_argmax(v, i2);
+            if (lane == 0) {
+                s_last = i2;
+                out[k] = i2;
+                if (po) { po[k * 3 + 0] = p[(size_t)i2 * 3 + 0]; po[k * 3 + 1] = p[(size_t)i2 * 3 + 1]; po[k * 3 + 2] = p[(size_t)i2 * 3 + 2]; }
+            }
+        }
+        __syncthreads();
+        last = s_last;
+    }
+    for (int k = max(kk, 0) + tid; k < K; k += 1024) {
+        out[k] = -1;
+        if (po) { po[k * 3 + 0] = 0.f; po[k * 3 + 1] = 0.f; po[k * 3 + 2] = 0.f; }
+    }
+}
+
+template <int PPL, bool FMA>
+static int launch_wave(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
+    hipLaunchKernelGGL((fps_wave_kernel<PPL, FMA>), dim3(B), dim3(64), (size_t)N * 3 * sizeof(float), st, pts, lengths, N, K, idx, po);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+template <int PPT, bool FMA>
+static int launch_block(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
+    hipLaunchKernelGGL((fps_block_kernel<PPT, FMA>), dim3(B), dim3(1024), 0, st, pts, lengths, N, K, idx, po);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+template <bool FMA>
+static int fps_mode(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
+    if (N <= 128) return launch_wave<2, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 512) return launch_wave<8, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 1024) return launch_wave<16, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 2048) return launch_wave<32, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 8192) return launch_block<8, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 65536) return launch_block<64, FMA>(pts, lengths, B, N, K, idx, po, st);
+    set_error("fps: N=%d too large (max 65536)", N);
+    return LS_ERR_INVALID;
+}
+
+int fps_dispatch(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out,
+                 float* pts_out, hipStream_t st) {
+    LS_REQUIRE(B > 0 && N > 0 && K > 0, "fps: empty problem (B=%d N=%d K=%d)", B, N, K);
+    return (flags & LS_FLAG_CONTRACT_FMA) ? fps_mode<true>(pts, lengths, B, N, K, idx_out, pts_out, st)
+                                          : fps_mode<false>(pts, lengths, B, N, K, idx_out, pts_out, st);
+}
+
+}  // namespace ls

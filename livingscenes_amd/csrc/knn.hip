@@ -1,0 +1,224 @@
+// knn.hip -- feature-space K-nearest-neighbour graph build (K <= 16), bit-exact w.r.t. oracle/ls_oracle.c.
+//
+// Replaces pytorch3d.ops.knn_points as called at
+//   /root/reference/lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:139-141
+//
+// Data layout (HBM): features [B, N, 3, C] fp32 ("x-major rows").  Canonical distance
+//   d(q,s) = sum_{c=0..C-1} sum_{x=0..2} (q[x][c]-s[x][c])^2   accumulated sequentially in that order
+// (the reference flattens [B,C,3,N] -> [B,3C,N], so j = c*3+x), each term rounded per the FMA flag.
+//
+// Kernel shape (wave64, 256 threads = 4 waves per workgroup):
+//   * a workgroup owns 64 queries of one instance and streams the instance's candidates in tiles of 64;
+//   * both tiles are staged through LDS in channel chunks of CC (32 channels = 96 dims), rows padded to
+//     100 floats so the 16-lane groups of ds_read_b128 hit 16 distinct 16-B bank slots (row stride/4 odd);
+//   * each thread owns a 4x4 (query x candidate) register micro-tile: 24 ds_read_b128 feed 192 pair-dims;
+//   * the 64x64 distance tile goes back to LDS and each wave merges 16 query rows into per-query sorted
+//     top-K lists that live in lanes 0..K-1 of two VGPRs (dist, idx): a ballot finds candidates that beat
+//     the current K-th entry under the lexicographic (dist, idx) order, and each survivor is inserted with
+//     one ballot (position) + one DPP row shift -- no LDS, no divergence beyond a wave-uniform loop.
+//   * blockIdx is remapped so that the tiles of one instance run on one XCD and share its L2.
+// Roofline: VALU-bound (3 VALU ops per pair-dim without FMA, 2 with): algorithmic bytes per instance-layer
+// are (Nd+Ns)*3C*4 + Nd*K*4, three orders of magnitude below the VALU time.
+#include "ls_common.h"
+
+namespace ls {
+
+constexpr int KNN_TQ = 64;   // queries per workgroup
+constexpr int KNN_TS = 64;   // candidates per tile
+constexpr int KNN_MAXK = 16;
+
+template <bool FMA>
+__device__ __forceinline__ float accq(float d, float a, float b) {
+#pragma clang fp contract(off)
+    const float diff = a - b;
+    if constexpr (FMA) {
+        return __builtin_fmaf(diff, diff, d);
+    } else {
+        const float p = diff * diff;
+        return d + p;
+    }
+}
+
+// CC = channels per LDS chunk (32, or 1 for raw xyz clouds where C == 1)
+template <int CC, bool FMA>
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+                                                  const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int C,
+                                                  int K, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+                                                  int qtiles) {
+    constexpr int ROW = (CC == 1) ? 4 : (3 * CC + 4);  // floats per staged row
+    __shared__ __attribute__((aligned(16))) float lq[KNN_TQ * ROW];
+    __shared__ __attribute__((aligned(16))) float lc[KNN_TS * ROW];
+    __shared__ float ldist[KNN_TQ * (KNN_TS + 1)];
+    __shared__ int lqrow[KNN_TQ];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = logical / qtiles, qt = logical % qtiles;
+    const int q0 = qt * KNN_TQ;
+    const size_t row_f = (size_t)3 * C;
+    const float* dbase = dstf + (size_t)b * dst_n * row_f;
+    const float* sbase = srcf + (size_t)b * Ns * row_f;
+
+    if (tid < KNN_TQ) {
+        int q = q0 + tid;
+        int r = -1;
+        if (q < Nd) r = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
+        lqrow[tid] = r;
+    }
+    __syncthreads();
+
+    const int tx = tid & 15, ty = tid >> 4;  // candidates tx+16j, queries ty*4+i
+
+    // per-wave top-K lists for its 16 query rows: entry l of query qq lives in lane l of ld[qq]/li[qq]
+    float ld[16];
+    int li[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ld[i] = INFINITY; li[i] = INT_MAX; }
+
+    for (int s0 = 0; s0 < Ns; s0 += KNN_TS) {
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+
+        for (int c0 = 0; c0 < C; c0 += CC) {
+            __syncthreads();  // previous chunk / previous selection fully consumed
+            if constexpr (CC == 1) {
+                // raw clouds: 3 floats per point
+                for (int t = tid; t < KNN_TQ * 3; t += 256) {
+                    int r = t / 3, x = t % 3;
+                    int gr = lqrow[r];
+                    lq[r * ROW + x] = gr >= 0 ? dbase[(size_t)gr * 3 + x] : 0.0f;
+                    int s = s0 + r;
+                    lc[r * ROW + x] = s < Ns ? sbase[(size_t)s * 3 + x] : 0.0f;
+                }
+            } else {
+                constexpr int V4 = 3 * CC / 4;  // float4 per row-chunk
+                for (int t = tid; t < KNN_TQ * V4; t += 256) {
+                    int r = t / V4, v = t % V4;
+                    int x = v / (CC / 4), cc = (v % (CC / 4)) * 4;
+                    int gr = lqrow[r];
+                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gr >= 0) val = *reinterpret_cast<const float4*>(dbase + (size_t)gr * row_f + (size_t)x * C + c0 + cc);
+                    *reinterpret_cast<float4*>(&lq[r * ROW + x * CC + cc]) = val;
+                    int s = s0 + r;
+                    float4 vc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (s < Ns) vc = *reinterpret_cast<const float4*>(sbase + (size_t)s * row_f + (size_t)x * C + c0 + cc);
+                    *reinterpret_cast<float4*>(&lc[r * ROW + x * CC + cc]) = vc;
+                }
+            }
+            __syncthreads();
+            if constexpr (CC == 1) {
+                float qv[4][3], cv[4][3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        qv[i][x] = lq[(ty * 4 + i) * ROW + x];
+                        cv[i][x] = lc[(tx + 16 * i) * ROW + x];
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int x = 0; x < 3; ++x) acc[i][j] = accq<FMA>(acc[i][j], qv[i][x], cv[j][x]);
+            } else {
+#pragma unroll 2
+                for (int c4 = 0; c4 < CC; c4 += 4) {
+                    float4 qv[4][3], cv[4][3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int x = 0; x < 3; ++x) {
+                            qv[i][x] = *reinterpret_cast<const float4*>(&lq[(ty * 4 + i) * ROW + x * CC + c4]);
+                            cv[i][x] = *reinterpret_cast<const float4*>(&lc[(tx + 16 * i) * ROW + x * CC + c4]);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float a = acc[i][j];
+                            // canonical order: channel-major, xyz-minor
+                            a = accq<FMA>(a, qv[i][0].x, cv[j][0].x); a = accq<FMA>(a, qv[i][1].x, cv[j][1].x); a = accq<FMA>(a, qv[i][2].x, cv[j][2].x);
+                            a = accq<FMA>(a, qv[i][0].y, cv[j][0].y); a = accq<FMA>(a, qv[i][1].y, cv[j][1].y); a = accq<FMA>(a, qv[i][2].y, cv[j][2].y);
+                            a = accq<FMA>(a, qv[i][0].z, cv[j][0].z); a = accq<FMA>(a, qv[i][1].z, cv[j][1].z); a = accq<FMA>(a, qv[i][2].z, cv[j][2].z);
+                            a = accq<FMA>(a, qv[i][0].w, cv[j][0].w); a = accq<FMA>(a, qv[i][1].w, cv[j][1].w); a = accq<FMA>(a, qv[i][2].w, cv[j][2].w);
+                            acc[i][j] = a;
+                        }
+                }
+            }
+        }
+        // distance tile -> LDS (ldist is only read in the selection phase below, guarded by barriers)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ldist[(ty * 4 + i) * (KNN_TS + 1) + tx + 16 * j] = acc[i][j];
+        __syncthreads();
+
+        // ---- selection: wave `wave` merges candidates s0..s0+63 into its 16 query lists
+        const int cand = s0 + lane;
+        const bool cvalid = cand < Ns;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const float d = ldist[(wave * 16 + qq) * (KNN_TS + 1) + lane];
+            const float kd = __shfl(ld[qq], K - 1, 64);
+            const int ki = __shfl(li[qq], K - 1, 64);
+            const bool pass = cvalid && (d < kd || (d == kd && cand < ki));
+            unsigned long long mask = __ballot(pass);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float cd = __shfl(d, l, 64);
+                const int ci = s0 + l;
+                const bool less = (ld[qq] < cd) || (ld[qq] == cd && li[qq] < ci);
+                const int pos = __builtin_popcountll(__ballot(less) & ((1ull << K) - 1ull));
+                // shift entries >= pos up by one lane, drop the last, insert at pos
+                const float ud = __shfl_up(ld[qq], 1, 64);
+                const int ui = __shfl_up(li[qq], 1, 64);
+                if (lane == pos) { ld[qq] = cd; li[qq] = ci; }
+                else if (lane > pos) { ld[qq] = ud; li[qq] = ui; }
+            }
+        }
+    }
+
+    // ---- write the sorted lists
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+        const int q = q0 + wave * 16 + qq;
+        if (q < Nd && lane < K) {
+            const size_t o = ((size_t)b * Nd + q) * K + lane;
+            idx_out[o] = li[qq] == INT_MAX ? -1 : li[qq];
+            if (dist_out) dist_out[o] = ld[qq];
+        }
+    }
+}
+
+template <int CC, bool FMA>
+static int launch_knn(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
+                      int C, int K, int32_t* idx_out, float* dist_out, hipStream_t st) {
+    const int qtiles = cdiv(Nd, KNN_TQ);
+    dim3 grid(B * qtiles), block(256);
+    hipLaunchKernelGGL((knn_kernel<CC, FMA>), grid, block, 0, st, dst, src, dst_rows, Nd, dst_n, Ns, C, K, idx_out,
+                       dist_out, qtiles);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C,
+                 int K, unsigned flags, int32_t* idx_out, float* dist_out, hipStream_t st) {
+    LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0 && dst_n > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
+    LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
+    LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
+    const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
+    if (C == 1) {
+        return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st)
+                   : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st);
+    }
+    return fma ? launch_knn<32, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st)
+               : launch_knn<32, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st);
+}
+
+}  // namespace ls

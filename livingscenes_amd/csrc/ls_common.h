@@ -1,0 +1,95 @@
+// ls_common.h -- shared device/host helpers for liblivingscenes_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <float.h>
+#include <limits.h>
+
+#include "../../include/livingscenes_hip.h"
+
+namespace ls {
+
+void set_error(const char* fmt, ...);
+
+#define LS_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ls::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LS_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define LS_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            ls::set_error(__VA_ARGS__); \
+            return LS_ERR_INVALID;     \
+        }                              \
+    } while (0)
+
+#define LS_LAUNCH_CHECK()                                                            \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) {                                                      \
+            ls::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LS_ERR_HIP;                                                       \
+        }                                                                            \
+    } while (0)
+
+constexpr int kWave = 64;
+constexpr int kXcds = 8;
+
+// XCD-aware block remap (MI355X: block b is dispatched to XCD b % 8, each XCD has a private 4 MiB L2).
+// Returns a logical block id such that the blocks resident on one XCD cover a CONTIGUOUS range of logical
+// ids, so consecutive logical ids (tiles of the same instance) share an L2.  Bijective for any nblocks.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks / kXcds, r = nblocks % kXcds;
+    const int xcd = bid % kXcds, slot = bid / kXcds;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reductions inside aligned groups of 16 lanes (one attention head = 16 channels = one DPP row)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// canonical squared-difference accumulation (oracle/ls_oracle.c acc_sq)
+template <bool FMA>
+__device__ __forceinline__ float acc_sq(float d, float diff) {
+    if constexpr (FMA) return __fmaf_rn(diff, diff, d);
+    else return __fadd_rn(d, __fmul_rn(diff, diff));
+}
+
+// VN activation closed form (vec_layers.py:241-268): y - (1-slope) * min(<y,k^>,0) * k^,  k^ = k / max(|k|,1e-12)
+__device__ __forceinline__ void vn_act(float& y0, float& y1, float& y2, float k0, float k1, float k2, float one_minus_slope) {
+    const float nrm = sqrtf(k0 * k0 + k1 * k1 + k2 * k2);
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    k0 *= inv; k1 *= inv; k2 *= inv;
+    const float p = y0 * k0 + y1 * k1 + y2 * k2;
+    const float f = one_minus_slope * fminf(p, 0.0f);
+    y0 -= f * k0; y1 -= f * k1; y2 -= f * k2;
+}
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace ls

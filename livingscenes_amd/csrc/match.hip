@@ -1,0 +1,206 @@
+// match.hip -- instance matching and closed-form registration.
+//
+//   cosine_scores_kernel   F.normalize + m0 @ m1^T            /root/reference/lib_more/matcher_new.py:110-120
+//   greedy_match_kernel    the renormalise / first-arg-max / delete loop   matcher_new.py:121-136 (also :166-181, :212-227)
+//   kabsch_kernel          weighted Kabsch + residuals         /root/reference/lib_more/pose_estimation.py:29-121
+//
+// All three are launch-latency-bound at the reference's sizes (32x32 scores, 256-point pseudo clouds), so each is a
+// single launch over the whole batch: one workgroup for the matcher loop (no host round trips: the reference's
+// .nonzero() syncs every iteration), one WAVE per Kabsch problem with the 3x3 SVD done in registers.
+#include "ls_common.h"
+#include "svd3.h"
+
+namespace ls {
+
+// ---------------------------------------------------------------------------------------------- scores
+__global__ __launch_bounds__(256) void cosine_scores_kernel(const float* __restrict__ m0, const float* __restrict__ m1, int n,
+                                                            int m, int D, float* __restrict__ inv_norm, float* __restrict__ S,
+                                                            int phase) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (phase == 0) {  // one wave per row of [m0; m1]: 1 / max(|row|, 1e-12)
+        if (w >= n + m) return;
+        const float* r = w < n ? m0 + (size_t)w * D : m1 + (size_t)(w - n) * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += r[c] * r[c];
+        s = wave_sum(s);
+        if (lane == 0) inv_norm[w] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    } else {           // one wave per score entry
+        if (w >= n * m) return;
+        const int i = w / m, j = w % m;
+        const float* a = m0 + (size_t)i * D;
+        const float* b = m1 + (size_t)j * D;
+        const float ia = inv_norm[i], ib = inv_norm[n + j];
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += (a[c] * ia) * (b[c] * ib);
+        s = wave_sum(s);
+        if (lane == 0) S[w] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- greedy loop
+// S [n,m] in global (L2-resident), destroyed.  Deleted rows/columns are tracked with alive flags; "first
+// row-major arg-max of the shrunken matrix" == lexicographically smallest (row, col) among alive maxima.
+__global__ __launch_bounds__(1024) void greedy_match_kernel(float* __restrict__ S, int n, int m, long long* __restrict__ m0,
+                                                            long long* __restrict__ m1) {
+    extern __shared__ int alive[];  // [n] rows | [m] cols
+    __shared__ float redv[16];
+    __shared__ int redi[16];
+    __shared__ float s_max;
+    __shared__ int s_pos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* ra = alive;
+    int* ca = alive + n;
+    for (int i = tid; i < n; i += 1024) { ra[i] = 1; m0[i] = -1; }
+    for (int j = tid; j < m; j += 1024) { ca[j] = 1; m1[j] = -1; }
+    __syncthreads();
+    const int total = n * m;
+    const int iters = n < m ? n : m;
+    for (int it = 0; it < iters; ++it) {
+        // max over alive entries
+        float mx = -INFINITY;
+        for (int e = tid; e < total; e += 1024) {
+            const int i = e / m, j = e % m;
+            if (ra[i] && ca[j]) mx = fmaxf(mx, S[e]);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) redv[wave] = mx;
+        __syncthreads();
+        if (tid == 0) { float v = redv[0]; for (int k = 1; k < 16; ++k) v = fmaxf(v, redv[k]); s_max = v; }
+        __syncthreads();
+        const float denom = s_max + 1e-5f;
+        // S /= (max + 1e-5) (matcher_new.py:123), then max of the renormalised matrix
+        float mx2 = -INFINITY;
+        for (int e = tid; e < total; e += 1024) {
+            const int i = e / m, j = e % m;
+            if (ra[i] && ca[j]) { const float v = S[e] / denom; S[e] = v; mx2 = fmaxf(mx2, v); }
+        }
+        mx2 = wave_max(mx2);
+        __syncthreads();
+        if (lane == 0) redv[wave] = mx2;
+        __syncthreads();
+        if (tid == 0) { float v = redv[0]; for (int k = 1; k < 16; ++k) v = fmaxf(v, redv[k]); s_max = v; }
+        __syncthreads();
+        const float target = s_max;
+        int pos = INT_MAX;
+        for (int e = tid; e < total; e += 1024) {
+            const int i = e / m, j = e % m;
+            if (ra[i] && ca[j] && S[e] == target) { pos = e; break; }  // e ascending per thread
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pos = min(pos, __shfl_xor(pos, o, 64));
+        if (lane == 0) redi[wave] = pos;
+        __syncthreads();
+        if (tid == 0) {
+            int p = redi[0];
+            for (int k = 1; k < 16; ++k) p = min(p, redi[k]);
+            s_pos = p;
+            if (p != INT_MAX) {
+                const int i = p / m, j = p % m;
+                m0[i] = j; m1[j] = i;
+                ra[i] = 0; ca[j] = 0;
+            }
+        }
+        __syncthreads();
+        if (s_pos == INT_MAX) break;  // NaN scores: the reference would raise here
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Kabsch
+// one wave per problem; problem p pairs cloud x1[i1(p)] with x2[i2(p)]:
+//   pair_mode 0: i1 = i2 = p (batched Kabsch);  pair_mode 1: p = i*m + j -> (i, j) (residual matrix)
+__global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                     const float* __restrict__ weights, int nprob, int n, int pair_m,
+                                                     float eps, float* __restrict__ Rout, float* __restrict__ tout,
+                                                     float* __restrict__ res, float* __restrict__ res_mean,
+                                                     int32_t* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= nprob) return;
+    const int i1 = pair_m > 0 ? p / pair_m : p, i2 = pair_m > 0 ? p % pair_m : p;
+    const float* a = x1 + (size_t)i1 * n * 3;
+    const float* b = x2 + (size_t)i2 * n * 3;
+    const float* w = weights ? weights + (size_t)p * n : nullptr;
+    // weights / (sum + eps)   (pose_estimation.py:52-54)
+    float sw = 0.f;
+    for (int i = lane; i < n; i += 64) sw += w ? w[i] : 1.0f;
+    sw = wave_sum(sw) + eps;
+    // weighted means, divided by (sum of normalised weights + eps)  (:68-69)
+    float m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0}, swn = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const float wi = (w ? w[i] : 1.0f) / sw;
+        swn += wi;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { m1[x] += wi * a[i * 3 + x]; m2[x] += wi * b[i * 3 + x]; }
+    }
+    swn = wave_sum(swn) + eps;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { m1[x] = wave_sum(m1[x]) / swn; m2[x] = wave_sum(m2[x]) / swn; }
+    // covariance H = sum_i w_i (x1_i - mu1)(x2_i - mu2)^T   (:71-77)
+    float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = lane; i < n; i += 64) {
+        const float wi = (w ? w[i] : 1.0f) / sw;
+        float c1[3], c2[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { c1[x] = a[i * 3 + x] - m1[x]; c2[x] = b[i * 3 + x] - m2[x]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) H[r * 3 + c] += wi * c1[r] * c2[c];
+    }
+    double Hd[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Hd[e] = (double)wave_sum(H[e]);
+    float R[9];
+    bool ok = kabsch_rotation(Hd, R);
+    float t[3];
+    if (!ok) {  // SVD-failure branch of the reference (:79-88): identity rotation, zero translation
+#pragma unroll
+        for (int e = 0; e < 9; ++e) R[e] = (e % 4 == 0) ? 1.f : 0.f;
+        t[0] = t[1] = t[2] = 0.f;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[r] = m2[r] - (R[r * 3] * m1[0] + R[r * 3 + 1] * m1[1] + R[r * 3 + 2] * m1[2]);
+    }
+    if (lane == 0) {
+        if (Rout) for (int e = 0; e < 9; ++e) Rout[(size_t)p * 9 + e] = R[e];
+        if (tout) for (int e = 0; e < 3; ++e) tout[(size_t)p * 3 + e] = t[e];
+        if (flags) flags[p] = ok ? 0 : 1;
+    }
+    // residuals |R x1 + t - x2|   (:105-121)
+    float rs = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        float e2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float d = R[r * 3] * a[i * 3] + R[r * 3 + 1] * a[i * 3 + 1] + R[r * 3 + 2] * a[i * 3 + 2] + t[r] - b[i * 3 + r];
+            e2 += d * d;
+        }
+        const float e = sqrtf(e2);
+        if (res) res[(size_t)p * n + i] = e;
+        rs += e;
+    }
+    if (res_mean) { rs = wave_sum(rs); if (lane == 0) res_mean[p] = rs / (float)n; }
+}
+
+int cosine_scores_launch(const float* m0, const float* m1, int n, int m, int D, float* inv_norm_ws, float* S, hipStream_t st) {
+    hipLaunchKernelGGL(cosine_scores_kernel, dim3(cdiv(n + m, 4)), dim3(256), 0, st, m0, m1, n, m, D, inv_norm_ws, S, 0);
+    hipLaunchKernelGGL(cosine_scores_kernel, dim3(cdiv((long long)n * m, 4)), dim3(256), 0, st, m0, m1, n, m, D, inv_norm_ws, S, 1);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int greedy_match_launch(float* S, int n, int m, long long* m0, long long* m1, hipStream_t st) {
+    LS_REQUIRE((size_t)(n + m) * sizeof(int) <= 48 * 1024, "greedy_match: n+m=%d too large", n + m);
+    hipLaunchKernelGGL(greedy_match_kernel, dim3(1), dim3(1024), (size_t)(n + m) * sizeof(int), st, S, n, m, m0, m1);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int kabsch_launch(const float* x1, const float* x2, const float* w, int nprob, int n, int pair_m, float* R, float* t,
+                  float* res, float* res_mean, int32_t* flags, hipStream_t st) {
+    hipLaunchKernelGGL(kabsch_kernel, dim3(cdiv(nprob, 4)), dim3(256), 0, st, x1, x2, w, nprob, n, pair_m, 1e-7f, R, t, res,
+                       res_mean, flags);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+}  // namespace ls

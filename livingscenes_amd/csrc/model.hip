@@ -1,0 +1,388 @@
+// model.hip -- the C ABI: model handle, leaf-operator exports and the two composite hot-path entry points
+// (ls_encode = Shape_Prior.encode, ls_sdf_decode = FieldWrapper.forward).  Host code only enqueues work on the
+// caller's stream (plus one library-owned side stream for the FPS chain); it never synchronises the device.
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+#include "ls_common.h"
+
+namespace ls {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// kernels / launchers defined in the other translation units
+int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, hipStream_t);
+int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
+int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
+int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
+int edge_pool_launch(const float*, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
+int edge_attn_launch(const float*, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
+int prologue_launch(const float*, int, int, float*, float*, float*, hipStream_t);
+int transpose_cloud_launch(const float*, int, int, float*, hipStream_t);
+int mean_points_launch(const float*, int, int, int, float*, hipStream_t);
+int vn_act_rows_launch(const float*, int, const float*, int, int, int, int, float, float*, hipStream_t);
+int tail_launch(const float*, int, int, int, int, const float*, const float*, const float*, float, float, int, int, const float*,
+                const float*, float*, float*, float*, float*, hipStream_t);
+int sdf_prep_launch(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, float*,
+                    float*, hipStream_t);
+int sdf_affine_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
+                      hipStream_t);
+int sdf_out_launch(const float*, int, int, const float*, const float*, long long, float*, hipStream_t);
+int cosine_scores_launch(const float*, const float*, int, int, int, float*, float*, hipStream_t);
+int greedy_match_launch(float*, int, int, long long*, long long*, hipStream_t);
+int kabsch_launch(const float*, const float*, const float*, int, int, int, float*, float*, float*, float*, int32_t*, hipStream_t);
+size_t icp_workspace_bytes(int b, int n);
+int icp_run(const float*, const float*, const float*, const float*, int, int, int, int, float, unsigned, float*, float*, float*,
+            int32_t*, void*, size_t, hipStream_t);
+
+}  // namespace ls
+
+using namespace ls;
+
+struct ls_model {
+    ls_model_desc d;
+    float* blob = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float* scratch = nullptr;  // small device scratch for the matcher (inverse norms)
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------ plan
+struct EncPlan {
+    int L = 0;
+    int Ns[LS_MAX_LAYERS], Nd[LS_MAX_LAYERS], Cin[LS_MAX_LAYERS], Co[LS_MAX_LAYERS], ncols[LS_MAX_LAYERS], level[LS_MAX_LAYERS];
+    int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
+    int NP = 0, Cdp = 0;
+    // workspace offsets (bytes)
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_knn, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
+};
+
+static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
+    LS_REQUIRE(d.num_layers >= 2 && d.num_layers <= LS_MAX_LAYERS, "encoder: num_layers=%d unsupported", d.num_layers);
+    p.L = d.num_layers;
+    int cur = N;
+    p.nlevels = 0;
+    p.levelN[0] = N;
+    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0;
+    for (int i = 0; i < p.L; ++i) {
+        p.Ns[i] = cur;
+        const int f = d.down_factor[i] > 1 ? d.down_factor[i] : 1;
+        p.level[i] = -1;
+        if (f > 1) {
+            LS_REQUIRE(i > 0, "encoder: down-sampling at layer 0 unsupported");
+            p.level[i] = p.nlevels;
+            p.nlevels++;
+            cur = cur / f;
+            p.levelN[p.nlevels] = cur;
+        }
+        p.Nd[i] = cur;
+        LS_REQUIRE(cur >= 1, "encoder: N=%d too small for the down-sampling schedule", N);
+        p.Cin[i] = i == 0 ? 1 : d.feat_dim[i - 1];
+        p.Co[i] = d.feat_dim[i];
+        const bool attn = i >= d.atten_start_layer;
+        p.ncols[i] = i == 0 ? 0 : (attn ? 10 : 4) * p.Co[i];
+        LS_REQUIRE(p.Co[i] % 16 == 0, "encoder: feat_dim[%d]=%d must be a multiple of 16", i, p.Co[i]);
+        if (i > 0) LS_REQUIRE(p.Cin[i] % 32 == 0, "encoder: feat_dim[%d]=%d must be a multiple of 32 (k-NN chunking)", i - 1, p.Cin[i]);
+        maxF = std::max(maxF, (size_t)p.Nd[i] * 3 * p.Co[i]);
+        maxT = std::max(maxT, (size_t)p.Ns[i] * 3 * p.ncols[i]);
+        maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
+        maxC = std::max(maxC, (size_t)p.Co[i]);
+        maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
+    }
+    LS_REQUIRE(d.num_knn == 16, "encoder: num_knn=%d unsupported (16)", d.num_knn);
+    LS_REQUIRE(p.Ns[p.L - 1] >= 1, "encoder: bad schedule");
+    p.NP = cur;
+    p.Cdp = (int)align_up((size_t)d.c_dim + 1, 4);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    for (int l = 0; l <= p.nlevels; ++l) {
+        p.o_pts[l] = take((size_t)B * p.levelN[l] * 3 * 4);
+        p.o_fps[l] = take((size_t)B * p.levelN[l] * 4);
+    }
+    p.o_centroid = take((size_t)B * 3 * 4);
+    p.o_scale0 = take((size_t)B * 4);
+    p.o_knn = take((size_t)B * maxKnn * 4);
+    p.o_fA = take((size_t)B * maxF * 4);
+    p.o_fB = take((size_t)B * maxF * 4);
+    p.o_msg = take((size_t)B * maxF * 4);
+    p.o_T = take((size_t)B * maxT * 4);
+    p.o_TG = take((size_t)B * maxTG * 4);
+    p.o_g = take((size_t)B * 3 * maxC * 4);
+    p.o_G = take((size_t)B * 3 * 4 * maxC * 4);
+    p.o_Tc = take((size_t)B * p.NP * 3 * p.Cdp * 4);
+    p.total = off;
+    return LS_OK;
+}
+
+extern "C" {
+
+int ls_version(void) { return 100; }
+const char* ls_last_error(void) { return g_err; }
+
+int ls_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return LS_ERR_NO_DEVICE; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ leaf exports
+int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K,
+               unsigned flags, int32_t* idx_out, float* dist_out, void* stream) {
+    return knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, (hipStream_t)stream);
+}
+int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out, float* pts_out,
+               void* stream) {
+    return fps_dispatch(pts, lengths, B, N, K, flags, idx_out, pts_out, (hipStream_t)stream);
+}
+int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
+                int relu, void* stream) {
+    return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream);
+}
+int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out, void* stream) {
+    return prologue_launch(x, B, N, pts_out, centroid_out, scale0_out, (hipStream_t)stream);
+}
+int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* stream) {
+    LS_REQUIRE(n > 0 && m > 0 && D > 0, "cosine_scores: empty problem");
+    // inverse norms are staged behind the score matrix tail: scores buffer must hold n*m + n + m floats? no:
+    // keep the ABI simple -- use a small library-owned scratch per call via hipMallocAsync on the stream.
+    float* scratch = nullptr;
+    LS_HIP_CHECK(hipMallocAsync((void**)&scratch, (size_t)(n + m) * sizeof(float), (hipStream_t)stream));
+    int rc = cosine_scores_launch(m0, m1, n, m, D, scratch, scores, (hipStream_t)stream);
+    LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
+    return rc;
+}
+int ls_greedy_match_f32(float* scores, int n, int m, int64_t* matches0, int64_t* matches1, void* stream) {
+    LS_REQUIRE(n > 0 && m > 0, "greedy_match: empty problem");
+    return greedy_match_launch(scores, n, m, (long long*)matches0, (long long*)matches1, (hipStream_t)stream);
+}
+int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, float* R, float* t, float* res,
+                          int32_t* flags_out, void* stream) {
+    LS_REQUIRE(b > 0 && n > 0, "kabsch: empty problem");
+    return kabsch_launch(x1, x2, weights, b, n, 0, R, t, res, nullptr, flags_out, (hipStream_t)stream);
+}
+int ls_kabsch_residual_matrix_f32(const float* src, const float* tgt, int n, int m, int P, float* res, void* stream) {
+    LS_REQUIRE(n > 0 && m > 0 && P > 0, "kabsch_residual_matrix: empty problem");
+    return kabsch_launch(src, tgt, nullptr, n * m, P, m, nullptr, nullptr, nullptr, res, nullptr, (hipStream_t)stream);
+}
+size_t ls_icp_workspace_bytes(int b, int n) { return icp_workspace_bytes(b, n); }
+int ls_icp_f32(const float* X, const float* Y, const float* R0, const float* T0, int b, int n, int m, int max_iter,
+               float rel_rmse_thr, unsigned flags, float* R, float* T, float* rmse, int32_t* iters_out, void* workspace,
+               size_t workspace_bytes, void* stream) {
+    return icp_run(X, Y, R0, T0, b, n, m, max_iter, rel_rmse_thr, flags, R, T, rmse, iters_out, workspace, workspace_bytes,
+                   (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ model
+int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_t** out) {
+    LS_REQUIRE(desc && blob_host && out, "model_create: null argument");
+    LS_REQUIRE(desc->blob_floats > 0, "model_create: empty blob");
+    ls_model* m = new ls_model();
+    m->d = *desc;
+    hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
+    if (e != hipSuccess) { delete m; set_error("hipMalloc(model blob): %s", hipGetErrorString(e)); return LS_ERR_HIP; }
+    e = hipMemcpy(m->blob, blob_host, (size_t)desc->blob_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
+    *out = m;
+    return LS_OK;
+}
+
+void ls_model_destroy(ls_model_t* m) {
+    if (!m) return;
+    if (m->blob) (void)hipFree(m->blob);
+    if (m->side) (void)hipStreamDestroy(m->side);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    delete m;
+}
+
+size_t ls_encoder_workspace_bytes(const ls_model_t* m, int B, int N) {
+    if (!m) return 0;
+    EncPlan p;
+    if (make_plan(m->d, B, N, p) != LS_OK) return 0;
+    return p.total;
+}
+
+int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, unsigned flags, float* z_so3, float* z_inv,
+              float* s_out, float* t_out, int32_t* trace_knn, int32_t* trace_fps, void* workspace, size_t workspace_bytes,
+              void* stream) {
+    LS_REQUIRE(m && x && z_so3 && z_inv && s_out && t_out && workspace, "encode: null argument");
+    LS_REQUIRE(B > 0 && N >= 16, "encode: need B>0, N>=16 (B=%d N=%d)", B, N);
+    const ls_model_desc& d = m->d;
+    EncPlan p;
+    int rc = make_plan(d, B, N, p);
+    if (rc != LS_OK) return rc;
+    if (workspace_bytes < p.total) { set_error("encode: workspace %zu < required %zu", workspace_bytes, p.total); return LS_ERR_WORKSPACE; }
+    LS_REQUIRE(p.Ns[p.L - 1] >= 16 || true, "unreachable");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto F = [&](size_t o) { return (float*)(ws + o); };
+    auto I = [&](size_t o) { return (int32_t*)(ws + o); };
+    const float* W = m->blob;
+    float* pts0 = F(p.o_pts[0]);
+    float* centroid = F(p.o_centroid);
+    float* scale0 = F(p.o_scale0);
+
+    if (pre_normalised) rc = transpose_cloud_launch(x, B, N, pts0, st);
+    else rc = prologue_launch(x, B, N, pts0, centroid, scale0, st);
+    if (rc != LS_OK) return rc;
+
+    // ---- FPS chain on the side stream: depends on xyz only, overlaps with layers 0..first down-sample
+    if (p.nlevels > 0) {
+        LS_HIP_CHECK(hipEventRecord(m->ev_fork, st));
+        LS_HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        size_t toff = 0;
+        for (int l = 0; l < p.nlevels; ++l) {
+            int32_t* idx = trace_fps ? trace_fps + toff : I(p.o_fps[l + 1]);
+            toff += (size_t)B * p.levelN[l + 1];
+            rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), m->side);
+            if (rc != LS_OK) return rc;
+        }
+        LS_HIP_CHECK(hipEventRecord(m->ev_join, m->side));
+    }
+
+    float* cur = F(p.o_fA);
+    float* nxt = F(p.o_fB);
+    float* msg = F(p.o_msg);
+    float* T = F(p.o_T);
+    bool joined = false;
+    size_t knn_off = 0, fps_off = 0;
+    for (int i = 0; i < p.L; ++i) {
+        const int Ns = p.Ns[i], Nd = p.Nd[i], Co = p.Co[i];
+        const int32_t* dst_rows = nullptr;
+        if (p.level[i] >= 0) {
+            if (!joined) { LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0)); joined = true; }
+            dst_rows = trace_fps ? trace_fps + fps_off : I(p.o_fps[p.level[i] + 1]);
+            fps_off += (size_t)B * Nd;
+        }
+        int32_t* knn = trace_knn ? trace_knn + knn_off : I(p.o_knn);
+        knn_off += (size_t)B * Nd * 16;
+        const bool attn = i >= d.atten_start_layer;
+        const bool glob = i >= d.res_global_start_layer;
+        float* mp = glob ? msg : nxt;
+        if (i == 0) {
+            rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, st);
+            if (rc != LS_OK) return rc;
+            LS_REQUIRE(!attn, "encoder: attention at layer 0 unsupported (atten_start_layer >= 1)");
+            rc = edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st);
+            if (rc != LS_OK) return rc;
+        } else {
+            const int Cin = p.Cin[i], nc = p.ncols[i];
+            rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, st);
+            if (rc != LS_OK) return rc;
+            rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, st);
+            if (rc != LS_OK) return rc;
+            if (attn) rc = edge_attn_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st);
+            else rc = edge_pool_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, mp, st);
+            if (rc != LS_OK) return rc;
+        }
+        if (glob) {
+            float* g = F(p.o_g);
+            float* G = F(p.o_G);
+            float* TG = F(p.o_TG);
+            const float* Wg = W + d.off_glob[i];
+            rc = mean_points_launch(msg, B, Nd, Co, g, st);
+            if (rc != LS_OK) return rc;
+            rc = gemm_dispatch(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, st);
+            if (rc != LS_OK) return rc;
+            rc = gemm_dispatch(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, st);
+            if (rc != LS_OK) return rc;
+            rc = vn_act_rows_launch(TG, 2 * Co, G, 4 * Co, B, Nd, Co, d.neg_slope, nxt, st);
+            if (rc != LS_OK) return rc;
+        }
+        std::swap(cur, nxt);
+    }
+    if (p.nlevels > 0 && !joined) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
+
+    // ---- tail
+    const int Cl = p.Co[p.L - 1];
+    float* Tc = F(p.o_Tc);
+    rc = gemm_dispatch(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, p.Cdp, B * p.NP * 3, p.Cdp, Cl, 0, st);
+    if (rc != LS_OK) return rc;
+    rc = tail_launch(Tc, p.Cdp, B, p.NP, d.c_dim, W + d.off_inv_t, W + d.off_c_fc0_t, W + d.off_c_misc, d.neg_slope,
+                     d.scale_factor, d.center_pred, d.center_pred_scale, pre_normalised ? nullptr : centroid,
+                     pre_normalised ? nullptr : scale0, z_so3, z_inv, s_out, t_out, st);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ SDF decode
+static int dec_out(const ls_model_desc& d, int l) {  // padded output width of linear layer l
+    const int nl = d.dec_num_linear;
+    if (l == nl - 1) return 1;
+    if (d.dec_latent_in >= 0 && l + 1 == d.dec_latent_in) return (int)align_up((size_t)(d.dec_width - (2 * d.c_dim + 1)), 4);
+    return d.dec_width;
+}
+
+size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M) {
+    if (!m || m->d.dec_num_linear <= 0) return 0;
+    const size_t w = (size_t)m->d.dec_width;
+    size_t b = 0;
+    b += 2 * align_up((size_t)B * w * 4 * 4, 256);   // A0, A4
+    b += 2 * align_up((size_t)B * w * 4, 256);       // beff0, beff4
+    b += 2 * align_up((size_t)B * M * w * 4, 256);   // ping-pong activations
+    return b;
+}
+
+int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s, const float* t,
+                  int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream) {
+    LS_REQUIRE(m && query && z_so3 && z_inv && s && t && sdf && workspace, "sdf_decode: null argument");
+    const ls_model_desc& d = m->d;
+    LS_REQUIRE(d.dec_num_linear >= 3, "sdf_decode: model has no decoder packed");
+    LS_REQUIRE(B > 0 && M > 0, "sdf_decode: empty problem");
+    const size_t need = ls_sdf_workspace_bytes(m, B, M);
+    if (workspace_bytes < need) { set_error("sdf_decode: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int w = d.dec_width, L = d.c_dim, nl = d.dec_num_linear, li = d.dec_latent_in;
+    char* ws = (char*)workspace;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { float* p = (float*)(ws + off); off = align_up(off + bytes, 256); return p; };
+    float* A0 = take((size_t)B * w * 16);
+    float* A4 = take((size_t)B * w * 16);
+    float* b0 = take((size_t)B * w * 4);
+    float* b4 = take((size_t)B * w * 4);
+    float* hA = take((size_t)B * M * w * 4);
+    float* hB = take((size_t)B * M * w * 4);
+    const float* W = m->blob;
+    int rc = sdf_prep_launch(W + d.off_dec_inv_t[0], W + d.off_dec_so3_t[0], W + d.off_dec_len[0], W + d.off_dec_b[0], z_so3,
+                             z_inv, B, L, w, A0, b0, st);
+    if (rc != LS_OK) return rc;
+    if (li >= 0) {
+        rc = sdf_prep_launch(W + d.off_dec_inv_t[li], W + d.off_dec_so3_t[li], W + d.off_dec_len[li], W + d.off_dec_b[li], z_so3,
+                             z_inv, B, L, w, A4, b4, st);
+        if (rc != LS_OK) return rc;
+    }
+    // layer 0: pure affine in (q, |q|)
+    rc = sdf_affine_launch(query, s, t, A0, b0, B, M, w, w, 0, hA, st);
+    if (rc != LS_OK) return rc;
+    float* cur = hA;
+    float* nxt = hB;
+    int kin = w;
+    for (int l = 1; l < nl - 1; ++l) {
+        const int outw = dec_out(d, l);
+        if (l == li) {
+            rc = gemm_dispatch(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, B * M, outw, kin, 0, st);
+            if (rc != LS_OK) return rc;
+            rc = sdf_affine_launch(query, s, t, A4, b4, B, M, w, w, 1, nxt, st);
+        } else {
+            rc = gemm_dispatch(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, B * M, outw, kin, 1, st);
+        }
+        if (rc != LS_OK) return rc;
+        kin = outw;
+        std::swap(cur, nxt);
+    }
+    return sdf_out_launch(cur, w, kin, W + d.off_dec_w[nl - 1], W + d.off_dec_b[nl - 1], (long long)B * M, sdf, st);
+}
+
+}  // extern "C"

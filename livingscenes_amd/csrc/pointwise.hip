@@ -1,0 +1,280 @@
+// pointwise.hip -- the small HBM-bound kernels around the edge-conv: encode prologue, per-instance mean,
+// point-wise VN activation (residual global conv), and the encoder tail (conv_c pooling + the four heads).
+#include "ls_common.h"
+
+namespace ls {
+
+// ---------------------------------------------------------------------------------------------- prologue
+// Shape_Prior.encode, /root/reference/model_utils.py:171-177: centroid = mean_n x; x -= centroid;
+// scale_0 = mean(top-5 of the N*N entries of cdist(x,x)); x /= scale_0.  The symmetric matrix holds every
+// unordered pair twice, so top-5 = (d1,d1,d2,d2,d3) with d1>=d2>=d3 the three largest pair distances.
+// One workgroup per instance; cloud staged in LDS; each thread keeps a private top-3 of squared distances.
+__device__ __forceinline__ void top3_insert(float v, float& a, float& b, float& c) {
+    if (v > c) {
+        if (v > b) { c = b; if (v > a) { b = a; a = v; } else b = v; }
+        else c = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__ x, int N, float* __restrict__ pts_out,
+                                                       float* __restrict__ centroid_out, float* __restrict__ scale0_out) {
+    extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N] centred cloud
+    __shared__ float red[3 * 4 + 4 * 3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = x + (size_t)b * 3 * N;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int n = tid; n < N; n += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = xb[(size_t)a * N + n]; sp[a * N + n] = v; s[a] += v; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s[a] = wave_sum(s[a]); if (lane == 0) red[a * 4 + wave] = s[a]; }
+    __syncthreads();
+    float c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = (red[a * 4] + red[a * 4 + 1] + red[a * 4 + 2] + red[a * 4 + 3]) / (float)N;
+    for (int n = tid; n < N; n += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sp[a * N + n] -= c[a];
+    }
+    __syncthreads();
+    float t0 = -1.f, t1 = -1.f, t2 = -1.f;
+    for (int i = tid; i < N; i += 256) {
+        const float px = sp[i], py = sp[N + i], pz = sp[2 * N + i];
+        for (int j = i + 1; j < N; ++j) {
+            const float dx = px - sp[j], dy = py - sp[N + j], dz = pz - sp[2 * N + j];
+            top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
+        }
+    }
+    // merge the 64 private top-3 of a wave, then the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u0 = __shfl_xor(t0, o, 64), u1 = __shfl_xor(t1, o, 64), u2 = __shfl_xor(t2, o, 64);
+        top3_insert(u0, t0, t1, t2); top3_insert(u1, t0, t1, t2); top3_insert(u2, t0, t1, t2);
+    }
+    if (lane == 0) { red[12 + wave * 3] = t0; red[12 + wave * 3 + 1] = t1; red[12 + wave * 3 + 2] = t2; }
+    __syncthreads();
+    t0 = t1 = t2 = -1.f;
+    for (int i = 0; i < 12; ++i) top3_insert(red[12 + i], t0, t1, t2);
+    const float d1 = sqrtf(fmaxf(t0, 0.f)), d2 = sqrtf(fmaxf(t1, 0.f)), d3 = sqrtf(fmaxf(t2, 0.f));
+    const float sc = ((((d1 + d1) + d2) + d2) + d3) / 5.0f;
+    if (tid == 0) {
+        scale0_out[b] = sc;
+        centroid_out[b * 3 + 0] = c[0]; centroid_out[b * 3 + 1] = c[1]; centroid_out[b * 3 + 2] = c[2];
+    }
+    float* po = pts_out + (size_t)b * N * 3;
+    for (int t = tid; t < N * 3; t += 256) { const int n = t / 3, a = t % 3; po[t] = sp[a * N + n] / sc; }
+}
+
+// [B,3,N] -> [B,N,3] without normalisation (pre_normalised path)
+__global__ void transpose_cloud_kernel(const float* __restrict__ x, int N, float* __restrict__ pts_out, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / (N * 3), r = t % (N * 3), n = r / 3, a = r % 3;
+    pts_out[t] = x[((size_t)b * 3 + a) * N + n];
+}
+
+// ---------------------------------------------------------------------------------------------- mean over points
+// dst_f.mean(-1) of vec_dgcnn_atten.py:223: in [B,N,3,C] -> out [B,3,C]; sequential over n (deterministic)
+__global__ __launch_bounds__(256) void mean_points_kernel(const float* __restrict__ f, int N, int row, float* __restrict__ out) {
+    const int b = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= row) return;
+    const float* p = f + (size_t)b * N * row + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int n = 0;
+    for (; n + 3 < N; n += 4) {
+        s0 += p[(size_t)n * row]; s1 += p[(size_t)(n + 1) * row]; s2 += p[(size_t)(n + 2) * row]; s3 += p[(size_t)(n + 3) * row];
+    }
+    for (; n < N; ++n) s0 += p[(size_t)n * row];
+    out[(size_t)b * row + col] = ((s0 + s1) + (s2 + s3)) / (float)N;
+}
+
+// ---------------------------------------------------------------------------------------------- point-wise VN activation
+// global_conv VecLNA of vec_dgcnn_atten.py:222-225 after the GEMMs:
+//   y  = T[p][x][0:C]   + G[b][x][2C:3C]      (W_a f[n]      + W_b mean_n f)
+//   kd = T[p][x][C:2C]  + G[b][x][3C:4C]      (Wd W_a f[n]   + Wd W_b mean_n f)
+// T [B*N*3, ldt] (cols lin|dir), G [B*3, ldg] (cols ..|..|lin_g|dir_g) or NULL; out [B,N,3,C]
+__global__ __launch_bounds__(256) void vn_act_rows_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ G,
+                                                          int ldg, int N, int C, float oms, float* __restrict__ out,
+                                                          long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C);
+    const long long p = t / C;
+    const int b = (int)(p / N);
+    const float* Tp = T + (size_t)p * 3 * ldt;
+    float y[3], k[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        y[x] = Tp[x * ldt + c];
+        k[x] = Tp[x * ldt + C + c];
+        if (G) {
+            y[x] += G[((size_t)b * 3 + x) * ldg + 2 * C + c];
+            k[x] += G[((size_t)b * 3 + x) * ldg + 3 * C + c];
+        }
+    }
+    vn_act(y[0], y[1], y[2], k[0], k[1], k[2], oms);
+    float* op = out + (size_t)p * 3 * C + c;
+    op[0] = y[0]; op[C] = y[1]; op[2 * C] = y[2];
+}
+
+// ---------------------------------------------------------------------------------------------- encoder tail
+// vec_dgcnn_atten.py:231-250 + Shape_Prior.encode epilogue (model_utils.py:182-195), one workgroup per instance.
+//   Tc [B, NP, 3, ldc]: conv_c.lin output in cols [0,Cd), the shared lin_dir output in col Cd
+//   X = mean_n act_shared(...)               (:231-232; shared_nonlinearity -> one direction per point)
+//   z_so3 = cevn(X); scale = mean_c |X_c| * SF; z_inv = <cevn(fc_inv X), z_so3>          (:234-238)
+//   center = VecResBlock(X) * SF   (vec_layers.py:631-651: act2(shortcut X + lin1 VecLNA_fc0 X))  (:246-250)
+//   t = center + centroid ; s = scale_0 * scale
+struct TailW {
+    const float* inv_t;    // [Cd][Cd]  fc_inv^T
+    const float* fc0_t;    // [Cd][2h]  {fc0.lin ; fc0.dir*fc0.lin}^T
+    const float* misc;     // lin1 [h] | shortcut [Cd] | act2 dir [1]
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc, int ldc, int NP, int Cd, TailW w, float oms,
+                                                   float scale_factor, int center_pred, int center_scale,
+                                                   const float* __restrict__ centroid, const float* __restrict__ scale0,
+                                                   float* __restrict__ z_so3, float* __restrict__ z_inv,
+                                                   float* __restrict__ s_out, float* __restrict__ t_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* X = sm;                 // [3][Cd]
+    float* kdir = X + 3 * Cd;      // [NP][3] normalised shared directions
+    float* H = kdir + 3 * NP;      // [3][h]
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int h = Cd / 2;
+    const float* Tb = Tc + (size_t)b * NP * 3 * ldc;
+    for (int n = tid; n < NP; n += 256) {
+        const float k0 = Tb[((size_t)n * 3 + 0) * ldc + Cd], k1 = Tb[((size_t)n * 3 + 1) * ldc + Cd], k2 = Tb[((size_t)n * 3 + 2) * ldc + Cd];
+        const float inv = 1.0f / fmaxf(sqrtf(k0 * k0 + k1 * k1 + k2 * k2), 1e-12f);
+        kdir[n * 3 + 0] = k0 * inv; kdir[n * 3 + 1] = k1 * inv; kdir[n * 3 + 2] = k2 * inv;
+    }
+    __syncthreads();
+    float ss = 0.f, sn = 0.f;
+    for (int c = tid; c < Cd; c += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int n = 0; n < NP; ++n) {
+            const float* r = Tb + (size_t)n * 3 * ldc + c;
+            float y0 = r[0], y1 = r[ldc], y2 = r[2 * ldc];
+            const float k0 = kdir[n * 3], k1 = kdir[n * 3 + 1], k2 = kdir[n * 3 + 2];
+            const float p = y0 * k0 + y1 * k1 + y2 * k2;
+            const float f = oms * fminf(p, 0.f);
+            a0 += y0 - f * k0; a1 += y1 - f * k1; a2 += y2 - f * k2;
+        }
+        a0 /= (float)NP; a1 /= (float)NP; a2 /= (float)NP;
+        X[c] = a0; X[Cd + c] = a1; X[2 * Cd + c] = a2;
+        const float q = a0 * a0 + a1 * a1 + a2 * a2;
+        ss += q; sn += sqrtf(q);
+    }
+    const float fro = sqrtf(block_sum_256(ss, red));
+    const float nsum = block_sum_256(sn, red);
+    const float invf = 1.0f / fmaxf(fro, 1e-12f);
+    __syncthreads();
+    // fc_inv
+    float yi[4][3];
+    float ssi = 0.f;
+    int cnt = 0;
+    for (int o = tid; o < Cd; o += 256, ++cnt) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int c = 0; c < Cd; ++c) {
+            const float wv = w.inv_t[(size_t)c * Cd + o];
+            a0 += wv * X[c]; a1 += wv * X[Cd + c]; a2 += wv * X[2 * Cd + c];
+        }
+        if (cnt < 4) { yi[cnt][0] = a0; yi[cnt][1] = a1; yi[cnt][2] = a2; }
+        ssi += a0 * a0 + a1 * a1 + a2 * a2;
+    }
+    const float invfi = 1.0f / fmaxf(sqrtf(block_sum_256(ssi, red)), 1e-12f);
+    cnt = 0;
+    for (int o = tid; o < Cd; o += 256, ++cnt) {
+        const float z0 = X[o] * invf, z1 = X[Cd + o] * invf, z2 = X[2 * Cd + o] * invf;
+        float* zp = z_so3 + ((size_t)b * Cd + o) * 3;
+        zp[0] = z0; zp[1] = z1; zp[2] = z2;
+        if (cnt < 4) z_inv[(size_t)b * Cd + o] = (yi[cnt][0] * z0 + yi[cnt][1] * z1 + yi[cnt][2] * z2) * invfi;
+    }
+    const float sc0 = scale0 ? scale0[b] : 1.0f;
+    if (tid == 0) s_out[b] = sc0 * (nsum / (float)Cd * scale_factor);
+    // fc_center
+    float ctr[3] = {0.f, 0.f, 0.f};
+    if (center_pred) {
+        for (int o = tid; o < h; o += 256) {
+            float y0 = 0.f, y1 = 0.f, y2 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+            for (int c = 0; c < Cd; ++c) {
+                const float wl = w.fc0_t[(size_t)c * 2 * h + o], wd = w.fc0_t[(size_t)c * 2 * h + h + o];
+                const float x0 = X[c], x1 = X[Cd + c], x2 = X[2 * Cd + c];
+                y0 += wl * x0; y1 += wl * x1; y2 += wl * x2;
+                k0 += wd * x0; k1 += wd * x1; k2 += wd * x2;
+            }
+            vn_act(y0, y1, y2, k0, k1, k2, oms);
+            H[o] = y0; H[h + o] = y1; H[2 * h + o] = y2;
+        }
+        __syncthreads();
+        float v[3] = {0.f, 0.f, 0.f};
+        for (int c = tid; c < Cd; c += 256) {
+            const float wsv = w.misc[h + c];
+            v[0] += wsv * X[c]; v[1] += wsv * X[Cd + c]; v[2] += wsv * X[2 * Cd + c];
+        }
+        for (int o = tid; o < h; o += 256) {
+            const float wl = w.misc[o];
+            v[0] += wl * H[o]; v[1] += wl * H[h + o]; v[2] += wl * H[2 * h + o];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v[a] = block_sum_256(v[a], red);
+        const float wd2 = w.misc[h + Cd];
+        float k0 = wd2 * v[0], k1 = wd2 * v[1], k2 = wd2 * v[2];
+        vn_act(v[0], v[1], v[2], k0, k1, k2, oms);
+        const float sf = center_scale ? scale_factor : 1.0f;
+        ctr[0] = v[0] * sf; ctr[1] = v[1] * sf; ctr[2] = v[2] * sf;
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t_out[b * 3 + a] = ctr[a] + (centroid ? centroid[b * 3 + a] : 0.f);
+    }
+}
+
+int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, hipStream_t st) {
+    LS_REQUIRE(N >= 3 && N <= 8192, "prologue: N=%d out of range (3..8192)", N);
+    hipLaunchKernelGGL(prologue_kernel, dim3(B), dim3(256), (size_t)3 * N * sizeof(float), st, x, N, pts, centroid, scale0);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int transpose_cloud_launch(const float* x, int B, int N, float* pts, hipStream_t st) {
+    const int total = B * N * 3;
+    hipLaunchKernelGGL(transpose_cloud_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, N, pts, total);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int mean_points_launch(const float* f, int B, int N, int C, float* out, hipStream_t st) {
+    const int row = 3 * C;
+    hipLaunchKernelGGL(mean_points_kernel, dim3(cdiv(row, 256), B), dim3(256), 0, st, f, N, row, out);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int vn_act_rows_launch(const float* T, int ldt, const float* G, int ldg, int B, int N, int C, float neg_slope, float* out,
+                       hipStream_t st) {
+    const long long total = (long long)B * N * C;
+    hipLaunchKernelGGL(vn_act_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, T, ldt, G, ldg, N, C, 1.0f - neg_slope, out, total);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int tail_launch(const float* Tc, int ldc, int B, int NP, int Cd, const float* inv_t, const float* fc0_t, const float* misc,
+                float neg_slope, float scale_factor, int center_pred, int center_scale, const float* centroid,
+                const float* scale0, float* z_so3, float* z_inv, float* s_out, float* t_out, hipStream_t st) {
+    LS_REQUIRE(Cd <= 1024 && Cd % 2 == 0, "tail: c_dim=%d unsupported (even, <= 1024)", Cd);
+    TailW w{inv_t, fc0_t, misc};
+    const size_t smem = (size_t)(3 * Cd + 3 * NP + 3 * (Cd / 2)) * sizeof(float);
+    hipLaunchKernelGGL(tail_kernel, dim3(B), dim3(256), smem, st, Tc, ldc, NP, Cd, w, 1.0f - neg_slope, scale_factor,
+                       center_pred, center_scale, centroid, scale0, z_so3, z_inv, s_out, t_out);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+}  // namespace ls

@@ -1,0 +1,217 @@
+"""Tensor-level wrappers over the C ABI (include/livingscenes_hip.h).  Inputs/outputs are HIP torch tensors;
+torch only provides device memory and the current stream.  No CPU fallback anywhere (see _lib.ptr)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, load, ptr, stream_ptr
+
+DEFAULT_FLAGS = 0  # canonical arithmetic: separately rounded multiply/add (oracle contract=0)
+
+
+def _f32(t):
+    return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+def knn(dst, src, K=16, dst_rows=None, flags=DEFAULT_FLAGS, return_dist=False):
+    """dst [B,Nd',3,C], src [B,Ns,3,C] -> idx [B,Nd,K] int32 (Nd = dst_rows.shape[1] if given)."""
+    dst, src = _f32(dst), _f32(src)
+    B, dst_n, _, C = dst.shape
+    Ns = src.shape[1]
+    Nd = dst_rows.shape[1] if dst_rows is not None else dst_n
+    idx = torch.empty(B, Nd, K, dtype=torch.int32, device=src.device)
+    dist = torch.empty(B, Nd, K, dtype=torch.float32, device=src.device) if return_dist else None
+    check(load().ls_knn_f32(ptr(dst), ptr(src), ptr(dst_rows), B, Nd, dst_n, Ns, C, K, flags, ptr(idx), ptr(dist),
+                            stream_ptr(src.device)), "ls_knn_f32")
+    return (idx, dist) if return_dist else idx
+
+
+def fps(pts, K, lengths=None, flags=DEFAULT_FLAGS, return_points=False):
+    """pts [B,N,3] -> idx [B,K] int32 (and the gathered points [B,K,3])."""
+    pts = _f32(pts)
+    B, N, _ = pts.shape
+    idx = torch.empty(B, K, dtype=torch.int32, device=pts.device)
+    out = torch.empty(B, K, 3, dtype=torch.float32, device=pts.device) if return_points else None
+    if lengths is not None:
+        lengths = lengths.to(device=pts.device, dtype=torch.int32).contiguous()
+    check(load().ls_fps_f32(ptr(pts), ptr(lengths), B, N, K, flags, ptr(idx), ptr(out), stream_ptr(pts.device)), "ls_fps_f32")
+    return (idx, out) if return_points else idx
+
+
+def gemm(A, W, bias=None, relu=False):
+    """act(A[M,K] @ W[N,K]^T + bias) -> [M,N]."""
+    A, W = _f32(A), _f32(W)
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(load().ls_gemm_f32(ptr(A), K, ptr(W), K, ptr(bias), ptr(out), N, M, N, K, int(relu), stream_ptr(A.device)), "ls_gemm_f32")
+    return out
+
+
+def encode_prologue(x):
+    """x [B,3,N] -> (pts [B,N,3], centroid [B,3], scale0 [B])."""
+    x = _f32(x)
+    B, _, N = x.shape
+    pts = torch.empty(B, N, 3, dtype=torch.float32, device=x.device)
+    cen = torch.empty(B, 3, dtype=torch.float32, device=x.device)
+    sc = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(load().ls_encode_prologue_f32(ptr(x), B, N, ptr(pts), ptr(cen), ptr(sc), stream_ptr(x.device)), "ls_encode_prologue_f32")
+    return pts, cen, sc
+
+
+def cosine_scores(m0, m1):
+    m0, m1 = _f32(m0), _f32(m1)
+    n, D = m0.shape
+    m = m1.shape[0]
+    S = torch.empty(n, m, dtype=torch.float32, device=m0.device)
+    check(load().ls_cosine_scores_f32(ptr(m0), ptr(m1), n, m, D, ptr(S), stream_ptr(m0.device)), "ls_cosine_scores_f32")
+    return S
+
+
+def greedy_match(scores):
+    """scores [n,m] (copied; the kernel destroys its input) -> (matches0 [n], matches1 [m]) int64."""
+    S = _f32(scores).clone()
+    n, m = S.shape
+    m0 = torch.empty(n, dtype=torch.int64, device=S.device)
+    m1 = torch.empty(m, dtype=torch.int64, device=S.device)
+    check(load().ls_greedy_match_f32(ptr(S), n, m, ptr(m0), ptr(m1), stream_ptr(S.device)), "ls_greedy_match_f32")
+    return m0, m1
+
+
+def kabsch(x1, x2, weights=None, return_flags=False):
+    """x1,x2 [b,n,3] -> R [b,3,3], t [b,3,1], res [b,n] (, flags [b] int32)."""
+    x1, x2 = _f32(x1), _f32(x2)
+    b, n, _ = x1.shape
+    if weights is not None:
+        weights = _f32(weights)
+    R = torch.empty(b, 3, 3, dtype=torch.float32, device=x1.device)
+    t = torch.empty(b, 3, dtype=torch.float32, device=x1.device)
+    res = torch.empty(b, n, dtype=torch.float32, device=x1.device)
+    fl = torch.empty(b, dtype=torch.int32, device=x1.device)
+    check(load().ls_kabsch_batched_f32(ptr(x1), ptr(x2), ptr(weights), b, n, ptr(R), ptr(t), ptr(res), ptr(fl),
+                                       stream_ptr(x1.device)), "ls_kabsch_batched_f32")
+    return (R, t.unsqueeze(2), res, fl) if return_flags else (R, t.unsqueeze(2), res)
+
+
+def kabsch_residual_matrix(src, tgt):
+    """src [n,P,3], tgt [m,P,3] -> mean residual [n,m]."""
+    src, tgt = _f32(src), _f32(tgt)
+    n, P, _ = src.shape
+    m = tgt.shape[0]
+    res = torch.empty(n, m, dtype=torch.float32, device=src.device)
+    check(load().ls_kabsch_residual_matrix_f32(ptr(src), ptr(tgt), n, m, P, ptr(res), stream_ptr(src.device)),
+          "ls_kabsch_residual_matrix_f32")
+    return res
+
+
+def icp(X, Y, R0, T0, max_iter=100, rel_rmse_thr=1e-6, flags=DEFAULT_FLAGS):
+    """Row-vector convention Xt = X R + T.  X [b,n,3], Y [b,m,3], R0 [b,3,3], T0 [b,3] -> R, T, rmse [b], iters [b]."""
+    X, Y, R0, T0 = _f32(X), _f32(Y), _f32(R0), _f32(T0)
+    b, n, _ = X.shape
+    m = Y.shape[1]
+    R = torch.empty(b, 3, 3, dtype=torch.float32, device=X.device)
+    T = torch.empty(b, 3, dtype=torch.float32, device=X.device)
+    rmse = torch.empty(b, dtype=torch.float32, device=X.device)
+    iters = torch.empty(b, dtype=torch.int32, device=X.device)
+    ws = torch.empty(load().ls_icp_workspace_bytes(b, n), dtype=torch.uint8, device=X.device)
+    check(load().ls_icp_f32(ptr(X), ptr(Y), ptr(R0), ptr(T0), b, n, m, max_iter, rel_rmse_thr, flags, ptr(R), ptr(T),
+                            ptr(rmse), ptr(iters), ptr(ws), ws.numel(), stream_ptr(X.device)), "ls_icp_f32")
+    return R, T, rmse, iters
+
+
+class HipModel:
+    """Owner of an ls_model_t (device-resident packed weights) with encode / sdf_decode entry points."""
+
+    def __init__(self, desc, blob, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LsError("HipModel needs a HIP device: the MI355X path has no CPU fallback")
+        self.desc = desc
+        self._h = ctypes.c_void_p()
+        self._ws = None
+        with torch.cuda.device(self.device):
+            check(load().ls_model_create(ctypes.byref(desc), blob.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self._h)),
+                  "ls_model_create")
+
+    def close(self):
+        if self._h:
+            load().ls_model_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def n_levels(self):
+        return [int(self.desc.down_factor[i]) for i in range(self.desc.num_layers)]
+
+    def encode(self, x, pre_normalised=False, flags=DEFAULT_FLAGS, trace=False):
+        """x [B,3,N] -> (z_so3 [B,C,3], z_inv [B,C], s [B], t [B,3]) (+ per-layer knn / fps index lists)."""
+        x = _f32(x)
+        B, three, N = x.shape
+        assert three == 3
+        d = self.desc
+        C = d.c_dim
+        dev = x.device
+        z_so3 = torch.empty(B, C, 3, dtype=torch.float32, device=dev)
+        z_inv = torch.empty(B, C, dtype=torch.float32, device=dev)
+        s = torch.empty(B, dtype=torch.float32, device=dev)
+        t = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        need = load().ls_encoder_workspace_bytes(self._h, B, N)
+        if need == 0:
+            raise _lib.LsError("ls_encoder_workspace_bytes: " + load().ls_last_error().decode())
+        ws = self._workspace(need)
+        tk = tf = None
+        nds, fps_n = [], []
+        cur = N
+        for i in range(d.num_layers):
+            if d.down_factor[i] > 1:
+                cur //= d.down_factor[i]
+                fps_n.append(cur)
+            nds.append(cur)
+        if trace:
+            tk = torch.empty(B * sum(nds) * 16, dtype=torch.int32, device=dev)
+            tf = torch.empty(max(1, B * sum(fps_n)), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(load().ls_encode(self._h, ptr(x), B, N, int(pre_normalised), flags, ptr(z_so3), ptr(z_inv), ptr(s), ptr(t),
+                                   ptr(tk), ptr(tf), ptr(ws), ws.numel(), stream_ptr(dev)), "ls_encode")
+        if not trace:
+            return z_so3, z_inv, s, t
+        knn_l, fps_l, o = [], [], 0
+        for nd in nds:
+            knn_l.append(tk[o:o + B * nd * 16].view(B, nd, 16))
+            o += B * nd * 16
+        o = 0
+        for nf in fps_n:
+            fps_l.append(tf[o:o + B * nf].view(B, nf))
+            o += B * nf
+        return z_so3, z_inv, s, t, knn_l, fps_l
+
+    def sdf_decode(self, query, z_so3, z_inv, s, t, max_ws_bytes=2 << 30):
+        """query [B,M,3] + code -> sdf [B,M]; queries are processed in chunks that keep the workspace bounded."""
+        query = _f32(query)
+        B, M, _ = query.shape
+        z_so3, z_inv, s, t = _f32(z_so3), _f32(z_inv), _f32(s), _f32(t.reshape(B, 3))
+        sdf = torch.empty(B, M, dtype=torch.float32, device=query.device)
+        per_q = 2 * self.desc.dec_width * 4 * B
+        chunk = max(64, min(M, int(max_ws_bytes // max(per_q, 1))))
+        for m0 in range(0, M, chunk):
+            mc = min(chunk, M - m0)
+            q = query[:, m0:m0 + mc].contiguous()
+            out = sdf if mc == M else torch.empty(B, mc, dtype=torch.float32, device=query.device)
+            need = load().ls_sdf_workspace_bytes(self._h, B, mc)
+            ws = self._workspace(need)
+            with torch.cuda.device(query.device):
+                check(load().ls_sdf_decode(self._h, ptr(q), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, mc, ptr(out), ptr(ws),
+                                           ws.numel(), stream_ptr(query.device)), "ls_sdf_decode")
+            if mc != M:
+                sdf[:, m0:m0 + mc] = out
+        return sdf

@@ -37,7 +37,7 @@ def small_encoder_cfg():
 
 def small_decoder_cfg():
     return dict(
-        dims=[64] * 4, dropout=None, dropout_prob=0.0, latent_dropout=False, latent_in=[2],
+        dims=[128] * 4, dropout=None, dropout_prob=0.0, latent_dropout=False, latent_in=[2],
         latent_size=32, norm_layers=list(range(4)), pe_dim=33, use_tanh=False, weight_norm=True)
 
 
