@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- object-instances/sec for the LivingScenes per-instance hot path (encode + match + register) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One STEP (per rank) = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  BASELINE.json configs[1] + [2]: 64 instances x 1024 points (a 32-object reference scene and its 32-object rescan)
+    -> Shape_Prior.encode (prologue, FPS, 7x [k-NN, VN edge-conv], heads)            (64 objects)
+    -> sequential_matcher on the 32x32 invariant-code scores                          (1 scene pair)
+    -> kabsch_transformation_estimation on the 32 matched pairs (z_so3 + t)           (32 poses)
+Weights: deterministic synthetic weights of the released architecture (the checkpoint is absent from the reference
+tree); data: synthetic chair-like clouds (livingscenes_amd.synth).  fp32 throughout, as the reference.
+Multi-GPU: instances shard embarrassingly (weak scaling: every rank runs its own 64-instance batch); RCCL is used to
+broadcast the weights once and to gather a result checksum -- there is no data-path collective.
+
+Prints ONE JSON line (rank 0): metric/value/... + "roofline" (dominant kernel, hipEvent-timed per launch in a separate
+profiled pass of the same K steps) + "cpu_baseline" (the CPU oracle = the reference's PyTorch-CPU op sequence, timed on
+this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
+
+
+def layer_plan(cfg, N):
+    """(Ns, Nd, Cin, Co, attn, glob) per encoder layer."""
+    out, cur = [], N
+    for i in range(cfg["num_layers"]):
+        ns = cur
+        if i in cfg["down_sample_layers"]:
+            cur //= cfg["down_sample_factor"][cfg["down_sample_layers"].index(i)]
+        out.append(dict(Ns=ns, Nd=cur, Cin=1 if i == 0 else cfg["feat_dim"][i - 1], Co=cfg["feat_dim"][i],
+                        attn=i >= cfg["atten_start_layer"], glob=i >= cfg["res_global_start_layer"]))
+    return out
+
+
+def algorithmic_cost(kind, layer, cfg, B, N):
+    """(bytes, flops) one launch of kernel `kind` at `layer` must move / execute."""
+    pl = layer_plan(cfg, N)
+    L = pl[min(layer, len(pl) - 1)]
+    Ns, Nd, Cin, Co = L["Ns"], L["Nd"], L["Cin"], L["Co"]
+    f4 = 4
+    if kind == "knn":
+        D = 3 * Cin
+        return B * ((Nd + Ns) * D * f4 + Nd * 16 * 4), 3.0 * B * Nd * Ns * D
+    if kind == "gemm_edge":
+        nc = (10 if L["attn"] else 4) * Co
+        return B * Ns * 3 * (Cin + nc) * f4 + nc * Cin * f4, 2.0 * B * Ns * 3 * Cin * nc
+    if kind == "edge_attn":
+        gather = B * Nd * 16 * 4 * Co * 3 * f4          # P_lin/P_dir of the K and V branches at 16 neighbours
+        own = B * Nd * 6 * Co * 3 * f4                  # Q-side columns of the destination row
+        return gather + own + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * 2 * 30
+    if kind == "edge_pool":
+        return B * Nd * 16 * 2 * Co * 3 * f4 + B * Nd * 2 * Co * 3 * f4 + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * 30
+    if kind == "edge_l0":
+        return B * Nd * 16 * (12 + 4) + B * Nd * 12 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * 40
+    if kind == "gemm_glob":
+        return B * Nd * 3 * 3 * Co * f4 + 4 * Co * Co * f4, 2.0 * B * Nd * 3 * Co * 2 * Co
+    if kind == "vn_act":
+        return B * Nd * 3 * 3 * Co * f4, 30.0 * B * Nd * Co
+    if kind == "mean":
+        return B * Nd * 3 * Co * f4, 1.0 * B * Nd * 3 * Co
+    if kind == "fps":
+        n = [N] + [p["Nd"] for p in pl if p["Nd"] != p["Ns"]]
+        return B * n[min(layer, len(n) - 1)] * 12, 0.0
+    if kind == "prologue":
+        return B * N * 24, 8.0 * B * N * N / 2
+    if kind == "gemm_tail":
+        return B * pl[-1]["Nd"] * 3 * (pl[-1]["Co"] + cfg["c_dim"]) * f4, 2.0 * B * pl[-1]["Nd"] * 3 * pl[-1]["Co"] * cfg["c_dim"]
+    if kind == "tail":
+        c = cfg["c_dim"]
+        return B * pl[-1]["Nd"] * 3 * c * f4 + 2 * c * c * f4, 2.0 * B * 3 * c * c * 2
+    return 0, 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="instances per step per GPU (two scenes of batch/2 objects)")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--cpu-instances", type=int, default=8, help="bounded sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    from livingscenes_amd import sharding as parallel, synth
+    from livingscenes_amd.lib_more.matcher_new import sequential_matcher
+    from livingscenes_amd.lib_more.pose_estimation import kabsch_transformation_estimation
+    from livingscenes_amd.model_utils import Shape_Prior
+
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    if rank == 0:
+        ew, dw = synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0)
+    else:  # other ranks start from zeros and receive rank 0's weights over RCCL
+        ew = {k: torch.zeros(s) for k, s in synth.encoder_param_shapes(ecfg).items()}
+        dw = {k: torch.zeros_like(v) for k, v in synth.make_decoder_weights(dcfg, 0).items()}
+    sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=dev)
+    if world > 1:
+        parallel.broadcast_weights(sp, src=0)
+
+    B, N = args.batch, args.points
+    n_obj = B // 2
+    scene = synth.make_scene_pair(n_obj, N, seed=1000 + rank)
+    x = torch.cat([scene["ref"], scene["rescan"]], 0).transpose(1, 2).contiguous().to(dev)  # [B,3,N] resident in HBM
+
+    def step():
+        emb = sp.encode(x)
+        m = sequential_matcher(emb["z_inv"][:n_obj], emb["z_inv"][n_obj:])
+        j = m["matches0"].clamp(min=0)
+        p1 = emb["z_so3"][:n_obj] + emb["t"][:n_obj]
+        p2 = (emb["z_so3"][n_obj:] + emb["t"][n_obj:]).index_select(0, j)
+        R, t, _, _ = kabsch_transformation_estimation(p1, p2)
+        return emb, m, R, t
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+
+    emb, m, R, t = out
+    # sanity of the measured work (outside the timed region): matches are the identity permutation, poses are rotations
+    n_correct = int((m["matches0"].cpu() == torch.arange(n_obj)).sum())
+    det_ok = bool((torch.det(R.cpu()) > 0.99).all())
+    if world > 1:  # RCCL gather of a per-rank result checksum (KB-scale, latency-bound; not on the data path)
+        parallel.gather_codes(emb, dst=0)
+
+    roof = None
+    if rank == 0 and not args.no_profile:
+        hip = sp.hip_model()
+        hip.profile_begin()
+        with torch.no_grad():
+            for _ in range(args.steps):
+                step()
+        prof = hip.profile_end()
+        tot = sum(p["total_ms"] for p in prof)
+        by = sorted(prof, key=lambda p: -p["total_ms"])
+        # dominant kernel = the (kind, layer) launch with the largest total time
+        dom = by[0]
+        abytes, aflops = algorithmic_cost(dom["kind"], dom["layer"], ecfg, B, N)
+        avg_s = dom["total_ms"] / dom["launches"] * 1e-3
+        t_hbm, t_fl = abytes / (HBM_PEAK_GBS * 1e9), aflops / (FP32_PEAK_TFLOPS * 1e12)
+        if t_fl >= t_hbm:
+            roof = dict(bound="mfma", pipe="valu-f32" if dom["kind"] != "gemm_edge" else "mfma-f32", achieved=aflops / avg_s / 1e12,
+                        peak=FP32_PEAK_TFLOPS, unit="TFLOP/s")
+        else:
+            roof = dict(bound="hbm", achieved=abytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = f"{dom['kind']}[layer {dom['layer']}]"
+        roof["avg_launch_us"] = avg_s * 1e6
+        roof["algorithmic_bytes_per_launch"] = abytes
+        roof["algorithmic_flops_per_launch"] = aflops
+        roof["timing"] = "hipEvent pair per launch on the launching stream, separate profiled pass of the same K steps"
+        roof["share_of_device_time"] = dom["total_ms"] / max(tot, 1e-9)
+        kinds = {}
+        for p in prof:
+            kinds[p["kind"]] = kinds.get(p["kind"], 0.0) + p["total_ms"]
+        roof["breakdown_ms_per_step"] = {k: round(v / args.steps, 4) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])}
+        roof["per_layer_ms_per_step"] = {f"{p['kind']}{p['layer']}": round(p["total_ms"] / args.steps, 4) for p in by[:12]}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_instances > 0:
+        from oracle import more, net  # the checker, timed as the CPU baseline ("port" of the reference's op sequence)
+        nb = args.cpu_instances
+        torch.set_num_threads(os.cpu_count() or 1)
+        xc = x[:nb].cpu()
+        ewc, _ = synth.make_encoder_weights(ecfg, 0), None
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            embc = net.shape_prior_encode(ewc, ecfg, xc)
+            h = nb // 2
+            mm = more.sequential_matcher(embc["z_inv"][:h], embc["z_inv"][h:])
+            more.kabsch_transformation_estimation(embc["z_so3"][:h] + embc["t"][:h], embc["z_so3"][h:] + embc["t"][h:])
+        tc = time.perf_counter() - t1
+        cpu = dict(value=nb / tc, unit="object-instances/s", cores=torch.get_num_threads(), kind="port",
+                   sample=f"{nb} instances x {N} pts in one batch: oracle Shape_Prior.encode + sequential_matcher "
+                          f"({h}x{h}) + Kabsch ({h}), {tc:.2f} s wall, torch {torch.__version__} CPU")
+
+    if rank == 0:
+        total_objects = B * args.steps * world
+        line = {
+            "metric": "object-instances/sec (encode+match+register), N=1024 pts",
+            "value": total_objects / dt,
+            "unit": "object-instances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded chair-like clouds; deterministic random-init weights of the released architecture)",
+            "config": {"workload": f"BASELINE configs[1]+[2]: batch={B} instances x N={N} pts per GPU = {n_obj}-object scene + rescan; "
+                                   f"VN-DGCNN encode, {n_obj}x{n_obj} sequential matching, {n_obj} Kabsch poses",
+                       "instances_per_step_per_gpu": B, "points": N, "parallelism": f"instance-sharded x{world}",
+                       "knn_arithmetic": "canonical (separately rounded mul/add)"},
+            "check": {"matches_identity": f"{n_correct}/{n_obj}", "rotations_proper": det_ok},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,27 @@ size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M);
 int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s,
                   const float* t, int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Live per-kernel timing (bench.py's roofline leg): while enabled, every kernel ls_encode / ls_sdf_decode
+ * launches is bracketed by hipEvents on the stream it is launched on.  ls_profile_end synchronises those
+ * streams and returns, per (kind, layer), the number of launches and their summed duration.
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum {
+    LS_K_PROLOGUE = 0, LS_K_FPS, LS_K_KNN, LS_K_GEMM_EDGE, LS_K_EDGE_L0, LS_K_EDGE_POOL, LS_K_EDGE_ATTN, LS_K_MEAN,
+    LS_K_GEMM_GLOB, LS_K_VN_ACT, LS_K_GEMM_TAIL, LS_K_TAIL, LS_K_SDF_PREP, LS_K_SDF_AFFINE, LS_K_GEMM_SDF, LS_K_SDF_OUT,
+    LS_K_COUNT
+} ls_kernel_kind;
+
+typedef struct {
+    int32_t kind;      /* ls_kernel_kind */
+    int32_t layer;     /* encoder layer / FPS level / decoder layer */
+    int32_t launches;
+    float total_ms;
+} ls_profile_entry;
+
+int ls_profile_begin(ls_model_t* m);
+int ls_profile_end(ls_model_t* m, ls_profile_entry* out_host, int max_entries, int* n_out_host);
+
 #ifdef __cplusplus
 }
 #endif

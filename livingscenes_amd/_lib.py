@@ -52,6 +52,13 @@ class ModelDesc(ctypes.Structure):
     ]
 
 
+class ProfileEntry(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("layer", ctypes.c_int32), ("launches", ctypes.c_int32), ("total_ms", ctypes.c_float)]
+
+
+KERNEL_KINDS = ["prologue", "fps", "knn", "gemm_edge", "edge_l0", "edge_pool", "edge_attn", "mean", "gemm_glob", "vn_act",
+                "gemm_tail", "tail", "sdf_prep", "sdf_affine", "gemm_sdf", "sdf_out"]
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _U = ctypes.c_uint
@@ -79,6 +86,8 @@ SIGNATURES = {
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ls_sdf_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_sdf_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "ls_profile_begin": (_I, [_P]),
+    "ls_profile_end": (_I, [_P, ctypes.POINTER(ProfileEntry), _I, ctypes.POINTER(ctypes.c_int)]),
 }
 
 _lib = None

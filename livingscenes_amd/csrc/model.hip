@@ -46,13 +46,40 @@ int icp_run(const float*, const float*, const float*, const float*, int, int, in
 
 using namespace ls;
 
+struct ProfRec { int kind, layer; hipEvent_t a, b; };
+
 struct ls_model {
     ls_model_desc d;
     float* blob = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    float* scratch = nullptr;  // small device scratch for the matcher (inverse norms)
+    bool profiling = false;
+    std::vector<ProfRec> prof;          // pending (un-collected) event pairs
+    std::vector<hipEvent_t> ev_pool;    // recycled events
+    float prof_ms[LS_K_COUNT][16];
+    int prof_n[LS_K_COUNT][16];
+    std::vector<hipStream_t> prof_streams;
 };
+
+// RAII bracket: records an event pair around one launch when profiling is on
+struct ProfScope {
+    ls_model* m; hipStream_t st; ProfRec r; bool on;
+    ProfScope(ls_model* m_, int kind, int layer, hipStream_t st_) : m(m_), st(st_), on(m_ && m_->profiling) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!m->ev_pool.empty()) { e = m->ev_pool.back(); m->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        r.kind = kind; r.layer = layer < 16 ? layer : 15; r.a = get(); r.b = get();
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        m->prof.push_back(r);
+        bool seen = false;
+        for (auto s : m->prof_streams) seen |= (s == st);
+        if (!seen) m->prof_streams.push_back(st);
+    }
+};
+#define PROF(kind, layer, st) ProfScope _ps_##__LINE__(m, kind, layer, st)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -205,6 +232,8 @@ void ls_model_destroy(ls_model_t* m) {
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -235,8 +264,11 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     float* centroid = F(p.o_centroid);
     float* scale0 = F(p.o_scale0);
 
-    if (pre_normalised) rc = transpose_cloud_launch(x, B, N, pts0, st);
-    else rc = prologue_launch(x, B, N, pts0, centroid, scale0, st);
+    {
+        PROF(LS_K_PROLOGUE, 0, st);
+        if (pre_normalised) rc = transpose_cloud_launch(x, B, N, pts0, st);
+        else rc = prologue_launch(x, B, N, pts0, centroid, scale0, st);
+    }
     if (rc != LS_OK) return rc;
 
     // ---- FPS chain on the side stream: depends on xyz only, overlaps with layers 0..first down-sample
@@ -247,7 +279,10 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
         for (int l = 0; l < p.nlevels; ++l) {
             int32_t* idx = trace_fps ? trace_fps + toff : I(p.o_fps[l + 1]);
             toff += (size_t)B * p.levelN[l + 1];
-            rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), m->side);
+            {
+                PROF(LS_K_FPS, l, m->side);
+                rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), m->side);
+            }
             if (rc != LS_OK) return rc;
         }
         LS_HIP_CHECK(hipEventRecord(m->ev_join, m->side));
@@ -273,19 +308,19 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
         const bool glob = i >= d.res_global_start_layer;
         float* mp = glob ? msg : nxt;
         if (i == 0) {
-            rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, st);
+            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, st); }
             if (rc != LS_OK) return rc;
             LS_REQUIRE(!attn, "encoder: attention at layer 0 unsupported (atten_start_layer >= 1)");
-            rc = edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st);
+            { PROF(LS_K_EDGE_L0, i, st); rc = edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
         } else {
             const int Cin = p.Cin[i], nc = p.ncols[i];
-            rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, st);
+            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, st); }
             if (rc != LS_OK) return rc;
-            rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, st);
+            { PROF(LS_K_GEMM_EDGE, i, st); rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, st); }
             if (rc != LS_OK) return rc;
-            if (attn) rc = edge_attn_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st);
-            else rc = edge_pool_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, mp, st);
+            if (attn) { PROF(LS_K_EDGE_ATTN, i, st); rc = edge_attn_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st); }
+            else { PROF(LS_K_EDGE_POOL, i, st); rc = edge_pool_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
         }
         if (glob) {
@@ -293,13 +328,15 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             float* G = F(p.o_G);
             float* TG = F(p.o_TG);
             const float* Wg = W + d.off_glob[i];
-            rc = mean_points_launch(msg, B, Nd, Co, g, st);
+            { PROF(LS_K_MEAN, i, st); rc = mean_points_launch(msg, B, Nd, Co, g, st); }
             if (rc != LS_OK) return rc;
-            rc = gemm_dispatch(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, st);
+            {
+                PROF(LS_K_GEMM_GLOB, i, st);
+                rc = gemm_dispatch(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, st);
+                if (rc == LS_OK) rc = gemm_dispatch(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, st);
+            }
             if (rc != LS_OK) return rc;
-            rc = gemm_dispatch(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, st);
-            if (rc != LS_OK) return rc;
-            rc = vn_act_rows_launch(TG, 2 * Co, G, 4 * Co, B, Nd, Co, d.neg_slope, nxt, st);
+            { PROF(LS_K_VN_ACT, i, st); rc = vn_act_rows_launch(TG, 2 * Co, G, 4 * Co, B, Nd, Co, d.neg_slope, nxt, st); }
             if (rc != LS_OK) return rc;
         }
         std::swap(cur, nxt);
@@ -309,8 +346,9 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     // ---- tail
     const int Cl = p.Co[p.L - 1];
     float* Tc = F(p.o_Tc);
-    rc = gemm_dispatch(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, p.Cdp, B * p.NP * 3, p.Cdp, Cl, 0, st);
+    { PROF(LS_K_GEMM_TAIL, 0, st); rc = gemm_dispatch(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, p.Cdp, B * p.NP * 3, p.Cdp, Cl, 0, st); }
     if (rc != LS_OK) return rc;
+    PROF(LS_K_TAIL, 0, st);
     rc = tail_launch(Tc, p.Cdp, B, p.NP, d.c_dim, W + d.off_inv_t, W + d.off_c_fc0_t, W + d.off_c_misc, d.neg_slope,
                      d.scale_factor, d.center_pred, d.center_pred_scale, pre_normalised ? nullptr : centroid,
                      pre_normalised ? nullptr : scale0, z_so3, z_inv, s_out, t_out, st);
@@ -355,16 +393,18 @@ int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const f
     float* hA = take((size_t)B * M * w * 4);
     float* hB = take((size_t)B * M * w * 4);
     const float* W = m->blob;
-    int rc = sdf_prep_launch(W + d.off_dec_inv_t[0], W + d.off_dec_so3_t[0], W + d.off_dec_len[0], W + d.off_dec_b[0], z_so3,
+    int rc;
+    {
+        PROF(LS_K_SDF_PREP, 0, st);
+        rc = sdf_prep_launch(W + d.off_dec_inv_t[0], W + d.off_dec_so3_t[0], W + d.off_dec_len[0], W + d.off_dec_b[0], z_so3,
                              z_inv, B, L, w, A0, b0, st);
-    if (rc != LS_OK) return rc;
-    if (li >= 0) {
-        rc = sdf_prep_launch(W + d.off_dec_inv_t[li], W + d.off_dec_so3_t[li], W + d.off_dec_len[li], W + d.off_dec_b[li], z_so3,
-                             z_inv, B, L, w, A4, b4, st);
-        if (rc != LS_OK) return rc;
+        if (rc == LS_OK && li >= 0)
+            rc = sdf_prep_launch(W + d.off_dec_inv_t[li], W + d.off_dec_so3_t[li], W + d.off_dec_len[li], W + d.off_dec_b[li],
+                                 z_so3, z_inv, B, L, w, A4, b4, st);
     }
+    if (rc != LS_OK) return rc;
     // layer 0: pure affine in (q, |q|)
-    rc = sdf_affine_launch(query, s, t, A0, b0, B, M, w, w, 0, hA, st);
+    { PROF(LS_K_SDF_AFFINE, 0, st); rc = sdf_affine_launch(query, s, t, A0, b0, B, M, w, w, 0, hA, st); }
     if (rc != LS_OK) return rc;
     float* cur = hA;
     float* nxt = hB;
@@ -372,17 +412,56 @@ int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const f
     for (int l = 1; l < nl - 1; ++l) {
         const int outw = dec_out(d, l);
         if (l == li) {
-            rc = gemm_dispatch(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, B * M, outw, kin, 0, st);
+            { PROF(LS_K_GEMM_SDF, l, st); rc = gemm_dispatch(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, B * M, outw, kin, 0, st); }
             if (rc != LS_OK) return rc;
+            PROF(LS_K_SDF_AFFINE, l, st);
             rc = sdf_affine_launch(query, s, t, A4, b4, B, M, w, w, 1, nxt, st);
         } else {
+            PROF(LS_K_GEMM_SDF, l, st);
             rc = gemm_dispatch(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, B * M, outw, kin, 1, st);
         }
         if (rc != LS_OK) return rc;
         kin = outw;
         std::swap(cur, nxt);
     }
+    PROF(LS_K_SDF_OUT, nl - 1, st);
     return sdf_out_launch(cur, w, kin, W + d.off_dec_w[nl - 1], W + d.off_dec_b[nl - 1], (long long)B * M, sdf, st);
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+static void prof_collect(ls_model* m) {
+    for (auto s : m->prof_streams) (void)hipStreamSynchronize(s);
+    for (auto& r : m->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { m->prof_ms[r.kind][r.layer] += ms; m->prof_n[r.kind][r.layer] += 1; }
+        m->ev_pool.push_back(r.a);
+        m->ev_pool.push_back(r.b);
+    }
+    m->prof.clear();
+}
+
+int ls_profile_begin(ls_model_t* m) {
+    LS_REQUIRE(m, "profile_begin: null model");
+    prof_collect(m);
+    memset(m->prof_ms, 0, sizeof(m->prof_ms));
+    memset(m->prof_n, 0, sizeof(m->prof_n));
+    m->profiling = true;
+    return LS_OK;
+}
+
+int ls_profile_end(ls_model_t* m, ls_profile_entry* out, int max_entries, int* n_out) {
+    LS_REQUIRE(m && out && n_out, "profile_end: null argument");
+    prof_collect(m);
+    m->profiling = false;
+    int n = 0;
+    for (int k = 0; k < LS_K_COUNT; ++k)
+        for (int l = 0; l < 16; ++l)
+            if (m->prof_n[k][l] > 0 && n < max_entries) {
+                out[n].kind = k; out[n].layer = l; out[n].launches = m->prof_n[k][l]; out[n].total_ms = m->prof_ms[k][l];
+                ++n;
+            }
+    *n_out = n;
+    return LS_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,203 @@
+"""Host-side mirror of /root/reference/model_utils.py for the inference path: same names, arguments and return
+conventions (Shape_Prior.encode / encode_fps / decoder, FieldWrapper, load_ckpt_from_log, slice_code_dict), with all
+device work done by liblivingscenes_hip.so.  There is no PyTorch compute path and no CPU fallback.
+"""
+import glob
+import logging
+import os
+import os.path as osp
+
+import torch
+import yaml
+from torch import distributions as dist
+from torch import nn
+
+from . import ops
+from .deepsdf_decoder import DeepSDF_Decoder
+from .vec_dgcnn_atten import VecDGCNN_att
+
+
+def cfg_with_default(cfg, key_list, default):
+    root = cfg
+    for k in key_list:
+        if k in root.keys():
+            root = root[k]
+        else:
+            return default
+    return root
+
+
+def count_param(net):
+    return sum(p.numel() for p in net.parameters())
+
+
+def fps(points, lengths=None, K=50, random_start_point=False):
+    """pytorch3d.ops.sample_farthest_points stand-in (model_utils.py:10): returns (points[idx], idx int64).
+    random_start_point=True (only used when n_fps > 1, model_utils.py:202) rolls the cloud so that a random point
+    becomes index 0 and maps the indices back."""
+    B, N, _ = points.shape
+    if lengths is None and points.dtype == torch.float32 and not random_start_point:
+        idx, pts = ops.fps(points, K, return_points=True)
+        return pts, idx.long()
+    shift = torch.zeros(B, dtype=torch.long, device=points.device)
+    if random_start_point:
+        hi = lengths if lengths is not None else torch.full((B,), N, device=points.device)
+        shift = (torch.rand(B, device=points.device) * hi.to(points.device)).long()
+    if lengths is not None and random_start_point:
+        raise NotImplementedError("random start with ragged lengths is not used by the reference")
+    ar = torch.arange(N, device=points.device)[None]
+    perm = (ar + shift[:, None]) % N
+    rolled = torch.gather(points.float(), 1, perm[..., None].expand(-1, -1, 3)).contiguous()
+    idx = ops.fps(rolled, K, lengths=lengths).long()
+    idx = torch.where(idx >= 0, torch.gather(perm, 1, idx.clamp(min=0)), idx)
+    pts = torch.gather(points, 1, idx.clamp(min=0)[..., None].expand(-1, -1, 3))
+    return pts, idx
+
+
+class FieldWrapper(nn.Module):
+    """model_utils.py:221-263.  forward(query, z_none, c, return_sdf) with the 'inner_deepsdf' decoder: the HIP library
+    folds (z_inv, z_so3, s, t) into the first / skip layers and runs the 768-wide MLP on the matrix cores."""
+
+    def __init__(self, decoder, decoder_type, sdf2occ_factor=-1.0):
+        super().__init__()
+        assert decoder_type == "inner_deepsdf", "only the released decoder_type is implemented"
+        self.F = decoder
+        self.sdf2occ_factor = sdf2occ_factor
+        self.decoder_type = decoder_type
+        self._owner = None  # Shape_Prior (set by it; not a sub-module: avoids a registration cycle)
+
+    def forward(self, query, z_none, c, return_sdf=False):
+        hip = self._owner().hip_model()
+        sdf = hip.sdf_decode(query, c["z_so3"], c["z_inv"], c["s"], c["t"])
+        if return_sdf:
+            return sdf
+        return dist.Bernoulli(logits=self.sdf2occ_factor * sdf)
+
+
+class Shape_Prior(nn.Module):
+    """model_utils.py:83-218 (inference wrapper).  ``cfg`` = {working_dir, field_cfg (yaml path), field_pt (checkpoint)}."""
+
+    def __init__(self, cfg, model_id, use_double=True):
+        super().__init__()
+        self.model_id = model_id
+        working_dir = cfg["working_dir"]
+        with open(osp.join(working_dir, cfg["field_cfg"]), "r") as f:
+            self.field_cfg = yaml.full_load(f)
+        self.decoder_type = cfg_with_default(self.field_cfg, ["model", "decoder_type"], "cbatchnorm")
+        self.encoder_type = cfg_with_default(self.field_cfg, ["model", "encoder_type"], "sim3pointres")
+        if self.encoder_type != "vecdgcnn_atten" or self.decoder_type != "inner_deepsdf":
+            raise NotImplementedError(f"only encoder_type 'vecdgcnn_atten' + decoder_type 'inner_deepsdf' (the released "
+                                      f"config) are implemented, got {self.encoder_type!r} / {self.decoder_type!r}")
+        encoder = VecDGCNN_att(**self.field_cfg["model"]["encoder"])
+        decoder = DeepSDF_Decoder(**self.field_cfg["model"]["decoder"])
+        self.field_input_n = self.field_cfg["dataset"]["n_pcl"]
+        f_param = torch.load(osp.join(working_dir, cfg["field_pt"]), map_location="cpu")
+        field_loaded_ep = f_param["epoch"]
+        f_param = f_param["model_state_dict"]
+        encoder.load_state_dict({".".join(k.split(".")[2:]): f_param[k] for k in f_param if "encoder" in k}, strict=True)
+        decoder.load_state_dict({".".join(k.split(".")[2:]): f_param[k] for k in f_param if "decoder" in k}, strict=True)
+        if cfg_with_default(self.field_cfg, ["model", "use_cls"], False):
+            raise NotImplementedError("cls_head is absent from the released config")
+        self.cls_head = None
+        self._finish(encoder, decoder, use_double,
+                     cfg_with_default(self.field_cfg, ["model", "sdf2occ_factor"], -1.0))
+        logging.info(f"Model {self.model_id} successfully loaded at epoch {field_loaded_ep}.")
+        logging.info(f"Encoder with {count_param(self.encoder)} params")
+        logging.info(f"Decoder with {count_param(self.decoder)} params")
+
+    def _finish(self, encoder, decoder, use_double, sdf2occ_factor):
+        if use_double:
+            raise NotImplementedError("use_double=True: the released inference config runs fp32 "
+                                      "(configs/room4cates.yaml:15); the HIP path is fp32 only")
+        self.use_double = False
+        self.encoder = encoder
+        self.decoder = FieldWrapper(decoder, decoder_type="inner_deepsdf", sdf2occ_factor=sdf2occ_factor)
+        import weakref
+        self.decoder._owner = weakref.ref(self)
+
+    @classmethod
+    def from_state(cls, enc_cfg, dec_cfg, enc_w, dec_w, device="cuda", n_pcl=1024, model_id="chair", sdf2occ_factor=-1.0):
+        """Build from in-memory config/state dicts (synthetic weights, tests, bench) without touching the file system."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.model_id, self.field_cfg = model_id, {"model": {"encoder": enc_cfg, "decoder": dec_cfg}, "dataset": {"n_pcl": n_pcl}}
+        self.decoder_type, self.encoder_type, self.cls_head = "inner_deepsdf", "vecdgcnn_atten", None
+        encoder, decoder = VecDGCNN_att(**enc_cfg), DeepSDF_Decoder(**dec_cfg)
+        encoder.load_state_dict(enc_w, strict=True)
+        decoder.load_state_dict(dec_w, strict=True)
+        self.field_input_n = n_pcl
+        self._finish(encoder, decoder, False, sdf2occ_factor)
+        return self.to(device).eval()
+
+    def hip_model(self):
+        return self.encoder.hip_model(self.decoder.F)
+
+    def encode(self, x):
+        """x [B,3,N] -> {'z_so3' [B,256,3], 'z_inv' [B,256], 's' [B], 't' [B,1,3]}   (model_utils.py:165-197)"""
+        z_so3, z_inv, s, t = self.hip_model().encode(x)
+        return {"z_so3": z_so3, "z_inv": z_inv, "s": s, "t": t.unsqueeze(1)}
+
+    def encode_fps(self, batch_pc, batch_mask, n_fps=1):
+        """model_utils.py:199-215: per instance mask-select, FPS to field_input_n points (n_fps draws), encode, average.
+        All instances are FPS-sampled in ONE ragged launch and encoded in ONE batch (the reference loops with B=1)."""
+        assert batch_pc.shape[-1] == batch_mask.shape[-1], "point cloud and mask must have same length!"
+        B, _, Nmax = batch_pc.shape
+        mask = batch_mask.reshape(B, Nmax).bool()
+        lengths = mask.sum(-1)
+        # stable compaction: valid points first, original order (== pc.T[mask])
+        order = torch.argsort((~mask).to(torch.int8), dim=1, stable=True)
+        pts = torch.gather(batch_pc.transpose(1, 2).float(), 1, order[..., None].expand(-1, -1, 3)).contiguous()
+        K = self.field_input_n
+        if int(lengths.min()) < K:
+            raise ValueError(f"encode_fps: an instance has fewer than {K} valid points")
+        draws = []
+        for _ in range(n_fps):
+            if n_fps == 1:
+                idx = ops.fps(pts, K, lengths=lengths)
+            else:  # random start (model_utils.py:202): roll each valid prefix by a random offset
+                shift = (torch.rand(B, device=pts.device) * lengths).long()
+                ar = torch.arange(Nmax, device=pts.device)[None]
+                perm = torch.where(ar < lengths[:, None], (ar + shift[:, None]) % lengths[:, None].clamp(min=1), ar)
+                rolled = torch.gather(pts, 1, perm[..., None].expand(-1, -1, 3)).contiguous()
+                idx = torch.gather(perm, 1, ops.fps(rolled, K, lengths=lengths).long()).int()
+            draws.append(torch.gather(pts, 1, idx.long()[..., None].expand(-1, -1, 3)))
+        x = torch.stack(draws, 1).reshape(B * n_fps, K, 3).transpose(1, 2).contiguous()
+        emb = self.encode(x)
+        return {k: v.reshape(B, n_fps, *v.shape[1:]).mean(1) for k, v in emb.items()}
+
+    def forward(self, x):
+        raise NotImplementedError()
+
+
+def load_models_dict(cfg, device):
+    """model_utils.py:65-80."""
+    out = nn.ModuleDict()
+    for name in cfg["shape_priors"].keys():
+        c = cfg["shape_priors"][name]
+        c["working_dir"] = cfg["working_dir"]
+        out[name] = Shape_Prior(c, model_id=name,
+                                use_double=cfg_with_default(cfg, ["solver_global", "use_double"], True)).to(device).eval()
+    return out
+
+
+def load_ckpt_from_log(ckpt_path, room_cfg="./configs/room4cates.yaml"):
+    """model_utils.py:267-283: <ckpt_path>/checkpoint/*latest.pt + <ckpt_path>/files_backup/*.yaml."""
+    with open(room_cfg, "r") as f:
+        cfg = yaml.full_load(f)
+    cfg["working_dir"] = os.getcwd()
+    ckpt_list = glob.glob(osp.join(ckpt_path, "checkpoint/*latest.pt"))
+    assert len(ckpt_list) == 1, " Error loading the checkpoint! "
+    cfg["shape_priors"]["chair"]["field_pt"] = ckpt_list[0]
+    field_cfg = glob.glob(osp.join(ckpt_path, "files_backup/*.yaml"))
+    assert len(field_cfg) == 1, "config file not found of more than one config file found!"
+    cfg["shape_priors"]["chair"]["field_cfg"] = field_cfg[0]
+    return load_models_dict(cfg, torch.device("cuda"))
+
+
+def wrap_encoder_output(outputs):
+    return {"z_so3": outputs[2], "z_inv": outputs[-1], "s": outputs[1], "t": outputs[0]}
+
+
+def slice_code_dict(code_dict, index):
+    """model_utils.py:308-318."""
+    return {k: code_dict[k][index][None] for k in ("z_inv", "z_so3", "s", "t")}

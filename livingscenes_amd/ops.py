@@ -150,6 +150,17 @@ class HipModel:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def profile_begin(self):
+        check(load().ls_profile_begin(self._h), "ls_profile_begin")
+
+    def profile_end(self):
+        """-> list of dicts {kind, layer, launches, total_ms} (hipEvent-bracketed per launch)."""
+        buf = (_lib.ProfileEntry * 256)()
+        n = ctypes.c_int(0)
+        check(load().ls_profile_end(self._h, buf, 256, ctypes.byref(n)), "ls_profile_end")
+        return [dict(kind=_lib.KERNEL_KINDS[buf[i].kind], layer=buf[i].layer, launches=buf[i].launches, total_ms=buf[i].total_ms)
+                for i in range(n.value)]
+
     def n_levels(self):
         return [int(self.desc.down_factor[i]) for i in range(self.desc.num_layers)]
 

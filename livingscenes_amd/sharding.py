@@ -1,0 +1,98 @@
+"""Instance sharding across the GPUs of one node.  One process per GPU (torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).  Instances are independent through encode / SDF decode and
+registration pairs are independent after matching, so the data path has NO collective: the only exchanges are
+  * a one-off broadcast of the packed weights (29.6 MB fp32) from rank 0, and
+  * a gather / all-gather of per-instance codes (z_so3 768 + z_inv 256 + s 1 + t 3 = 1028 floats = 4.1 KB) to the rank
+    that runs a scene's 32x32 matcher, and of the (R, t) results (12 floats per pair).
+All messages are KB..MB sized, i.e. latency-bound: flat broadcast / direct gather, never a ring of small buckets."""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def shard_range(n_items, rank=None, world_size=None):
+    """Contiguous block partition of n_items: rank r gets [lo, hi).  Sizes differ by at most one."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    q, r = divmod(n_items, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def broadcast_weights(module, src=0):
+    """Broadcast every parameter of `module` from rank `src` as ONE flat fp32 buffer (one collective, not 78)."""
+    if world()[1] == 1:
+        return
+    params = [p for p in module.parameters()]
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+
+CODE_KEYS = ("z_so3", "z_inv", "s", "t")
+
+
+def pack_codes(emb):
+    """{z_so3 [B,C,3], z_inv [B,C], s [B], t [B,1,3]} -> [B, 4C+4] rows (one message per shard)."""
+    B = emb["z_inv"].shape[0]
+    return torch.cat([emb["z_so3"].reshape(B, -1), emb["z_inv"].reshape(B, -1), emb["s"].reshape(B, 1), emb["t"].reshape(B, 3)], 1).contiguous()
+
+
+def unpack_codes(rows):
+    B, W = rows.shape
+    C = (W - 4) // 4
+    return {"z_so3": rows[:, :3 * C].reshape(B, C, 3), "z_inv": rows[:, 3 * C:4 * C], "s": rows[:, 4 * C], "t": rows[:, 4 * C + 1:].reshape(B, 1, 3)}
+
+
+def all_gather_codes(emb, counts=None):
+    """All ranks receive the codes of all shards, concatenated in rank order.  `counts` = rows per rank (defaults
+    to equal shards); ragged shards are padded to the largest."""
+    rank, ws = world()
+    if ws == 1:
+        return emb
+    rows = pack_codes(emb)
+    if counts is None:
+        counts = [rows.shape[0]] * ws
+    mx = max(counts)
+    pad = rows.new_zeros(mx, rows.shape[1])
+    pad[: rows.shape[0]] = rows
+    bufs = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    return unpack_codes(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0))
+
+
+def gather_codes(emb, dst=0, counts=None):
+    """Rank `dst` receives all codes (rank order); other ranks get None."""
+    rank, ws = world()
+    if ws == 1:
+        return emb
+    rows = pack_codes(emb)
+    if counts is None:
+        counts = [rows.shape[0]] * ws
+    mx = max(counts)
+    pad = rows.new_zeros(mx, rows.shape[1])
+    pad[: rows.shape[0]] = rows
+    bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return unpack_codes(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0))
+
+
+def sharded_encode(model, x_all):
+    """Encode a list/batch of instances x_all [n,3,N] (same tensor on every rank) with each rank encoding its block,
+    then all-gather the codes so that every rank can run the (deterministic, tiny) matcher."""
+    rank, ws = world()
+    n = x_all.shape[0]
+    lo, hi = shard_range(n, rank, ws)
+    emb = model.encode(x_all[lo:hi].contiguous())
+    counts = [shard_range(n, r, ws)[1] - shard_range(n, r, ws)[0] for r in range(ws)]
+    return all_gather_codes(emb, counts)
