@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
                                                       float* __restrict__ out, int total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 5, o = lane & 31;  // two points per wave, 32 lanes each (Co <= 32 per pass)
-    int pid = (blockIdx.x * 4 + wave) * 2 + sub;
+    int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 2 + sub;
     const bool live = pid < total;
     if (!live) pid = total - 1;
     const int b = pid / N;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict_
     const int lpp = Co <= 32 ? 32 : 64;         // lanes per point
     const int ppw = 64 / lpp;                   // points per wave
     const int sub = lane / lpp, ol = lane % lpp;
-    int pid = (blockIdx.x * 4 + wave) * ppw + sub;
+    int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * ppw + sub;
     const bool live = pid < total;
     if (!live) pid = total - 1;
     const int b = pid / Nd;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict_
     float* lq = smem + (size_t)wave * per_wave;
     float* lscore = lq + 3 * Co;
     float* latt = lscore + nh * EK;
-    int pid = blockIdx.x * 4 + wave;
+    int pid = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;  // consecutive points (one instance) share an XCD L2
     const bool live = pid < total;
     if (!live) pid = total - 1;
     const int b = pid / Nd;

@@ -39,6 +39,30 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
     }
 }
 
+// Wave arg-max on the DPP network (no LDS crossbar round trips): the pair (value >= 0, index) is packed into a
+// 64-bit key = float bits << 32 | ~index, so "larger value, then smaller index" is a plain unsigned max.  Stages:
+// quad_perm x2, row_half_mirror, row_mirror (16-lane row max), row_bcast15 (rows 1,3), row_bcast31 (rows 2,3);
+// lane 63 ends up with the wave maximum.  Padding slots must be given the key 0.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void dpp_max_u64(unsigned& hi, unsigned& lo) {
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROWMASK, 0xF, false);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROWMASK, 0xF, false);
+    const bool take = ohi > hi || (ohi == hi && olo > lo);
+    hi = take ? ohi : hi;
+    lo = take ? olo : lo;
+}
+__device__ __forceinline__ int wave_argmax_dpp(float v, int i, bool valid) {
+    unsigned hi = valid ? __float_as_uint(v) + 1u : 0u;  // +1: a valid 0.0 still beats padding
+    unsigned lo = valid ? ~(unsigned)i : 0u;
+    dpp_max_u64<0xB1, 0xF>(hi, lo);   // quad_perm [1,0,3,2]
+    dpp_max_u64<0x4E, 0xF>(hi, lo);   // quad_perm [2,3,0,1]
+    dpp_max_u64<0x141, 0xF>(hi, lo);  // row_half_mirror
+    dpp_max_u64<0x140, 0xF>(hi, lo);  // row_mirror
+    dpp_max_u64<0x142, 0xA>(hi, lo);  // row_bcast15 -> rows 1, 3
+    dpp_max_u64<0x143, 0xC>(hi, lo);  // row_bcast31 -> rows 2, 3
+    return (int)~(unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
 template <int PPL, bool FMA>
 __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
                                                       int N, int K, int32_t* __restrict__ idx_out,
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ 
             md[i] = (md[i] == -INFINITY) ? md[i] : m;
             if (md[i] > bv) { bv = md[i]; bi = i * 64 + lane; }  // ascending index inside the lane: strict '>'
         }
-        wave_argmax(bv, bi);
+        bi = wave_argmax_dpp(bv, bi, bi != INT_MAX);
         last = bi;
         if (lane == 0) {
             out[k] = bi;

@@ -13,9 +13,10 @@
 //     100 floats so the 16-lane groups of ds_read_b128 hit 16 distinct 16-B bank slots (row stride/4 odd);
 //   * each thread owns a 4x4 (query x candidate) register micro-tile: 24 ds_read_b128 feed 192 pair-dims;
 //   * the 64x64 distance tile goes back to LDS and each wave merges 16 query rows into per-query sorted
-//     top-K lists that live in lanes 0..K-1 of two VGPRs (dist, idx): a ballot finds candidates that beat
-//     the current K-th entry under the lexicographic (dist, idx) order, and each survivor is inserted with
-//     one ballot (position) + one DPP row shift -- no LDS, no divergence beyond a wave-uniform loop.
+//     top-K lists that live in the 16 lanes of a DPP row (4 queries per VGPR pair): every lane filters 4
+//     candidates against its row's K-th entry under the lexicographic (dist, idx) order; survivors are
+//     inserted one per row per step with two ballots + one DPP row_shr:1 -- four queries advance per wave
+//     instruction, no LDS traffic besides the tile read, no divergence beyond a wave-uniform loop.
 //   * blockIdx is remapped so that the tiles of one instance run on one XCD and share its L2.
 // Roofline: VALU-bound (3 VALU ops per pair-dim without FMA, 2 with): algorithmic bytes per instance-layer
 // are (Nd+Ns)*3C*4 + Nd*K*4, three orders of magnitude below the VALU time.
@@ -26,6 +27,7 @@ namespace ls {
 constexpr int KNN_TQ = 64;   // queries per workgroup
 constexpr int KNN_TS = 64;   // candidates per tile
 constexpr int KNN_MAXK = 16;
+constexpr int KNN_LD = KNN_TS + 4;  // distance-tile row stride (floats), multiple of 4 for 16-byte rows
 
 template <bool FMA>
 __device__ __forceinline__ float accq(float d, float a, float b) {
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
     constexpr int ROW = (CC == 1) ? 4 : (3 * CC + 4);  // floats per staged row
     __shared__ __attribute__((aligned(16))) float lq[KNN_TQ * ROW];
     __shared__ __attribute__((aligned(16))) float lc[KNN_TS * ROW];
-    __shared__ float ldist[KNN_TQ * (KNN_TS + 1)];
+    __shared__ __attribute__((aligned(16))) float ldist[KNN_TQ * KNN_LD];
     __shared__ int lqrow[KNN_TQ];
 
     const int tid = threadIdx.x;
@@ -70,11 +72,12 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
 
     const int tx = tid & 15, ty = tid >> 4;  // candidates tx+16j, queries ty*4+i
 
-    // per-wave top-K lists for its 16 query rows: entry l of query qq lives in lane l of ld[qq]/li[qq]
-    float ld[16];
-    int li[16];
+    // per-wave top-K lists: group g, row r = lane>>4 -> query wave*16 + g*4 + r, entry e = lane&15 of its sorted list;
+    // rkd/rki = the row's current K-th entry replicated over the row (the admission threshold)
+    float ld[4], rkd[4];
+    int li[4], rki[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ld[i] = INFINITY; li[i] = INT_MAX; }
+    for (int i = 0; i < 4; ++i) { ld[i] = INFINITY; li[i] = INT_MAX; rkd[i] = INFINITY; rki[i] = INT_MAX; }
 
     for (int s0 = 0; s0 < Ns; s0 += KNN_TS) {
         float acc[4][4];
@@ -151,47 +154,74 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
                 }
             }
         }
-        // distance tile -> LDS (ldist is only read in the selection phase below, guarded by barriers)
+        // distance tile -> LDS, candidate c of a query row stored at slot (c & 15) * 4 + (c >> 4): the four distances a
+        // thread owns for one query are contiguous (one ds_write_b128) and so are the four a selection lane reads.
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ldist[(ty * 4 + i) * (KNN_TS + 1) + tx + 16 * j] = acc[i][j];
+            *reinterpret_cast<float4*>(&ldist[(ty * 4 + i) * KNN_LD + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         __syncthreads();
 
-        // ---- selection: wave `wave` merges candidates s0..s0+63 into its 16 query lists
-        const int cand = s0 + lane;
-        const bool cvalid = cand < Ns;
+        // ---- selection, row-parallel: 16-lane row r of group g owns query wave*16 + g*4 + r; its sorted top-K list lives
+        // in the row's lanes (entry e in lane 16r+e).  Each lane filters 4 candidates (c = e + 16j) against the row's K-th
+        // entry; survivors are inserted one per row per step: ballot -> first proposing lane per row -> bpermute the
+        // candidate to the row -> ballot of "list entry < candidate" gives the insert position -> DPP row_shr:1 shifts the
+        // tail.  Four queries advance per wave instruction; the loop is wave-uniform.
+        const int e16 = lane & 15, rowbase = lane & 48;
 #pragma unroll
-        for (int qq = 0; qq < 16; ++qq) {
-            const float d = ldist[(wave * 16 + qq) * (KNN_TS + 1) + lane];
-            const float kd = __shfl(ld[qq], K - 1, 64);
-            const int ki = __shfl(li[qq], K - 1, 64);
-            const bool pass = cvalid && (d < kd || (d == kd && cand < ki));
-            unsigned long long mask = __ballot(pass);
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float cd = __shfl(d, l, 64);
-                const int ci = s0 + l;
-                const bool less = (ld[qq] < cd) || (ld[qq] == cd && li[qq] < ci);
-                const int pos = __builtin_popcountll(__ballot(less) & ((1ull << K) - 1ull));
-                // shift entries >= pos up by one lane, drop the last, insert at pos
-                const float ud = __shfl_up(ld[qq], 1, 64);
-                const int ui = __shfl_up(li[qq], 1, 64);
-                if (lane == pos) { ld[qq] = cd; li[qq] = ci; }
-                else if (lane > pos) { ld[qq] = ud; li[qq] = ui; }
+        for (int g = 0; g < 4; ++g) {
+            const int qrow = wave * 16 + g * 4 + (lane >> 4);
+            const float4 dv = *reinterpret_cast<const float4*>(&ldist[qrow * KNN_LD + e16 * 4]);
+            const int cbase = s0 + e16;
+            float kd = rkd[g];
+            int ki = rki[g];
+            auto passbits = [&]() -> unsigned {
+                unsigned p = 0;
+                p |= (cbase < Ns && (dv.x < kd || (dv.x == kd && cbase < ki))) ? 1u : 0u;
+                p |= (cbase + 16 < Ns && (dv.y < kd || (dv.y == kd && cbase + 16 < ki))) ? 2u : 0u;
+                p |= (cbase + 32 < Ns && (dv.z < kd || (dv.z == kd && cbase + 32 < ki))) ? 4u : 0u;
+                p |= (cbase + 48 < Ns && (dv.w < kd || (dv.w == kd && cbase + 48 < ki))) ? 8u : 0u;
+                return p;
+            };
+            unsigned pend = passbits();
+            unsigned long long m64 = __ballot(pend != 0);
+            while (m64) {
+                const int j = __builtin_ctz(pend | 16u);
+                const float pd = j == 0 ? dv.x : (j == 1 ? dv.y : (j == 2 ? dv.z : dv.w));
+                const int pi = cbase + 16 * j;
+                const unsigned rb = (unsigned)(m64 >> rowbase) & 0xFFFFu;
+                const bool rowhas = rb != 0;
+                const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);  // == rowbase+16 (no lane of this row) if !rowhas
+                const float cd = __int_as_float(__builtin_amdgcn_ds_bpermute(srclane << 2, __float_as_int(pd)));
+                const int ci = __builtin_amdgcn_ds_bpermute(srclane << 2, pi);
+                if (lane == srclane) pend &= pend - 1;
+                const bool less = rowhas && (ld[g] < cd || (ld[g] == cd && li[g] < ci));
+                const unsigned long long l64 = __ballot(less);
+                const int pos = __builtin_popcount((unsigned)(l64 >> rowbase) & 0xFFFFu);
+                const float ud = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ld[g]), 0x111, 0xF, 0xF, false));
+                const int ui = __builtin_amdgcn_update_dpp(0, li[g], 0x111, 0xF, 0xF, false);
+                if (rowhas) {
+                    if (e16 == pos) { ld[g] = cd; li[g] = ci; }
+                    else if (e16 > pos) { ld[g] = ud; li[g] = ui; }
+                }
+                kd = __int_as_float(__builtin_amdgcn_ds_bpermute((rowbase + K - 1) << 2, __float_as_int(ld[g])));
+                ki = __builtin_amdgcn_ds_bpermute((rowbase + K - 1) << 2, li[g]);
+                pend &= passbits();
+                m64 = __ballot(pend != 0);
             }
+            rkd[g] = kd;
+            rki[g] = ki;
         }
     }
 
     // ---- write the sorted lists
 #pragma unroll
-    for (int qq = 0; qq < 16; ++qq) {
-        const int q = q0 + wave * 16 + qq;
-        if (q < Nd && lane < K) {
-            const size_t o = ((size_t)b * Nd + q) * K + lane;
-            idx_out[o] = li[qq] == INT_MAX ? -1 : li[qq];
-            if (dist_out) dist_out[o] = ld[qq];
+    for (int g = 0; g < 4; ++g) {
+        const int q = q0 + wave * 16 + g * 4 + (lane >> 4);
+        const int e = lane & 15;
+        if (q < Nd && e < K) {
+            const size_t o = ((size_t)b * Nd + q) * K + e;
+            idx_out[o] = li[g] == INT_MAX ? -1 : li[g];
+            if (dist_out) dist_out[o] = ld[g];
         }
     }
 }

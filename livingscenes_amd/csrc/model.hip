@@ -24,7 +24,8 @@ int gemm_dispatch(const float*, int, const float*, int, const float*, float*, in
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
 int edge_pool_launch(const float*, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
 int edge_attn_launch(const float*, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
-int prologue_launch(const float*, int, int, float*, float*, float*, hipStream_t);
+int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipStream_t);
+size_t prologue_scratch_floats(int B);
 int transpose_cloud_launch(const float*, int, int, float*, hipStream_t);
 int mean_points_launch(const float*, int, int, int, float*, hipStream_t);
 int vn_act_rows_launch(const float*, int, const float*, int, int, int, int, float, float*, hipStream_t);
@@ -90,7 +91,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_knn, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -137,6 +138,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     }
     p.o_centroid = take((size_t)B * 3 * 4);
     p.o_scale0 = take((size_t)B * 4);
+    p.o_pro = take(prologue_scratch_floats(B) * 4);
     p.o_knn = take((size_t)B * maxKnn * 4);
     p.o_fA = take((size_t)B * maxF * 4);
     p.o_fB = take((size_t)B * maxF * 4);
@@ -176,7 +178,12 @@ int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* b
     return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream);
 }
 int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out, void* stream) {
-    return prologue_launch(x, B, N, pts_out, centroid_out, scale0_out, (hipStream_t)stream);
+    LS_REQUIRE(B > 0, "prologue: empty batch");
+    float* scratch = nullptr;
+    LS_HIP_CHECK(hipMallocAsync((void**)&scratch, prologue_scratch_floats(B) * sizeof(float), (hipStream_t)stream));
+    int rc = prologue_launch(x, B, N, pts_out, centroid_out, scale0_out, scratch, (hipStream_t)stream);
+    LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
+    return rc;
 }
 int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* stream) {
     LS_REQUIRE(n > 0 && m > 0 && D > 0, "cosine_scores: empty problem");
@@ -267,7 +274,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     {
         PROF(LS_K_PROLOGUE, 0, st);
         if (pre_normalised) rc = transpose_cloud_launch(x, B, N, pts0, st);
-        else rc = prologue_launch(x, B, N, pts0, centroid, scale0, st);
+        else rc = prologue_launch(x, B, N, pts0, centroid, scale0, F(p.o_pro), st);
     }
     if (rc != LS_OK) return rc;
 

@@ -16,12 +16,11 @@ __device__ __forceinline__ void top3_insert(float v, float& a, float& b, float& 
     }
 }
 
-__global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__ x, int N, float* __restrict__ pts_out,
-                                                       float* __restrict__ centroid_out, float* __restrict__ scale0_out) {
-    extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N] centred cloud
-    __shared__ float red[3 * 4 + 4 * 3];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* xb = x + (size_t)b * 3 * N;
+constexpr int PRO_SPLIT = 16;  // workgroups per instance for the N^2/2 pair scan
+
+// centroid of instance b, cloud staged (un-centred) into sp[3][N]; identical summation order in every caller
+__device__ __forceinline__ void stage_and_centroid(const float* __restrict__ xb, int N, float* sp, float* red, float c[3]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float s[3] = {0.f, 0.f, 0.f};
     for (int n = tid; n < N; n += 256) {
 #pragma unroll
@@ -30,23 +29,32 @@ __global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__
 #pragma unroll
     for (int a = 0; a < 3; ++a) { s[a] = wave_sum(s[a]); if (lane == 0) red[a * 4 + wave] = s[a]; }
     __syncthreads();
-    float c[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) c[a] = (red[a * 4] + red[a * 4 + 1] + red[a * 4 + 2] + red[a * 4 + 3]) / (float)N;
+    __syncthreads();
+}
+
+// grid (B, PRO_SPLIT): block `by` scans rows i = by, by+PRO_SPLIT, ... against j > i (lanes stride over j: coalesced,
+// conflict-free LDS reads) and writes its private top-3 squared pair distances to partial[b][by][3].
+__global__ __launch_bounds__(256) void prologue_pairs_kernel(const float* __restrict__ x, int N, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N]
+    __shared__ float red[12 + 12];
+    const int b = blockIdx.x, by = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float c[3];
+    stage_and_centroid(x + (size_t)b * 3 * N, N, sp, red, c);
     for (int n = tid; n < N; n += 256) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) sp[a * N + n] -= c[a];
     }
     __syncthreads();
     float t0 = -1.f, t1 = -1.f, t2 = -1.f;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = by; i < N; i += PRO_SPLIT) {
         const float px = sp[i], py = sp[N + i], pz = sp[2 * N + i];
-        for (int j = i + 1; j < N; ++j) {
+        for (int j = i + 1 + tid; j < N; j += 256) {
             const float dx = px - sp[j], dy = py - sp[N + j], dz = pz - sp[2 * N + j];
             top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
         }
     }
-    // merge the 64 private top-3 of a wave, then the 4 waves
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float u0 = __shfl_xor(t0, o, 64), u1 = __shfl_xor(t1, o, 64), u2 = __shfl_xor(t2, o, 64);
@@ -54,8 +62,25 @@ __global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__
     }
     if (lane == 0) { red[12 + wave * 3] = t0; red[12 + wave * 3 + 1] = t1; red[12 + wave * 3 + 2] = t2; }
     __syncthreads();
-    t0 = t1 = t2 = -1.f;
-    for (int i = 0; i < 12; ++i) top3_insert(red[12 + i], t0, t1, t2);
+    if (tid == 0) {
+        t0 = t1 = t2 = -1.f;
+        for (int i = 0; i < 12; ++i) top3_insert(red[12 + i], t0, t1, t2);
+        float* po = partial + ((size_t)b * PRO_SPLIT + by) * 3;
+        po[0] = t0; po[1] = t1; po[2] = t2;
+    }
+}
+
+// grid (B): merge the partial top-3, scale_0, centroid, normalised cloud [B,N,3]
+__global__ __launch_bounds__(256) void prologue_finish_kernel(const float* __restrict__ x, int N, const float* __restrict__ partial,
+                                                              float* __restrict__ pts_out, float* __restrict__ centroid_out,
+                                                              float* __restrict__ scale0_out) {
+    extern __shared__ __attribute__((aligned(16))) float sp[];
+    __shared__ float red[12];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float c[3];
+    stage_and_centroid(x + (size_t)b * 3 * N, N, sp, red, c);
+    float t0 = -1.f, t1 = -1.f, t2 = -1.f;
+    for (int i = 0; i < PRO_SPLIT * 3; ++i) top3_insert(partial[(size_t)b * PRO_SPLIT * 3 + i], t0, t1, t2);
     const float d1 = sqrtf(fmaxf(t0, 0.f)), d2 = sqrtf(fmaxf(t1, 0.f)), d3 = sqrtf(fmaxf(t2, 0.f));
     const float sc = ((((d1 + d1) + d2) + d2) + d3) / 5.0f;
     if (tid == 0) {
@@ -63,7 +88,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__
         centroid_out[b * 3 + 0] = c[0]; centroid_out[b * 3 + 1] = c[1]; centroid_out[b * 3 + 2] = c[2];
     }
     float* po = pts_out + (size_t)b * N * 3;
-    for (int t = tid; t < N * 3; t += 256) { const int n = t / 3, a = t % 3; po[t] = sp[a * N + n] / sc; }
+    for (int t = tid; t < N * 3; t += 256) { const int n = t / 3, a = t % 3; po[t] = (sp[a * N + n] - c[a]) / sc; }
 }
 
 // [B,3,N] -> [B,N,3] without normalisation (pre_normalised path)
@@ -76,17 +101,28 @@ __global__ void transpose_cloud_kernel(const float* __restrict__ x, int N, float
 
 // ---------------------------------------------------------------------------------------------- mean over points
 // dst_f.mean(-1) of vec_dgcnn_atten.py:223: in [B,N,3,C] -> out [B,3,C]; sequential over n (deterministic)
+// block = 16 float4-column groups x 16 row slices; fixed-order LDS combine (bit-reproducible, no atomics)
 __global__ __launch_bounds__(256) void mean_points_kernel(const float* __restrict__ f, int N, int row, float* __restrict__ out) {
-    const int b = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= row) return;
-    const float* p = f + (size_t)b * N * row + col;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int n = 0;
-    for (; n + 3 < N; n += 4) {
-        s0 += p[(size_t)n * row]; s1 += p[(size_t)(n + 1) * row]; s2 += p[(size_t)(n + 2) * row]; s3 += p[(size_t)(n + 3) * row];
+    __shared__ float4 part[16][16];
+    const int b = blockIdx.y, cg = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int col = (blockIdx.x * 16 + cg) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < row) {
+        const float* p = f + (size_t)b * N * row + col;
+        for (int n = rs; n < N; n += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)n * row);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    for (; n < N; ++n) s0 += p[(size_t)n * row];
-    out[(size_t)b * row + col] = ((s0 + s1) + (s2 + s3)) / (float)N;
+    part[rs][cg] = s;
+    __syncthreads();
+    if (rs == 0 && col < row) {
+        float4 t = part[0][cg];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { const float4 v = part[r][cg]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const float inv = 1.0f / (float)N;
+        *reinterpret_cast<float4*>(out + (size_t)b * row + col) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- point-wise VN activation
@@ -240,9 +276,11 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     }
 }
 
-int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, hipStream_t st) {
+size_t prologue_scratch_floats(int B) { return (size_t)B * PRO_SPLIT * 3; }
+int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, float* partial, hipStream_t st) {
     LS_REQUIRE(N >= 3 && N <= 8192, "prologue: N=%d out of range (3..8192)", N);
-    hipLaunchKernelGGL(prologue_kernel, dim3(B), dim3(256), (size_t)3 * N * sizeof(float), st, x, N, pts, centroid, scale0);
+    hipLaunchKernelGGL(prologue_pairs_kernel, dim3(B, PRO_SPLIT), dim3(256), (size_t)3 * N * sizeof(float), st, x, N, partial);
+    hipLaunchKernelGGL(prologue_finish_kernel, dim3(B), dim3(256), (size_t)3 * N * sizeof(float), st, x, N, partial, pts, centroid, scale0);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -254,7 +292,8 @@ int transpose_cloud_launch(const float* x, int B, int N, float* pts, hipStream_t
 }
 int mean_points_launch(const float* f, int B, int N, int C, float* out, hipStream_t st) {
     const int row = 3 * C;
-    hipLaunchKernelGGL(mean_points_kernel, dim3(cdiv(row, 256), B), dim3(256), 0, st, f, N, row, out);
+    LS_REQUIRE(row % 4 == 0, "mean_points: 3*C must be a multiple of 4");
+    hipLaunchKernelGGL(mean_points_kernel, dim3(cdiv(row, 64), B), dim3(256), 0, st, f, N, row, out);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
