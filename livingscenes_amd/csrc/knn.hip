@@ -41,6 +41,29 @@ __device__ __forceinline__ float accq(float d, float a, float b) {
     }
 }
 
+typedef unsigned long long u64;
+
+// (dist >= 0, idx) -> sortable key; invalid candidates get the "empty" key ~0
+__device__ __forceinline__ u64 make_key(float d, int idx, bool valid) {
+    const u64 k = ((u64)__float_as_uint(d) << 32) | (unsigned)idx;
+    return valid ? k : ~0ull;
+}
+__device__ __forceinline__ void key_cx(u64& a, u64& b) {  // compare-exchange: a <= b afterwards
+    const bool sw = b < a;
+    const u64 lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+__device__ __forceinline__ u64 bperm64(int srclane, u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(srclane << 2, (int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(srclane << 2, (int)(unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 dpp_row_shr1(u64 v) {  // lane e of a 16-lane row receives lane e-1's value (lane 0: 0)
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x111, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x111, 0xF, 0xF, false);
+    return ((u64)hi << 32) | lo;
+}
+
 // CC = channels per LDS chunk (32, or 1 for raw xyz clouds where C == 1)
 template <int CC, bool FMA>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
@@ -72,12 +95,11 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
 
     const int tx = tid & 15, ty = tid >> 4;  // candidates tx+16j, queries ty*4+i
 
-    // per-wave top-K lists: group g, row r = lane>>4 -> query wave*16 + g*4 + r, entry e = lane&15 of its sorted list;
-    // rkd/rki = the row's current K-th entry replicated over the row (the admission threshold)
-    float ld[4], rkd[4];
-    int li[4], rki[4];
+    // per-wave top-K lists: group g, row r = lane>>4 -> query wave*16 + g*4 + r, entry e = lane&15 of its sorted key
+    // list; rkey = the row's current K-th key replicated over the row (the admission threshold); ~0 = empty slot
+    u64 lk[4], rkey[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ld[i] = INFINITY; li[i] = INT_MAX; rkd[i] = INFINITY; rki[i] = INT_MAX; }
+    for (int i = 0; i < 4; ++i) { lk[i] = ~0ull; rkey[i] = ~0ull; }
 
     for (int s0 = 0; s0 < Ns; s0 += KNN_TS) {
         float acc[4][4];
@@ -161,55 +183,40 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
             *reinterpret_cast<float4*>(&ldist[(ty * 4 + i) * KNN_LD + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         __syncthreads();
 
-        // ---- selection, row-parallel: 16-lane row r of group g owns query wave*16 + g*4 + r; its sorted top-K list lives
-        // in the row's lanes (entry e in lane 16r+e).  Each lane filters 4 candidates (c = e + 16j) against the row's K-th
-        // entry; survivors are inserted one per row per step: ballot -> first proposing lane per row -> bpermute the
-        // candidate to the row -> ballot of "list entry < candidate" gives the insert position -> DPP row_shr:1 shifts the
-        // tail.  Four queries advance per wave instruction; the loop is wave-uniform.
+        // ---- selection, row-parallel and branch-free.  (dist, idx) pairs are packed into one u64 key
+        // (non-negative float bits << 32 | idx) so the lexicographic order is a single unsigned compare.  The 16-lane row
+        // r of group g owns query wave*16 + g*4 + r; its sorted top-K keys live in the row's lanes (entry e in lane
+        // 16r+e).  Each lane sorts its 4 candidate keys once (c = e + 16j); while any lane's smallest pending key beats
+        // its row's K-th key: ballot -> first proposing lane per row -> bpermute its key to the row -> ballot of
+        // "entry < candidate" gives the insert position -> DPP row_shr:1 shifts the tail.  Four queries advance per
+        // wave instruction; the only control flow is the wave-uniform loop exit.
         const int e16 = lane & 15, rowbase = lane & 48;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int qrow = wave * 16 + g * 4 + (lane >> 4);
             const float4 dv = *reinterpret_cast<const float4*>(&ldist[qrow * KNN_LD + e16 * 4]);
             const int cbase = s0 + e16;
-            float kd = rkd[g];
-            int ki = rki[g];
-            auto passbits = [&]() -> unsigned {
-                unsigned p = 0;
-                p |= (cbase < Ns && (dv.x < kd || (dv.x == kd && cbase < ki))) ? 1u : 0u;
-                p |= (cbase + 16 < Ns && (dv.y < kd || (dv.y == kd && cbase + 16 < ki))) ? 2u : 0u;
-                p |= (cbase + 32 < Ns && (dv.z < kd || (dv.z == kd && cbase + 32 < ki))) ? 4u : 0u;
-                p |= (cbase + 48 < Ns && (dv.w < kd || (dv.w == kd && cbase + 48 < ki))) ? 8u : 0u;
-                return p;
-            };
-            unsigned pend = passbits();
-            unsigned long long m64 = __ballot(pend != 0);
+            u64 k0 = make_key(dv.x, cbase, cbase < Ns), k1 = make_key(dv.y, cbase + 16, cbase + 16 < Ns);
+            u64 k2 = make_key(dv.z, cbase + 32, cbase + 32 < Ns), k3 = make_key(dv.w, cbase + 48, cbase + 48 < Ns);
+            key_cx(k0, k1); key_cx(k2, k3); key_cx(k0, k2); key_cx(k1, k3); key_cx(k1, k2);
+            u64 kk = rkey[g];
+            u64 m64 = __ballot(k0 < kk);
             while (m64) {
-                const int j = __builtin_ctz(pend | 16u);
-                const float pd = j == 0 ? dv.x : (j == 1 ? dv.y : (j == 2 ? dv.z : dv.w));
-                const int pi = cbase + 16 * j;
                 const unsigned rb = (unsigned)(m64 >> rowbase) & 0xFFFFu;
                 const bool rowhas = rb != 0;
-                const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);  // == rowbase+16 (no lane of this row) if !rowhas
-                const float cd = __int_as_float(__builtin_amdgcn_ds_bpermute(srclane << 2, __float_as_int(pd)));
-                const int ci = __builtin_amdgcn_ds_bpermute(srclane << 2, pi);
-                if (lane == srclane) pend &= pend - 1;
-                const bool less = rowhas && (ld[g] < cd || (ld[g] == cd && li[g] < ci));
-                const unsigned long long l64 = __ballot(less);
+                const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);  // rowbase+16 (no lane of this row) if !rowhas
+                const u64 cand = bperm64(srclane, k0);
+                const bool is_src = lane == srclane;
+                k0 = is_src ? k1 : k0; k1 = is_src ? k2 : k1; k2 = is_src ? k3 : k2; k3 = is_src ? ~0ull : k3;
+                const u64 l64 = __ballot(rowhas & (lk[g] < cand));
                 const int pos = __builtin_popcount((unsigned)(l64 >> rowbase) & 0xFFFFu);
-                const float ud = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ld[g]), 0x111, 0xF, 0xF, false));
-                const int ui = __builtin_amdgcn_update_dpp(0, li[g], 0x111, 0xF, 0xF, false);
-                if (rowhas) {
-                    if (e16 == pos) { ld[g] = cd; li[g] = ci; }
-                    else if (e16 > pos) { ld[g] = ud; li[g] = ui; }
-                }
-                kd = __int_as_float(__builtin_amdgcn_ds_bpermute((rowbase + K - 1) << 2, __float_as_int(ld[g])));
-                ki = __builtin_amdgcn_ds_bpermute((rowbase + K - 1) << 2, li[g]);
-                pend &= passbits();
-                m64 = __ballot(pend != 0);
+                const u64 up = dpp_row_shr1(lk[g]);
+                const bool s1 = rowhas & (e16 == pos), s2 = rowhas & (e16 > pos);
+                lk[g] = s1 ? cand : (s2 ? up : lk[g]);
+                kk = bperm64(rowbase + K - 1, lk[g]);
+                m64 = __ballot(k0 < kk);
             }
-            rkd[g] = kd;
-            rki[g] = ki;
+            rkey[g] = kk;
         }
     }
 
@@ -220,8 +227,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
         const int e = lane & 15;
         if (q < Nd && e < K) {
             const size_t o = ((size_t)b * Nd + q) * K + e;
-            idx_out[o] = li[g] == INT_MAX ? -1 : li[g];
-            if (dist_out) dist_out[o] = ld[g];
+            const unsigned hi = (unsigned)(lk[g] >> 32), lo = (unsigned)lk[g];
+            idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lo;
+            if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
         }
     }
 }
