@@ -64,23 +64,58 @@ __device__ __forceinline__ u64 dpp_row_shr1(u64 v) {  // lane e of a 16-lane row
     return ((u64)hi << 32) | lo;
 }
 
+// Stage one 64-row x CC-channel chunk: global rows are x-major ([x][c], c contiguous -> coalesced float4 loads); the LDS
+// image is CANONICAL (dim j = c*3 + x contiguous), so that one ds_read_b128 yields four consecutive summation terms.
+template <int CC>
+struct Stager {
+    // thread -> (row rr = tid>>2, quarter q = tid&3); its float4 number u covers x = u / U2, channels (u % U2)*16 + q*4..+3
+    // (the four threads of a row read 64 contiguous bytes per load; LDS offsets are compile-time per u)
+    static constexpr int U2 = CC / 16;                 // float4-quads per xyz component (2 for CC = 32)
+    static constexpr int PER = 3 * U2;                 // float4 per thread (6)
+    float4 r[PER];
+    __device__ __forceinline__ void load(const float* __restrict__ base, const int* rowmap, int row0, int nrows, size_t row_f,
+                                         int C, int c0, int tid) {
+        const int rr = tid >> 2, q = tid & 3;
+        const int gr = rowmap ? rowmap[rr] : ((row0 + rr) < nrows ? row0 + rr : -1);
+        const float* p = base + (size_t)(gr >= 0 ? gr : 0) * row_f + c0 + q * 4;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)(u / U2) * C + (u % U2) * 16);
+            r[u] = gr >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int ROW, int tid) const {
+        const int rr = tid >> 2, q = tid & 3;
+        float* p0 = lds + rr * ROW + q * 12;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            float* p = p0 + (u % U2) * 48 + (u / U2);
+            p[0] = r[u].x; p[3] = r[u].y; p[6] = r[u].z; p[9] = r[u].w;
+        }
+    }
+};
+
 // CC = channels per LDS chunk (32, or 1 for raw xyz clouds where C == 1)
 template <int CC, bool FMA>
-__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+__global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                   const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int C,
                                                   int K, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-                                                  int qtiles) {
-    constexpr int ROW = (CC == 1) ? 4 : (3 * CC + 4);  // floats per staged row
+                                                  int qtiles, int splits, int tiles_per_split, u64* __restrict__ partial) {
+    constexpr int ROW = (CC == 1) ? 4 : (3 * CC + 4);  // floats per staged row (ROW/4 odd: conflict-free ds_read_b128)
+    constexpr int LC_FLOATS = (KNN_TS * ROW > KNN_TQ * KNN_LD) ? KNN_TS * ROW : KNN_TQ * KNN_LD;
     __shared__ __attribute__((aligned(16))) float lq[KNN_TQ * ROW];
-    __shared__ __attribute__((aligned(16))) float lc[KNN_TS * ROW];
-    __shared__ __attribute__((aligned(16))) float ldist[KNN_TQ * KNN_LD];
+    __shared__ __attribute__((aligned(16))) float lc[LC_FLOATS];   // candidate chunk; re-used as the 64x64 distance tile
     __shared__ int lqrow[KNN_TQ];
+    float* ldist = lc;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = logical / qtiles, qt = logical % qtiles;
+    const int sp = logical % splits;                 // candidate range of this workgroup (split-S for under-filled grids)
+    const int b = (logical / splits) / qtiles, qt = (logical / splits) % qtiles;
     const int q0 = qt * KNN_TQ;
+    const int s_begin = sp * tiles_per_split * KNN_TS;
+    const int s_end = min(Ns, s_begin + tiles_per_split * KNN_TS);
     const size_t row_f = (size_t)3 * C;
     const float* dbase = dstf + (size_t)b * dst_n * row_f;
     const float* sbase = srcf + (size_t)b * Ns * row_f;
@@ -101,80 +136,88 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
 #pragma unroll
     for (int i = 0; i < 4; ++i) { lk[i] = ~0ull; rkey[i] = ~0ull; }
 
-    for (int s0 = 0; s0 < Ns; s0 += KNN_TS) {
+    const int nchunks = (CC == 1) ? 1 : C / CC;
+    const bool q_once = nchunks == 1;  // single chunk: the query tile is loop invariant, stage it once
+
+    if constexpr (CC == 1) {
+        for (int t = tid; t < KNN_TQ * 3; t += 256) {
+            const int r = t / 3, x = t % 3;
+            const int gr = lqrow[r];
+            lq[r * ROW + x] = gr >= 0 ? dbase[(size_t)gr * 3 + x] : 0.0f;
+        }
+    }
+    Stager<(CC == 1 ? 16 : CC)> sq, sc;  // register staging buffers (next chunk in flight under the current compute)
+    if constexpr (CC != 1) {
+        sq.load(dbase, lqrow, 0, 0, row_f, C, 0, tid);
+        sc.load(sbase, nullptr, s_begin, Ns, row_f, C, 0, tid);
+        if (q_once) { sq.store(lq, ROW, tid); }
+    }
+
+    for (int s0 = s_begin; s0 < s_end; s0 += KNN_TS) {
         float acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
 
-        for (int c0 = 0; c0 < C; c0 += CC) {
-            __syncthreads();  // previous chunk / previous selection fully consumed
-            if constexpr (CC == 1) {
-                // raw clouds: 3 floats per point
-                for (int t = tid; t < KNN_TQ * 3; t += 256) {
-                    int r = t / 3, x = t % 3;
-                    int gr = lqrow[r];
-                    lq[r * ROW + x] = gr >= 0 ? dbase[(size_t)gr * 3 + x] : 0.0f;
-                    int s = s0 + r;
-                    lc[r * ROW + x] = s < Ns ? sbase[(size_t)s * 3 + x] : 0.0f;
-                }
-            } else {
-                constexpr int V4 = 3 * CC / 4;  // float4 per row-chunk
-                for (int t = tid; t < KNN_TQ * V4; t += 256) {
-                    int r = t / V4, v = t % V4;
-                    int x = v / (CC / 4), cc = (v % (CC / 4)) * 4;
-                    int gr = lqrow[r];
-                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gr >= 0) val = *reinterpret_cast<const float4*>(dbase + (size_t)gr * row_f + (size_t)x * C + c0 + cc);
-                    *reinterpret_cast<float4*>(&lq[r * ROW + x * CC + cc]) = val;
-                    int s = s0 + r;
-                    float4 vc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (s < Ns) vc = *reinterpret_cast<const float4*>(sbase + (size_t)s * row_f + (size_t)x * C + c0 + cc);
-                    *reinterpret_cast<float4*>(&lc[r * ROW + x * CC + cc]) = vc;
-                }
+        if constexpr (CC == 1) {
+            __syncthreads();  // previous selection finished with ldist (== lc)
+            for (int t = tid; t < KNN_TS * 3; t += 256) {
+                const int r = t / 3, x = t % 3;
+                const int sidx = s0 + r;
+                lc[r * ROW + x] = sidx < Ns ? sbase[(size_t)sidx * 3 + x] : 0.0f;
             }
             __syncthreads();
-            if constexpr (CC == 1) {
-                float qv[4][3], cv[4][3];
+            float qv[4][3], cv[4][3];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int x = 0; x < 3; ++x) {
-                        qv[i][x] = lq[(ty * 4 + i) * ROW + x];
-                        cv[i][x] = lc[(tx + 16 * i) * ROW + x];
+                for (int x = 0; x < 3; ++x) {
+                    qv[i][x] = lq[(ty * 4 + i) * ROW + x];
+                    cv[i][x] = lc[(tx + 16 * i) * ROW + x];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) acc[i][j] = accq<FMA>(acc[i][j], qv[i][x], cv[j][x]);
+            __syncthreads();  // everyone is done reading lc before it becomes the distance tile
+        } else {
+            for (int ch = 0; ch < nchunks; ++ch) {
+                __syncthreads();  // previous chunk's compute / previous tile's selection done with lq, lc
+                if (!q_once) sq.store(lq, ROW, tid);
+                sc.store(lc, ROW, tid);
+                __syncthreads();
+                // prefetch the next chunk (or the next tile's first chunk) into registers
+                {
+                    int nch = ch + 1, ns0 = s0;
+                    if (nch == nchunks) { nch = 0; ns0 = s0 + KNN_TS; }
+                    if (ns0 < s_end) {
+                        if (!q_once) sq.load(dbase, lqrow, 0, 0, row_f, C, nch * CC, tid);
+                        sc.load(sbase, nullptr, ns0, Ns, row_f, C, nch * CC, tid);
                     }
+                }
+#pragma unroll 1
+                for (int d4 = 0; d4 < 3 * CC; d4 += 4) {
+                    float4 qv[4], cv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int x = 0; x < 3; ++x) acc[i][j] = accq<FMA>(acc[i][j], qv[i][x], cv[j][x]);
-            } else {
-#pragma unroll 2
-                for (int c4 = 0; c4 < CC; c4 += 4) {
-                    float4 qv[4][3], cv[4][3];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int x = 0; x < 3; ++x) {
-                            qv[i][x] = *reinterpret_cast<const float4*>(&lq[(ty * 4 + i) * ROW + x * CC + c4]);
-                            cv[i][x] = *reinterpret_cast<const float4*>(&lc[(tx + 16 * i) * ROW + x * CC + c4]);
-                        }
+                    for (int i = 0; i < 4; ++i) {
+                        qv[i] = *reinterpret_cast<const float4*>(&lq[(ty * 4 + i) * ROW + d4]);
+                        cv[i] = *reinterpret_cast<const float4*>(&lc[(tx + 16 * i) * ROW + d4]);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            float a = acc[i][j];
-                            // canonical order: channel-major, xyz-minor
-                            a = accq<FMA>(a, qv[i][0].x, cv[j][0].x); a = accq<FMA>(a, qv[i][1].x, cv[j][1].x); a = accq<FMA>(a, qv[i][2].x, cv[j][2].x);
-                            a = accq<FMA>(a, qv[i][0].y, cv[j][0].y); a = accq<FMA>(a, qv[i][1].y, cv[j][1].y); a = accq<FMA>(a, qv[i][2].y, cv[j][2].y);
-                            a = accq<FMA>(a, qv[i][0].z, cv[j][0].z); a = accq<FMA>(a, qv[i][1].z, cv[j][1].z); a = accq<FMA>(a, qv[i][2].z, cv[j][2].z);
-                            a = accq<FMA>(a, qv[i][0].w, cv[j][0].w); a = accq<FMA>(a, qv[i][1].w, cv[j][1].w); a = accq<FMA>(a, qv[i][2].w, cv[j][2].w);
+                            float a = acc[i][j];  // canonical order j = c*3+x == LDS order
+                            a = accq<FMA>(a, qv[i].x, cv[j].x); a = accq<FMA>(a, qv[i].y, cv[j].y);
+                            a = accq<FMA>(a, qv[i].z, cv[j].z); a = accq<FMA>(a, qv[i].w, cv[j].w);
                             acc[i][j] = a;
                         }
                 }
             }
+            __syncthreads();  // everyone is done reading lc before it becomes the distance tile
         }
         // distance tile -> LDS, candidate c of a query row stored at slot (c & 15) * 4 + (c >> 4): the four distances a
         // thread owns for one query are contiguous (one ds_write_b128) and so are the four a selection lane reads.
@@ -225,7 +268,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
     for (int g = 0; g < 4; ++g) {
         const int q = q0 + wave * 16 + g * 4 + (lane >> 4);
         const int e = lane & 15;
-        if (q < Nd && e < K) {
+        if (q < Nd && splits > 1) {
+            partial[(((size_t)b * Nd + q) * splits + sp) * 16 + e] = e < K ? lk[g] : ~0ull;
+        } else if (q < Nd && e < K) {
             const size_t o = ((size_t)b * Nd + q) * K + e;
             const unsigned hi = (unsigned)(lk[g] >> 32), lo = (unsigned)lk[g];
             idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lo;
@@ -234,29 +279,88 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ dstf
     }
 }
 
+// merge the per-split sorted key lists of every query: one 16-lane row per query, same insertion step as above
+__global__ __launch_bounds__(256) void knn_merge_kernel(const u64* __restrict__ partial, int total_q, int splits, int K,
+                                                        int32_t* __restrict__ idx_out, float* __restrict__ dist_out) {
+    const int lane = threadIdx.x & 63, e16 = lane & 15, rowbase = lane & 48;
+    const int q = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = q < total_q;
+    const u64* pq = partial + (size_t)(live ? q : 0) * splits * 16;
+    u64 lkey = live ? pq[e16] : ~0ull;                       // split 0 is already sorted
+    u64 kk = bperm64(rowbase + K - 1, lkey);
+    for (int s = 1; s < splits; ++s) {
+        u64 k0 = live ? pq[s * 16 + e16] : ~0ull;
+        u64 m64 = __ballot(k0 < kk);
+        while (m64) {
+            const unsigned rb = (unsigned)(m64 >> rowbase) & 0xFFFFu;
+            const bool rowhas = rb != 0;
+            const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);
+            const u64 cand = bperm64(srclane, k0);
+            k0 = (lane == srclane) ? ~0ull : k0;
+            const u64 l64 = __ballot(rowhas & (lkey < cand));
+            const int pos = __builtin_popcount((unsigned)(l64 >> rowbase) & 0xFFFFu);
+            const u64 up = dpp_row_shr1(lkey);
+            const bool s1 = rowhas & (e16 == pos), s2 = rowhas & (e16 > pos);
+            lkey = s1 ? cand : (s2 ? up : lkey);
+            kk = bperm64(rowbase + K - 1, lkey);
+            m64 = __ballot(k0 < kk);
+        }
+    }
+    if (live && e16 < K) {
+        const size_t o = (size_t)q * K + e16;
+        const unsigned hi = (unsigned)(lkey >> 32), lo = (unsigned)lkey;
+        idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lo;
+        if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
+    }
+}
+
+// number of candidate splits for a launch: fill >= ~4 workgroups per CU when the (instance x query-tile) grid is small
+static int knn_choose_splits(int B, int Nd, int Ns) {
+    const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
+    const int blocks = B * qtiles;
+    if (blocks >= 768 || ctiles < 2) return 1;
+    int sp = cdiv(1024, blocks);
+    if (sp > ctiles) sp = ctiles;
+    if (sp > 16) sp = 16;
+    return sp < 1 ? 1 : sp;
+}
+size_t knn_scratch_bytes(int B, int Nd, int Ns) {
+    const int sp = knn_choose_splits(B, Nd, Ns);
+    return sp > 1 ? (size_t)B * Nd * sp * 16 * sizeof(u64) : 0;
+}
+
 template <int CC, bool FMA>
 static int launch_knn(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
-                      int C, int K, int32_t* idx_out, float* dist_out, hipStream_t st) {
-    const int qtiles = cdiv(Nd, KNN_TQ);
-    dim3 grid(B * qtiles), block(256);
+                      int C, int K, int32_t* idx_out, float* dist_out, void* scratch, hipStream_t st) {
+    const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
+    int splits = scratch ? knn_choose_splits(B, Nd, Ns) : 1;
+    const int tps = cdiv(ctiles, splits);
+    splits = cdiv(ctiles, tps);
+    dim3 grid(B * qtiles * splits), block(256);
     hipLaunchKernelGGL((knn_kernel<CC, FMA>), grid, block, 0, st, dst, src, dst_rows, Nd, dst_n, Ns, C, K, idx_out,
-                       dist_out, qtiles);
+                       dist_out, qtiles, splits, tps, (u64*)scratch);
     LS_LAUNCH_CHECK();
+    if (splits > 1) {
+        const int total_q = B * Nd;
+        hipLaunchKernelGGL(knn_merge_kernel, dim3(cdiv(total_q, 16)), dim3(256), 0, st, (const u64*)scratch, total_q, splits, K,
+                           idx_out, dist_out);
+        LS_LAUNCH_CHECK();
+    }
     return LS_OK;
 }
 
 int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C,
-                 int K, unsigned flags, int32_t* idx_out, float* dist_out, hipStream_t st) {
+                 int K, unsigned flags, int32_t* idx_out, float* dist_out, void* scratch, hipStream_t st) {
     LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0 && dst_n > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
     if (C == 1) {
-        return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st)
-                   : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st);
+        return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st)
+                   : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st);
     }
-    return fma ? launch_knn<32, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st)
-               : launch_knn<32, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, st);
+    return fma ? launch_knn<32, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st)
+               : launch_knn<32, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st);
 }
 
 }  // namespace ls

@@ -18,7 +18,8 @@ void set_error(const char* fmt, ...) {
 }
 
 // kernels / launchers defined in the other translation units
-int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, hipStream_t);
+int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, void*, hipStream_t);
+size_t knn_scratch_bytes(int B, int Nd, int Ns);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
@@ -91,7 +92,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -100,7 +101,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     int cur = N;
     p.nlevels = 0;
     p.levelN[0] = N;
-    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0;
+    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0, maxKs = 0;
     for (int i = 0; i < p.L; ++i) {
         p.Ns[i] = cur;
         const int f = d.down_factor[i] > 1 ? d.down_factor[i] : 1;
@@ -125,6 +126,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
         maxC = std::max(maxC, (size_t)p.Co[i]);
         maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
+        maxKs = std::max(maxKs, knn_scratch_bytes(B, p.Nd[i], p.Ns[i]));
     }
     LS_REQUIRE(d.num_knn == 16, "encoder: num_knn=%d unsupported (16)", d.num_knn);
     LS_REQUIRE(p.Ns[p.L - 1] >= 1, "encoder: bad schedule");
@@ -140,6 +142,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_scale0 = take((size_t)B * 4);
     p.o_pro = take(prologue_scratch_floats(B) * 4);
     p.o_knn = take((size_t)B * maxKnn * 4);
+    p.o_knns = take(maxKs + 256);
     p.o_fA = take((size_t)B * maxF * 4);
     p.o_fB = take((size_t)B * maxF * 4);
     p.o_msg = take((size_t)B * maxF * 4);
@@ -167,7 +170,13 @@ int ls_device_count(void) {
 // ------------------------------------------------------------------------------------------------ leaf exports
 int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K,
                unsigned flags, int32_t* idx_out, float* dist_out, void* stream) {
-    return knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, (hipStream_t)stream);
+    LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
+    const size_t sb = knn_scratch_bytes(B, Nd, Ns);
+    void* scratch = nullptr;
+    if (sb) LS_HIP_CHECK(hipMallocAsync(&scratch, sb, (hipStream_t)stream));
+    int rc = knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, scratch, (hipStream_t)stream);
+    if (sb) LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
+    return rc;
 }
 int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out, float* pts_out,
                void* stream) {
@@ -315,14 +324,14 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
         const bool glob = i >= d.res_global_start_layer;
         float* mp = glob ? msg : nxt;
         if (i == 0) {
-            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, st); }
+            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, st); }
             if (rc != LS_OK) return rc;
             LS_REQUIRE(!attn, "encoder: attention at layer 0 unsupported (atten_start_layer >= 1)");
             { PROF(LS_K_EDGE_L0, i, st); rc = edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
         } else {
             const int Cin = p.Cin[i], nc = p.ncols[i];
-            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, st); }
+            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, st); }
             if (rc != LS_OK) return rc;
             { PROF(LS_K_GEMM_EDGE, i, st); rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, st); }
             if (rc != LS_OK) return rc;

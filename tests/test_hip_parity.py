@@ -49,6 +49,17 @@ def test_knn_bit_exact(shape, contract):
     assert np.array_equal(dist.cpu().numpy()[valid], refd[valid])  # distances bit-exact too
 
 
+def test_knn_large_batch_unsplit_path():
+    """B*qtiles >= 768 workgroups -> the single-pass (no candidate split) path, at the encoder's layer-1 shape."""
+    from livingscenes_amd import ops
+    from oracle import canon
+    rng = np.random.default_rng(77)
+    f = rng.standard_normal((48, 1024, 3, 32)).astype(np.float32)
+    ref = canon.knn_c(f, f, 16)
+    ft = torch.from_numpy(f).to(_dev())
+    assert np.array_equal(ops.knn(ft, ft, 16).cpu().numpy(), ref)
+
+
 def test_knn_dst_rows_and_self():
     from livingscenes_amd import ops
     from oracle import canon
