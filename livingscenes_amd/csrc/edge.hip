@@ -220,6 +220,164 @@ __global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------- attention layers, float4 lanes
+// Same math as edge_attn_kernel, re-mapped for memory efficiency: a lane owns FOUR consecutive channels (16-byte
+// gathers: 4x fewer load instructions, 256 B..1 KB contiguous per neighbour row), a point is LPP = Co/(4*NCH) lanes
+// (Co = 64/128/256/512 -> 16/32/64/64 lanes, 4/2/1/1 points per wave), an attention head (16 channels) is one DPP
+// quad, and the per-head scores for all 16 neighbours stay in the quad's registers, so the soft-max over neighbours
+// needs no cross-lane traffic and no LDS at all.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum(float v) { return dpp_add<0x4E>(dpp_add<0xB1>(v)); }
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {  // all-reduce over aligned groups of LPP lanes
+    v = quad_sum(v);
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror -> 16-lane sum in every lane
+    if constexpr (LPP >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LPP >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct F43 { float4 x, y, z; };  // one xyz triple for four channels
+__device__ __forceinline__ F43 ld43(const float* p, int ldt) {
+    F43 r;
+    r.x = *reinterpret_cast<const float4*>(p);
+    r.y = *reinterpret_cast<const float4*>(p + ldt);
+    r.z = *reinterpret_cast<const float4*>(p + 2 * ldt);
+    return r;
+}
+__device__ __forceinline__ F43 add43(const F43& a, const F43& b) {
+    F43 r;
+    r.x = make_float4(a.x.x + b.x.x, a.x.y + b.x.y, a.x.z + b.x.z, a.x.w + b.x.w);
+    r.y = make_float4(a.y.x + b.y.x, a.y.y + b.y.y, a.y.z + b.y.z, a.y.w + b.y.w);
+    r.z = make_float4(a.z.x + b.z.x, a.z.y + b.z.y, a.z.z + b.z.z, a.z.w + b.z.w);
+    return r;
+}
+// VN activation on four channels in place (y := act(y, k))
+__device__ __forceinline__ void act43(F43& y, const F43& k, float oms) {
+    vn_act(y.x.x, y.y.x, y.z.x, k.x.x, k.y.x, k.z.x, oms);
+    vn_act(y.x.y, y.y.y, y.z.y, k.x.y, k.y.y, k.z.y, oms);
+    vn_act(y.x.z, y.y.z, y.z.z, k.x.z, k.y.z, k.z.z, oms);
+    vn_act(y.x.w, y.y.w, y.z.w, k.x.w, k.y.w, k.z.w, oms);
+}
+__device__ __forceinline__ float dot43(const F43& a, const F43& b) {
+    return a.x.x * b.x.x + a.y.x * b.y.x + a.z.x * b.z.x + a.x.y * b.x.y + a.y.y * b.y.y + a.z.y * b.z.y +
+           a.x.z * b.x.z + a.y.z * b.y.z + a.z.z * b.z.z + a.x.w * b.x.w + a.y.w * b.y.w + a.z.w * b.z.w;
+}
+
+template <int LPP, int NCH>
+__global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restrict__ T, int ldt, const int32_t* __restrict__ knn,
+                                                           const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
+                                                           float oms, float inv_sqrt_dk, float* __restrict__ out, int total) {
+    constexpr int PPW = 64 / LPP;
+    // lane-private LDS slots (stride 17: conflict-free): head scores per chunk and |k|^2 per neighbour.  Keeping these
+    // arrays out of VGPRs lets the neighbour loops stay rolled (bounded registers, 2 neighbours of loads in flight).
+    __shared__ float l_score[NCH][256][EK + 1];
+    __shared__ float l_ssk[256][EK + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / LPP, ll = lane % LPP;
+    int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * PPW + sub;
+    const bool live = pid < total;
+    if (!live) pid = total - 1;
+    const int b = pid / Nd;
+    const int drow = dst_rows ? dst_rows[pid] : (pid % Nd);
+    const float* Tb = T + (size_t)b * Ns * 3 * ldt;
+    const float* Td = Tb + (size_t)drow * 3 * ldt;
+    const int32_t* ki = knn + (size_t)pid * EK;
+
+    // ---- A: q = cevn(VecLNA_Q(dst_f[n]))
+    F43 qf[NCH];
+    float ssq = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = (ch * LPP + ll) * 4;
+        qf[ch] = ld43(Td + 8 * Co + c4, ldt);
+        const F43 kd = ld43(Td + 9 * Co + c4, ldt);
+        act43(qf[ch], kd, oms);
+        ssq += dot43(qf[ch], qf[ch]);
+    }
+    const float inv_q = 1.0f / fmaxf(sqrtf(group_sum<LPP>(ssq)), 1e-12f);
+
+    // ---- B: K branch -> per-head scores for the 16 neighbours, Frobenius norms of k
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = (ch * LPP + ll) * 4;
+        const F43 ql = ld43(Td + 6 * Co + c4, ldt), qd = ld43(Td + 7 * Co + c4, ldt);
+#pragma unroll 2
+        for (int k = 0; k < EK; ++k) {
+            const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
+            F43 y = add43(ld43(Tr + 2 * Co + c4, ldt), ql);
+            const F43 kd = add43(ld43(Tr + 3 * Co + c4, ldt), qd);
+            act43(y, kd, oms);
+            const float s2 = dot43(y, y);
+            l_ssk[tid][k] = (ch == 0) ? s2 : l_ssk[tid][k] + s2;
+            l_score[ch][tid][k] = quad_sum(dot43(y, qf[ch]));
+        }
+    }
+    float mx[NCH], sum[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) { mx[ch] = -INFINITY; sum[ch] = 0.f; }
+#pragma unroll 4
+    for (int k = 0; k < EK; ++k) {
+        const float invk = 1.0f / fmaxf(sqrtf(group_sum<LPP>(l_ssk[tid][k])), 1e-12f);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const float v = l_score[ch][tid][k] * inv_q * invk * inv_sqrt_dk;
+            l_score[ch][tid][k] = v;
+            mx[ch] = fmaxf(mx[ch], v);
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {  // soft-max numerators (the 1/sum is applied to the weighted sum below)
+#pragma unroll 4
+        for (int k = 0; k < EK; ++k) {
+            const float ex = expf(l_score[ch][tid][k] - mx[ch]);
+            l_score[ch][tid][k] = ex;
+            sum[ch] += ex;
+        }
+    }
+
+    // ---- C: V branch, weighted sum
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c4 = (ch * LPP + ll) * 4;
+        const F43 ql = ld43(Td + 4 * Co + c4, ldt), qd = ld43(Td + 5 * Co + c4, ldt);
+        F43 acc;
+        acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+        for (int k = 0; k < EK; ++k) {
+            const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
+            F43 y = add43(ld43(Tr + c4, ldt), ql);
+            const F43 kd = add43(ld43(Tr + Co + c4, ldt), qd);
+            act43(y, kd, oms);
+            const float w = l_score[ch][tid][k];
+            acc.x.x += w * y.x.x; acc.x.y += w * y.x.y; acc.x.z += w * y.x.z; acc.x.w += w * y.x.w;
+            acc.y.x += w * y.y.x; acc.y.y += w * y.y.y; acc.y.z += w * y.y.z; acc.y.w += w * y.y.w;
+            acc.z.x += w * y.z.x; acc.z.y += w * y.z.y; acc.z.z += w * y.z.z; acc.z.w += w * y.z.w;
+        }
+        if (live) {
+            const float inv = 1.0f / sum[ch];
+            float* op = out + (size_t)pid * 3 * Co + c4;
+            *reinterpret_cast<float4*>(op) = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
+            *reinterpret_cast<float4*>(op + Co) = make_float4(acc.y.x * inv, acc.y.y * inv, acc.y.z * inv, acc.y.w * inv);
+            *reinterpret_cast<float4*>(op + 2 * Co) = make_float4(acc.z.x * inv, acc.z.y * inv, acc.z.z * inv, acc.z.w * inv);
+        }
+    }
+}
+
+template <int LPP, int NCH>
+static int launch_attn_v4(const float* T, int ldt, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns, int Co,
+                          float neg_slope, float isd, float* out, hipStream_t st) {
+    const int total = B * Nd, ppb = 4 * (64 / LPP);
+    hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, knn, dst_rows, Nd, Ns, Co,
+                       1.0f - neg_slope, isd, out, total);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
 int edge_l0_launch(const float* pts, const int32_t* knn, const float* w0, int B, int N, int Co, float neg_slope, float* out,
                    hipStream_t st) {
     const int total = B * N;
@@ -241,6 +399,13 @@ int edge_pool_launch(const float* T, int ldt, const int32_t* knn, const int32_t*
 int edge_attn_launch(const float* T, int ldt, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns, int Co,
                      int head_c, float neg_slope, float* out, hipStream_t st) {
     LS_REQUIRE(head_c == 16 && Co % 16 == 0, "edge_attn: head width must be 16 and divide Co (head_c=%d Co=%d)", head_c, Co);
+    const float isd = 1.0f / sqrtf(3.0f * head_c);
+    if (ldt % 4 == 0) {
+        if (Co == 64) return launch_attn_v4<16, 1>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+        if (Co == 128) return launch_attn_v4<32, 1>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+        if (Co == 256) return launch_attn_v4<64, 1>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+        if (Co == 512) return launch_attn_v4<64, 2>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+    }
     const int total = B * Nd;
     const size_t smem = (size_t)4 * (3 * Co + 2 * (Co / 16) * EK) * sizeof(float);
     LS_REQUIRE(smem <= 64 * 1024, "edge_attn: Co=%d too wide", Co);
