@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------- pool layers (i >= 1)
-__global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict__ T, int ldt, const int32_t* __restrict__ knn,
+// P table: Tp[b, src point, xyz, ldp] (columns PV_lin | PV_dir [| PK_lin | PK_dir]);
+// Q table: Tq[b, q point, xyz, ldq]   (columns QV_lin | QV_dir [| QK_lin | QK_dir | Qq_lin | Qq_dir]) with NQ rows per
+// instance, indexed by dst_rows[pid] when q_via_rows (one combined table over the source points) else by the point id.
+__global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
+                                                        int NQ, int q_via_rows, const int32_t* __restrict__ knn,
                                                         const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
                                                         float oms, float* __restrict__ out, int total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,9 +83,9 @@ __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict_
     const bool live = pid < total;
     if (!live) pid = total - 1;
     const int b = pid / Nd;
-    const int drow = dst_rows ? dst_rows[pid] : (pid % Nd);
+    const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
     const float* Tb = T + (size_t)b * Ns * 3 * ldt;
-    const float* Td = Tb + (size_t)drow * 3 * ldt;
+    const float* Td = Tq + ((size_t)b * NQ + drow) * 3 * ldq;
     const int32_t* ki = knn + (size_t)pid * EK;
     for (int c0 = 0; c0 < Co; c0 += lpp) {
         const int oc = c0 + ol;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict_
         const int ow = on ? oc : 0;
         float ql[3], qd[3];
 #pragma unroll
-        for (int x = 0; x < 3; ++x) { ql[x] = Td[x * ldt + 2 * Co + ow]; qd[x] = Td[x * ldt + 3 * Co + ow]; }
+        for (int x = 0; x < 3; ++x) { ql[x] = Td[x * ldq + ow]; qd[x] = Td[x * ldq + Co + ow]; }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
         for (int k = 0; k < EK; ++k) {
@@ -108,7 +112,8 @@ __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------- attention layers
 // dynamic LDS per wave: q feature [3][Co] | head scores [Co/16][16] | attention weights [Co/16][16]
-__global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict__ T, int ldt, const int32_t* __restrict__ knn,
+__global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
+                                                        int NQ, int q_via_rows, const int32_t* __restrict__ knn,
                                                         const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
                                                         float oms, float inv_sqrt_dk, float* __restrict__ out, int total) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -122,9 +127,9 @@ __global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict_
     const bool live = pid < total;
     if (!live) pid = total - 1;
     const int b = pid / Nd;
-    const int drow = dst_rows ? dst_rows[pid] : (pid % Nd);
+    const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
     const float* Tb = T + (size_t)b * Ns * 3 * ldt;
-    const float* Td = Tb + (size_t)drow * 3 * ldt;
+    const float* Td = Tq + ((size_t)b * NQ + drow) * 3 * ldq;
     const int32_t* ki = knn + (size_t)pid * EK;
     int nbr[EK];
 #pragma unroll
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict_
     for (int c0 = 0; c0 < Co; c0 += 64) {
         const int oc = c0 + lane;
         if (oc < Co) {
-            float y0 = Td[8 * Co + oc], y1 = Td[ldt + 8 * Co + oc], y2 = Td[2 * ldt + 8 * Co + oc];
-            const float k0 = Td[9 * Co + oc], k1 = Td[ldt + 9 * Co + oc], k2 = Td[2 * ldt + 9 * Co + oc];
+            float y0 = Td[4 * Co + oc], y1 = Td[ldq + 4 * Co + oc], y2 = Td[2 * ldq + 4 * Co + oc];
+            const float k0 = Td[5 * Co + oc], k1 = Td[ldq + 5 * Co + oc], k2 = Td[2 * ldq + 5 * Co + oc];
             vn_act(y0, y1, y2, k0, k1, k2, oms);
             lq[oc] = y0; lq[Co + oc] = y1; lq[2 * Co + oc] = y2;
             ssq += y0 * y0 + y1 * y1 + y2 * y2;
@@ -156,8 +161,8 @@ __global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict_
         float ql[3], qd[3], qv[3];
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-            ql[x] = Td[x * ldt + 6 * Co + ow];
-            qd[x] = Td[x * ldt + 7 * Co + ow];
+            ql[x] = Td[x * ldq + 2 * Co + ow];
+            qd[x] = Td[x * ldq + 3 * Co + ow];
             qv[x] = lq[x * Co + ow];
         }
 #pragma unroll
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict_
         const int ow = on ? oc : 0;
         float ql[3], qd[3];
 #pragma unroll
-        for (int x = 0; x < 3; ++x) { ql[x] = Td[x * ldt + 4 * Co + ow]; qd[x] = Td[x * ldt + 5 * Co + ow]; }
+        for (int x = 0; x < 3; ++x) { ql[x] = Td[x * ldq + ow]; qd[x] = Td[x * ldq + Co + ow]; }
         const float* aw = latt + (ow >> 4) * EK;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -269,7 +274,8 @@ __device__ __forceinline__ float dot43(const F43& a, const F43& b) {
 }
 
 template <int LPP, int NCH>
-__global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restrict__ T, int ldt, const int32_t* __restrict__ knn,
+__global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
+                                                           int NQ, int q_via_rows, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
                                                            float oms, float inv_sqrt_dk, float* __restrict__ out, int total) {
     constexpr int PPW = 64 / LPP;
@@ -283,9 +289,9 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     const bool live = pid < total;
     if (!live) pid = total - 1;
     const int b = pid / Nd;
-    const int drow = dst_rows ? dst_rows[pid] : (pid % Nd);
+    const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
     const float* Tb = T + (size_t)b * Ns * 3 * ldt;
-    const float* Td = Tb + (size_t)drow * 3 * ldt;
+    const float* Td = Tq + ((size_t)b * NQ + drow) * 3 * ldq;
     const int32_t* ki = knn + (size_t)pid * EK;
 
     // ---- A: q = cevn(VecLNA_Q(dst_f[n]))
@@ -294,8 +300,8 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = (ch * LPP + ll) * 4;
-        qf[ch] = ld43(Td + 8 * Co + c4, ldt);
-        const F43 kd = ld43(Td + 9 * Co + c4, ldt);
+        qf[ch] = ld43(Td + 4 * Co + c4, ldq);
+        const F43 kd = ld43(Td + 5 * Co + c4, ldq);
         act43(qf[ch], kd, oms);
         ssq += dot43(qf[ch], qf[ch]);
     }
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = (ch * LPP + ll) * 4;
-        const F43 ql = ld43(Td + 6 * Co + c4, ldt), qd = ld43(Td + 7 * Co + c4, ldt);
+        const F43 ql = ld43(Td + 2 * Co + c4, ldq), qd = ld43(Td + 3 * Co + c4, ldq);
 #pragma unroll 2
         for (int k = 0; k < EK; ++k) {
             const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = (ch * LPP + ll) * 4;
-        const F43 ql = ld43(Td + 4 * Co + c4, ldt), qd = ld43(Td + 5 * Co + c4, ldt);
+        const F43 ql = ld43(Td + c4, ldq), qd = ld43(Td + Co + c4, ldq);
         F43 acc;
         acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
@@ -369,11 +375,12 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
 }
 
 template <int LPP, int NCH>
-static int launch_attn_v4(const float* T, int ldt, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns, int Co,
-                          float neg_slope, float isd, float* out, hipStream_t st) {
+static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
+                          const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float isd, float* out,
+                          hipStream_t st) {
     const int total = B * Nd, ppb = 4 * (64 / LPP);
-    hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, knn, dst_rows, Nd, Ns, Co,
-                       1.0f - neg_slope, isd, out, total);
+    hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn,
+                       dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -386,31 +393,32 @@ int edge_l0_launch(const float* pts, const int32_t* knn, const float* w0, int B,
     return LS_OK;
 }
 
-int edge_pool_launch(const float* T, int ldt, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns, int Co,
-                     float neg_slope, float* out, hipStream_t st) {
+int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
+                     const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st) {
     const int total = B * Nd;
     const int ppb = (Co <= 32) ? 8 : 4;
-    hipLaunchKernelGGL(edge_pool_kernel, dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, knn, dst_rows, Nd, Ns, Co,
-                       1.0f - neg_slope, out, total);
+    hipLaunchKernelGGL(edge_pool_kernel, dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns,
+                       Co, 1.0f - neg_slope, out, total);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
 
-int edge_attn_launch(const float* T, int ldt, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns, int Co,
-                     int head_c, float neg_slope, float* out, hipStream_t st) {
+int edge_attn_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
+                     const int32_t* dst_rows, int B, int Nd, int Ns, int Co, int head_c, float neg_slope, float* out,
+                     hipStream_t st) {
     LS_REQUIRE(head_c == 16 && Co % 16 == 0, "edge_attn: head width must be 16 and divide Co (head_c=%d Co=%d)", head_c, Co);
     const float isd = 1.0f / sqrtf(3.0f * head_c);
-    if (ldt % 4 == 0) {
-        if (Co == 64) return launch_attn_v4<16, 1>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
-        if (Co == 128) return launch_attn_v4<32, 1>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
-        if (Co == 256) return launch_attn_v4<64, 1>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
-        if (Co == 512) return launch_attn_v4<64, 2>(T, ldt, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+    if (ldt % 4 == 0 && ldq % 4 == 0) {
+        if (Co == 64) return launch_attn_v4<16, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+        if (Co == 128) return launch_attn_v4<32, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+        if (Co == 256) return launch_attn_v4<64, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+        if (Co == 512) return launch_attn_v4<64, 2>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
     }
     const int total = B * Nd;
     const size_t smem = (size_t)4 * (3 * Co + 2 * (Co / 16) * EK) * sizeof(float);
     LS_REQUIRE(smem <= 64 * 1024, "edge_attn: Co=%d too wide", Co);
-    hipLaunchKernelGGL(edge_attn_kernel, dim3(cdiv(total, 4)), dim3(256), smem, st, T, ldt, knn, dst_rows, Nd, Ns, Co,
-                       1.0f - neg_slope, 1.0f / sqrtf(3.0f * head_c), out, total);
+    hipLaunchKernelGGL(edge_attn_kernel, dim3(cdiv(total, 4)), dim3(256), smem, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns,
+                       Co, 1.0f - neg_slope, isd, out, total);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

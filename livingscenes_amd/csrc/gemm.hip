@@ -21,9 +21,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 
+// Optional row gather (down-sampled encoder layers): output row m = (b*gNd + n)*3 + x reads A row
+// (b*gNs + a_rows[b*gNd + n])*3 + x, i.e. the GEMM runs only on the FPS-selected points of each instance.
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
-                                                       int ldc, int M, int N, int K, int relu, int ntiles_n) {
+                                                       int ldc, int M, int N, int K, int relu, int ntiles_n,
+                                                       const int32_t* __restrict__ a_rows, int gNd, int gNs) {
     __shared__ __attribute__((aligned(16))) float As[GM * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[GN * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,12 +47,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // staging map: 128 rows x 4 float4 per operand tile = 512 float4, two per thread
     const int sr0 = tid >> 2, sk = (tid & 3) * 4;  // rows sr0 and sr0+64
     float4 ra[2], rb[2];
+    long long arow[2];  // source row of A for this thread's two staged rows (-1 = out of range)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int gm = m0 + sr0 + h * 64;
+        long long r = gm < M ? gm : -1;
+        if (a_rows && gm < M) {
+            const int pt = gm / 3, x = gm - pt * 3;
+            const int bb = pt / gNd;
+            r = ((long long)bb * gNs + a_rows[pt]) * 3 + x;
+        }
+        arow[h] = r;
+    }
     auto gload = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = sr0 + h * 64;
-            const int gm = m0 + r, gn = n0 + r, gk = k0 + sk;
-            ra[h] = (gm < M && gk < K) ? *reinterpret_cast<const float4*>(A + (size_t)gm * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int gn = n0 + r, gk = k0 + sk;
+            ra[h] = (arow[h] >= 0 && gk < K) ? *reinterpret_cast<const float4*>(A + (size_t)arow[h] * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[h] = (gn < N && gk < K) ? *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -111,13 +126,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
+int gemm_dispatch_gather(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
+                         int K, int relu, const int32_t* a_rows, int gNd, int gNs, hipStream_t st);
 int gemm_dispatch(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
                   int K, int relu, hipStream_t st) {
+    return gemm_dispatch_gather(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, st);
+}
+int gemm_dispatch_gather(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
+                         int K, int relu, const int32_t* a_rows, int gNd, int gNs, hipStream_t st) {
     LS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem (M=%d N=%d K=%d)", M, N, K);
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
     const int tm = cdiv(M, GM), tn = cdiv(N, GN);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
+                       gNd, gNs);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

@@ -23,8 +23,9 @@ size_t knn_scratch_bytes(int B, int Nd, int Ns);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
-int edge_pool_launch(const float*, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
-int edge_attn_launch(const float*, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
+int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
+int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
+int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t);
 int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipStream_t);
 size_t prologue_scratch_floats(int B);
 int transpose_cloud_launch(const float*, int, int, float*, hipStream_t);
@@ -122,7 +123,11 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         LS_REQUIRE(p.Co[i] % 16 == 0, "encoder: feat_dim[%d]=%d must be a multiple of 16", i, p.Co[i]);
         if (i > 0) LS_REQUIRE(p.Cin[i] % 32 == 0, "encoder: feat_dim[%d]=%d must be a multiple of 32 (k-NN chunking)", i - 1, p.Cin[i]);
         maxF = std::max(maxF, (size_t)p.Nd[i] * 3 * p.Co[i]);
-        maxT = std::max(maxT, (size_t)p.Ns[i] * 3 * p.ncols[i]);
+        {   // combined table over the source points, or split P (source points) + Q (destination points) tables
+            const int pc = (attn ? 4 : 2) * p.Co[i], qc = p.ncols[i] - pc;
+            const size_t need = (f > 1) ? (size_t)p.Ns[i] * 3 * pc + (size_t)p.Nd[i] * 3 * qc : (size_t)p.Ns[i] * 3 * p.ncols[i];
+            maxT = std::max(maxT, need);
+        }
         maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
         maxC = std::max(maxC, (size_t)p.Co[i]);
         maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
@@ -333,10 +338,26 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             const int Cin = p.Cin[i], nc = p.ncols[i];
             { PROF(LS_K_KNN, i, st); rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, st); }
             if (rc != LS_OK) return rc;
-            { PROF(LS_K_GEMM_EDGE, i, st); rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, st); }
+            const int pc = (attn ? 4 : 2) * Co, qc = nc - pc;  // neighbour-side / destination-side column counts
+            const float* Tq;
+            int ldp, ldq, NQ, qvr;
+            if (dst_rows) {
+                // down-sampled layer: P table on all source points, Q table only on the FPS-selected destination points
+                float* Tq_w = T + (size_t)B * Ns * 3 * pc;
+                PROF(LS_K_GEMM_EDGE, i, st);
+                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, st);
+                if (rc == LS_OK)
+                    rc = gemm_dispatch_gather(cur, Cin, W + d.off_edge[i] + (size_t)pc * Cin, Cin, nullptr, Tq_w, qc, B * Nd * 3, qc, Cin,
+                                              0, dst_rows, Nd, Ns, st);
+                Tq = Tq_w; ldp = pc; ldq = qc; NQ = Nd; qvr = 0;
+            } else {
+                PROF(LS_K_GEMM_EDGE, i, st);
+                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, st);
+                Tq = T + pc; ldp = nc; ldq = nc; NQ = Ns; qvr = 1;
+            }
             if (rc != LS_OK) return rc;
-            if (attn) { PROF(LS_K_EDGE_ATTN, i, st); rc = edge_attn_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st); }
-            else { PROF(LS_K_EDGE_POOL, i, st); rc = edge_pool_launch(T, nc, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, mp, st); }
+            if (attn) { PROF(LS_K_EDGE_ATTN, i, st); rc = edge_attn_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st); }
+            else { PROF(LS_K_EDGE_POOL, i, st); rc = edge_pool_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
         }
         if (glob) {
