@@ -1,0 +1,170 @@
+"""GPU tests of the reference-facing Python surface (model_utils / lib_more mirrors) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from livingscenes_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), (b.detach().cpu() if torch.is_tensor(b) else torch.as_tensor(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def small_prior():
+    from livingscenes_amd.model_utils import Shape_Prior
+    ecfg, dcfg = synth.small_encoder_cfg(), synth.small_decoder_cfg()
+    ew, dw = synth.make_encoder_weights(ecfg, 4), synth.make_decoder_weights(dcfg, 4)
+    return Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=_dev(), n_pcl=128), (ecfg, dcfg, ew, dw)
+
+
+def test_shape_prior_encode_and_decoder(small_prior):
+    from oracle import net
+    sp, (ecfg, dcfg, ew, dw) = small_prior
+    x = synth.make_instances(5, 128, seed=8)
+    emb = sp.encode(x.to(_dev()))
+    ref = net.shape_prior_encode(ew, ecfg, x)
+    assert emb["t"].shape == (5, 1, 3) and emb["z_so3"].shape == (5, ecfg["c_dim"], 3)
+    for k in ("z_so3", "z_inv", "s", "t"):
+        assert relerr(emb[k], ref[k]) < TOL, k
+    q = synth.make_queries(5, 200, seed=1).to(_dev()) * emb["s"][:, None, None] + emb["t"]
+    sdf = sp.decoder(q, None, emb, return_sdf=True)
+    ref_sdf = net.field_query(dw, dcfg, q.cpu(), {k: v.cpu() for k, v in emb.items()})
+    assert relerr(sdf, ref_sdf) < TOL
+    occ = sp.decoder(q, None, emb)  # Bernoulli(logits = sdf2occ_factor * sdf), model_utils.py:263
+    assert torch.allclose(occ.logits, -sdf)
+
+
+def test_encode_fps_ragged_matches_reference_loop(small_prior):
+    """encode_fps (model_utils.py:199-215): mask-select, FPS to n_pcl, encode -- vs the oracle run instance by instance."""
+    from oracle import net
+    sp, (ecfg, dcfg, ew, dw) = small_prior
+    g = torch.Generator().manual_seed(3)
+    B, Nmax = 3, 700
+    pc = torch.randn(B, 3, Nmax, generator=g)
+    mask = torch.zeros(B, 1, Nmax, dtype=torch.bool)
+    lens = [700, 333, 150]
+    for b, L in enumerate(lens):
+        perm = torch.randperm(Nmax, generator=g)[:L]
+        mask[b, 0, perm] = True
+    emb = sp.encode_fps(pc.to(_dev()), mask.to(_dev()))
+    for b in range(B):
+        valid = pc[b].T[mask[b, 0]].unsqueeze(0)
+        pts, _ = net.sample_farthest_points(valid, 128)
+        ref = net.shape_prior_encode(ew, ecfg, pts.transpose(1, 2).contiguous())
+        for k in ("z_so3", "z_inv", "s", "t"):
+            assert relerr(emb[k][b:b + 1], ref[k]) < TOL, (b, k)
+    emb2 = sp.encode_fps(pc.to(_dev()), mask.to(_dev()), n_fps=2)  # random-start draws, averaged
+    assert emb2["z_inv"].shape == emb["z_inv"].shape and torch.isfinite(emb2["z_so3"]).all()
+
+
+def test_all_matchers_vs_golden(golden):
+    from livingscenes_amd.lib_more import matcher_new as mn
+    g = golden("matchers")
+    d = _dev()
+    for name in ("n1", "n2", "n3", "n5", "n32"):
+        r = mn.sequential_matcher(torch.from_numpy(g[f"seq_{name}_a"]).to(d), torch.from_numpy(g[f"seq_{name}_b"]).to(d))
+        assert r["matches0"].dtype == torch.int64
+        assert np.array_equal(r["matches0"].cpu().numpy(), g[f"seq_{name}_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g[f"seq_{name}_m1"])
+    a, b = torch.from_numpy(g["nn_a"]).to(d), torch.from_numpy(g["nn_b"]).to(d)
+    r = mn.nn_matcher(a.T[None], b.T[None])
+    assert np.array_equal(r["matches0"].cpu().numpy(), g["nn_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g["nn_m1"])
+    r = mn.sinkhorn_matcher(a.T[None], b.T[None])
+    assert np.array_equal(r["matches0"].cpu().numpy(), g["sk_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g["sk_m1"])
+    src = {"z_inv": torch.from_numpy(g["eqsrc_z_inv"]).to(d), "z_so3": torch.from_numpy(g["eqsrc_z_so3"]).to(d)}
+    tgt = {"z_inv": torch.from_numpy(g["eqtgt_z_inv"]).to(d), "z_so3": torch.from_numpy(g["eqtgt_z_so3"]).to(d)}
+    for nm, fn in (("eq", mn.eq_seq_matcher), ("sim3", mn.sim3_seq_matcher)):
+        r = fn(src, tgt)
+        assert np.array_equal(r["matches0"].cpu().numpy(), g[f"{nm}_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g[f"{nm}_m1"])
+
+
+def test_more_solver_matching_registration_end2end(small_prior):
+    """More_Solver mirror: _solve_object_matching (5 methods), _solve_pairwise_registration(optim=False) incl. ICP,
+    _transform_latent and _solve_end2end vs the oracle pipeline (FPS -> encode -> Kabsch -> ICP) pair by pair."""
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    from oracle import more, net
+    sp, (ecfg, dcfg, ew, dw) = small_prior
+    d = _dev()
+    cfg = {"shape_priors": {"n_input_point": 128, "prior_name": "chair", "ckpt_dir": ""}, "fps": {"n_init": 1, "random_start": False}}
+    solver = More_Solver(cfg, model=sp)
+    sc = synth.make_scene_pair(4, 300, seed=11, noise=0.002)
+    ref_x, res_x = sc["ref"], sc["rescan"]
+    # --- pairwise registration (raw clouds of 300 points -> FPS 128 -> encode -> Kabsch -> ICP)
+    R, t = solver._solve_pairwise_registration(ref_x[:1].to(d), res_x[:1].to(d))
+    p1, _ = net.sample_farthest_points(ref_x[:1], 128)
+    p2, _ = net.sample_farthest_points(res_x[:1], 128)
+    c1 = net.shape_prior_encode(ew, ecfg, p1.transpose(1, 2).contiguous())
+    c2 = net.shape_prior_encode(ew, ecfg, p2.transpose(1, 2).contiguous())
+    Rk, tk, _, _ = more.kabsch_transformation_estimation(c1["z_so3"] + c1["t"], c2["z_so3"] + c2["t"])
+    Ri, Ti, _, _, _ = more.iterative_closest_point(p1, p2, Rk.transpose(1, 2).contiguous(), tk.squeeze(2))
+    assert R.shape == (1, 3, 3) and t.shape == (1, 3, 1)
+    assert relerr(R, Ri.transpose(1, 2)) < 1e-3 and relerr(t, Ti.unsqueeze(2)) < 1e-3
+    with pytest.raises(NotImplementedError):
+        solver._solve_pairwise_registration(ref_x[:1].to(d), res_x[:1].to(d), optim=True)
+    # --- matching on encoded scenes, every method returns int64 maps consistent with the oracle
+    emb_r = sp.encode(ref_x.transpose(1, 2).contiguous().to(d))
+    emb_s = sp.encode(res_x.transpose(1, 2).contiguous().to(d))
+    cr = {k: v.cpu() for k, v in emb_r.items()}
+    cs = {k: v.cpu() for k, v in emb_s.items()}
+    m = solver._solve_object_matching(emb_r, emb_s, "sequential")
+    assert np.array_equal(m["matches0"].cpu().numpy(), more.sequential_matcher(cr["z_inv"], cs["z_inv"])["matches0"].numpy())
+    for method in ("nn", "sinkhorn", "sim3_seq", "eq_seq"):
+        r = solver._solve_object_matching(emb_r, emb_s, method)
+        assert r["matches0"].shape == (4,) and r["matches1"].shape == (4,)
+    assert np.array_equal(solver._solve_object_matching(emb_r, emb_s, "eq_seq")["matches0"].cpu().numpy(),
+                          more.eq_seq_matcher(cr, cs)["matches0"].numpy())
+    # --- _transform_latent (more_solver.py:230-244)
+    T = torch.eye(4)[None, :3].clone().to(d)
+    T[0, :, 3] = torch.tensor([1.0, 2.0, 3.0])
+    one = {k: v[:1] for k, v in emb_r.items()}
+    tl = solver._transform_latent(one, T)
+    assert torch.allclose(tl["t"], one["t"] + T[:, :, 3][:, None]) and torch.equal(tl["z_so3"], one["z_so3"])
+    # --- end2end on masked, padded scenes
+    def scene(x):
+        n, N, _ = x.shape
+        pc = torch.zeros(n, 3, N + 50)
+        pc[:, :, :N] = x.transpose(1, 2)
+        mask = torch.zeros(n, 1, N + 50, dtype=torch.bool)
+        mask[:, :, :N] = True
+        return {"pc": pc.to(d), "pc_mask": mask.to(d)}
+    out = solver._solve_end2end(scene(ref_x), scene(res_x))
+    assert len(out["registration"]) == 4 and out["matches"].shape == (4,)
+    for i, j in enumerate(out["matches"].tolist()):
+        if j >= 0:
+            assert out["registration"][i].shape == (1, 4, 4) and abs(float(torch.det(out["registration"][i][0, :3, :3])) - 1) < 1e-3
+
+
+def test_flyingshape_style_harness_vs_oracle(small_prior):
+    """eval_matching / eval_relocalization counterparts: metrics from the HIP path == metrics from the oracle pipeline."""
+    from livingscenes_amd import harness
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    from oracle import more, net
+    sp, (ecfg, dcfg, ew, dw) = small_prior
+    cfg = {"shape_priors": {"n_input_point": 128, "prior_name": "chair", "ckpt_dir": ""}, "fps": {"n_init": 1}}
+    solver = More_Solver(cfg, model=sp)
+    scenes = [synth.make_scene_pair(6, 128, seed=40 + i, noise=0.002) for i in range(2)]
+    m = harness.eval_matching(scenes, solver)
+    r = harness.eval_relocalization(scenes, solver, icp=False)
+    ok = tot = 0
+    rre = []
+    for sc in scenes:
+        cr = net.shape_prior_encode(ew, ecfg, sc["ref"].transpose(1, 2).contiguous())
+        cs = net.shape_prior_encode(ew, ecfg, sc["rescan"].transpose(1, 2).contiguous())
+        mm = more.sequential_matcher(cr["z_inv"], cs["z_inv"])["matches0"]
+        ok += int((mm == torch.arange(6)).sum()); tot += 6
+        R, t, _, _ = more.kabsch_transformation_estimation(cr["z_so3"] + cr["t"], cs["z_so3"] + cs["t"])
+        gt = more.se3_concatenate(sc["rescan_T"][:, :3], more.se3_inverse(sc["ref_T"][:, :3]))
+        e = more.rotation_error(R, gt[:, :, :3]).reshape(-1)
+        rre.append(torch.minimum(torch.minimum(e, (180 - e).abs()), (90 - e).abs()))
+    assert abs(m["object_recall"] - 100.0 * ok / tot) < 1e-9
+    assert np.allclose(r["rre"], torch.cat(rre).numpy(), atol=2e-2)  # degrees; acos amplifies fp32 round-off near 0/180
