@@ -57,6 +57,10 @@ def algorithmic_cost(kind, layer, cfg, B, N):
         return B * ((Nd + Ns) * D * f4 + Nd * 16 * 4), 3.0 * B * Nd * Ns * D
     if kind == "gemm_edge":
         nc = (10 if L["attn"] else 4) * Co
+        pc = (4 if L["attn"] else 2) * Co
+        if Nd != Ns:  # down-sampled layer: neighbour-side columns on Ns rows, destination-side columns on Nd rows
+            rows_cols = Ns * pc + Nd * (nc - pc)
+            return B * 3 * (Ns * Cin + Nd * Cin + rows_cols) * f4 + nc * Cin * f4, 2.0 * B * 3 * Cin * rows_cols
         return B * Ns * 3 * (Cin + nc) * f4 + nc * Cin * f4, 2.0 * B * Ns * 3 * Cin * nc
     if kind == "edge_attn":
         gather = B * Nd * 16 * 4 * Co * 3 * f4          # P_lin/P_dir of the K and V branches at 16 neighbours
@@ -93,6 +97,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="instances per step per GPU (two scenes of batch/2 objects)")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--cpu-instances", type=int, default=8, help="bounded sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads for the CPU baseline: the reference's op sequence peaks at ~16 threads on the GPU box's "
+                         "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; scripts/cpu_threads_probe.py)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
@@ -204,7 +211,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_instances > 0:
         from oracle import more, net  # the checker, timed as the CPU baseline ("port" of the reference's op sequence)
         nb = args.cpu_instances
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
         xc = x[:nb].cpu()
         ewc, _ = synth.make_encoder_weights(ecfg, 0), None
         t1 = time.perf_counter()
