@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liblivingscenes_hip.so")
 
 LS_MAX_LAYERS = 8
 FLAG_CONTRACT_FMA = 1
+FLAG_KNN_MFMA_FILTER = 2
 
 
 class LsError(RuntimeError):

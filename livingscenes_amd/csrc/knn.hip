@@ -20,80 +20,9 @@
 //   * blockIdx is remapped so that the tiles of one instance run on one XCD and share its L2.
 // Roofline: VALU-bound (3 VALU ops per pair-dim without FMA, 2 with): algorithmic bytes per instance-layer
 // are (Nd+Ns)*3C*4 + Nd*K*4, three orders of magnitude below the VALU time.
-#include "ls_common.h"
+#include "knn_common.h"
 
 namespace ls {
-
-constexpr int KNN_TQ = 64;   // queries per workgroup
-constexpr int KNN_TS = 64;   // candidates per tile
-constexpr int KNN_MAXK = 16;
-constexpr int KNN_LD = KNN_TS + 4;  // distance-tile row stride (floats), multiple of 4 for 16-byte rows
-
-template <bool FMA>
-__device__ __forceinline__ float accq(float d, float a, float b) {
-#pragma clang fp contract(off)
-    const float diff = a - b;
-    if constexpr (FMA) {
-        return __builtin_fmaf(diff, diff, d);
-    } else {
-        const float p = diff * diff;
-        return d + p;
-    }
-}
-
-typedef unsigned long long u64;
-
-// (dist >= 0, idx) -> sortable key; invalid candidates get the "empty" key ~0
-__device__ __forceinline__ u64 make_key(float d, int idx, bool valid) {
-    const u64 k = ((u64)__float_as_uint(d) << 32) | (unsigned)idx;
-    return valid ? k : ~0ull;
-}
-__device__ __forceinline__ void key_cx(u64& a, u64& b) {  // compare-exchange: a <= b afterwards
-    const bool sw = b < a;
-    const u64 lo = sw ? b : a, hi = sw ? a : b;
-    a = lo; b = hi;
-}
-__device__ __forceinline__ u64 bperm64(int srclane, u64 v) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(srclane << 2, (int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(srclane << 2, (int)(unsigned)(v >> 32));
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 dpp_row_shr1(u64 v) {  // lane e of a 16-lane row receives lane e-1's value (lane 0: 0)
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x111, 0xF, 0xF, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x111, 0xF, 0xF, false);
-    return ((u64)hi << 32) | lo;
-}
-
-// Stage one 64-row x CC-channel chunk: global rows are x-major ([x][c], c contiguous -> coalesced float4 loads); the LDS
-// image is CANONICAL (dim j = c*3 + x contiguous), so that one ds_read_b128 yields four consecutive summation terms.
-template <int CC>
-struct Stager {
-    // thread -> (row rr = tid>>2, quarter q = tid&3); its float4 number u covers x = u / U2, channels (u % U2)*16 + q*4..+3
-    // (the four threads of a row read 64 contiguous bytes per load; LDS offsets are compile-time per u)
-    static constexpr int U2 = CC / 16;                 // float4-quads per xyz component (2 for CC = 32)
-    static constexpr int PER = 3 * U2;                 // float4 per thread (6)
-    float4 r[PER];
-    __device__ __forceinline__ void load(const float* __restrict__ base, const int* rowmap, int row0, int nrows, size_t row_f,
-                                         int C, int c0, int tid) {
-        const int rr = tid >> 2, q = tid & 3;
-        const int gr = rowmap ? rowmap[rr] : ((row0 + rr) < nrows ? row0 + rr : -1);
-        const float* p = base + (size_t)(gr >= 0 ? gr : 0) * row_f + c0 + q * 4;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)(u / U2) * C + (u % U2) * 16);
-            r[u] = gr >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __device__ __forceinline__ void store(float* lds, int ROW, int tid) const {
-        const int rr = tid >> 2, q = tid & 3;
-        float* p0 = lds + rr * ROW + q * 12;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            float* p = p0 + (u % U2) * 48 + (u / U2);
-            p[0] = r[u].x; p[3] = r[u].y; p[6] = r[u].z; p[9] = r[u].w;
-        }
-    }
-};
 
 // CC = channels per LDS chunk (32, or 1 for raw xyz clouds where C == 1)
 template <int CC, bool FMA>
@@ -226,57 +155,9 @@ __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ d
             *reinterpret_cast<float4*>(&ldist[(ty * 4 + i) * KNN_LD + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         __syncthreads();
 
-        // ---- selection, row-parallel and branch-free.  (dist, idx) pairs are packed into one u64 key
-        // (non-negative float bits << 32 | idx) so the lexicographic order is a single unsigned compare.  The 16-lane row
-        // r of group g owns query wave*16 + g*4 + r; its sorted top-K keys live in the row's lanes (entry e in lane
-        // 16r+e).  Each lane sorts its 4 candidate keys once (c = e + 16j); while any lane's smallest pending key beats
-        // its row's K-th key: ballot -> first proposing lane per row -> bpermute its key to the row -> ballot of
-        // "entry < candidate" gives the insert position -> DPP row_shr:1 shifts the tail.  Four queries advance per
-        // wave instruction; the only control flow is the wave-uniform loop exit.
-        const int e16 = lane & 15, rowbase = lane & 48;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int qrow = wave * 16 + g * 4 + (lane >> 4);
-            const float4 dv = *reinterpret_cast<const float4*>(&ldist[qrow * KNN_LD + e16 * 4]);
-            const int cbase = s0 + e16;
-            u64 k0 = make_key(dv.x, cbase, cbase < Ns), k1 = make_key(dv.y, cbase + 16, cbase + 16 < Ns);
-            u64 k2 = make_key(dv.z, cbase + 32, cbase + 32 < Ns), k3 = make_key(dv.w, cbase + 48, cbase + 48 < Ns);
-            key_cx(k0, k1); key_cx(k2, k3); key_cx(k0, k2); key_cx(k1, k3); key_cx(k1, k2);
-            u64 kk = rkey[g];
-            u64 m64 = __ballot(k0 < kk);
-            while (m64) {
-                const unsigned rb = (unsigned)(m64 >> rowbase) & 0xFFFFu;
-                const bool rowhas = rb != 0;
-                const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);  // rowbase+16 (no lane of this row) if !rowhas
-                const u64 cand = bperm64(srclane, k0);
-                const bool is_src = lane == srclane;
-                k0 = is_src ? k1 : k0; k1 = is_src ? k2 : k1; k2 = is_src ? k3 : k2; k3 = is_src ? ~0ull : k3;
-                const u64 l64 = __ballot(rowhas & (lk[g] < cand));
-                const int pos = __builtin_popcount((unsigned)(l64 >> rowbase) & 0xFFFFu);
-                const u64 up = dpp_row_shr1(lk[g]);
-                const bool s1 = rowhas & (e16 == pos), s2 = rowhas & (e16 > pos);
-                lk[g] = s1 ? cand : (s2 ? up : lk[g]);
-                kk = bperm64(rowbase + K - 1, lk[g]);
-                m64 = __ballot(k0 < kk);
-            }
-            rkey[g] = kk;
-        }
+        select_tile(ldist, lk, rkey, s0, Ns, K, wave, lane);
     }
-
-    // ---- write the sorted lists
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int q = q0 + wave * 16 + g * 4 + (lane >> 4);
-        const int e = lane & 15;
-        if (q < Nd && splits > 1) {
-            partial[(((size_t)b * Nd + q) * splits + sp) * 16 + e] = e < K ? lk[g] : ~0ull;
-        } else if (q < Nd && e < K) {
-            const size_t o = ((size_t)b * Nd + q) * K + e;
-            const unsigned hi = (unsigned)(lk[g] >> 32), lo = (unsigned)lk[g];
-            idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lo;
-            if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
-        }
-    }
+    write_lists(lk, b, q0, Nd, K, wave, lane, splits, sp, partial, idx_out, dist_out);
 }
 
 // merge the per-split sorted key lists of every query: one 16-lane row per query, same insertion step as above
@@ -324,10 +205,19 @@ static int knn_choose_splits(int B, int Nd, int Ns) {
     if (sp > 16) sp = 16;
     return sp < 1 ? 1 : sp;
 }
-size_t knn_scratch_bytes(int B, int Nd, int Ns) {
+// scratch layout: [split partial lists (u64)] [squared norms of the src rows (B*Ns floats)] [of the dst rows (B*dst_n)]
+static size_t knn_partial_bytes(int B, int Nd, int Ns) {
     const int sp = knn_choose_splits(B, Nd, Ns);
     return sp > 1 ? (size_t)B * Nd * sp * 16 * sizeof(u64) : 0;
 }
+size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, unsigned flags) {
+    size_t b = knn_partial_bytes(B, Nd, Ns);
+    if (flags & LS_FLAG_KNN_MFMA_FILTER) b += ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256;
+    return b;
+}
+int row_norms_launch(const float*, int, long long, float*, hipStream_t);
+int knn_mfma_launch(const float*, const float*, const int32_t*, const float*, const float*, int, int, int, int, int, int, bool, int32_t*,
+                    float*, int, int, u64*, hipStream_t);
 
 template <int CC, bool FMA>
 static int launch_knn(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
@@ -355,6 +245,33 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
+    if (C >= 32 && scratch && (flags & LS_FLAG_KNN_MFMA_FILTER)) {
+        // opt-in MFMA-filtered kernel (knn_mfma.hip): same result, ~10 % of the canonical distance work, but slower in practice
+        const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
+        int splits = knn_choose_splits(B, Nd, Ns);
+        const int tps = cdiv(ctiles, splits);
+        splits = cdiv(ctiles, tps);
+        char* sc = (char*)scratch;
+        u64* partial = (u64*)sc;
+        float* nsrc = (float*)(sc + knn_partial_bytes(B, Nd, Ns));
+        float* ndst = nsrc;
+        int rc = row_norms_launch(src, 3 * C, (long long)B * Ns, nsrc, st);
+        if (rc != LS_OK) return rc;
+        if (dst != src) {
+            ndst = nsrc + (size_t)B * Ns;
+            rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
+            if (rc != LS_OK) return rc;
+        }
+        rc = knn_mfma_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, splits, tps, partial, st);
+        if (rc != LS_OK) return rc;
+        if (splits > 1) {
+            const int total_q = B * Nd;
+            hipLaunchKernelGGL(knn_merge_kernel, dim3(cdiv(total_q, 16)), dim3(256), 0, st, (const u64*)partial, total_q, splits, K,
+                               idx_out, dist_out);
+            LS_LAUNCH_CHECK();
+        }
+        return LS_OK;
+    }
     if (C == 1) {
         return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st)
                    : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st);

@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 // kernels / launchers defined in the other translation units
 int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, void*, hipStream_t);
-size_t knn_scratch_bytes(int B, int Nd, int Ns);
+size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, unsigned flags);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
@@ -131,7 +131,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
         maxC = std::max(maxC, (size_t)p.Co[i]);
         maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
-        maxKs = std::max(maxKs, knn_scratch_bytes(B, p.Nd[i], p.Ns[i]));
+        maxKs = std::max(maxKs, knn_scratch_bytes(B, p.Nd[i], p.Ns[i], p.Ns[i], LS_FLAG_KNN_MFMA_FILTER));
     }
     LS_REQUIRE(d.num_knn == 16, "encoder: num_knn=%d unsupported (16)", d.num_knn);
     LS_REQUIRE(p.Ns[p.L - 1] >= 1, "encoder: bad schedule");
@@ -175,8 +175,10 @@ int ls_device_count(void) {
 // ------------------------------------------------------------------------------------------------ leaf exports
 int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K,
                unsigned flags, int32_t* idx_out, float* dist_out, void* stream) {
-    LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
-    const size_t sb = knn_scratch_bytes(B, Nd, Ns);
+    LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0 && dst_n > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
+    LS_REQUIRE(K >= 1 && K <= 16, "knn: K=%d unsupported (1..16)", K);
+    LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
+    const size_t sb = knn_scratch_bytes(B, Nd, dst_n, Ns, flags);
     void* scratch = nullptr;
     if (sb) LS_HIP_CHECK(hipMallocAsync(&scratch, sb, (hipStream_t)stream));
     int rc = knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, scratch, (hipStream_t)stream);

@@ -54,10 +54,40 @@ def test_knn_large_batch_unsplit_path():
     from livingscenes_amd import ops
     from oracle import canon
     rng = np.random.default_rng(77)
+    from livingscenes_amd import _lib
     f = rng.standard_normal((48, 1024, 3, 32)).astype(np.float32)
     ref = canon.knn_c(f, f, 16)
     ft = torch.from_numpy(f).to(_dev())
     assert np.array_equal(ops.knn(ft, ft, 16).cpu().numpy(), ref)
+    assert np.array_equal(ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("case", ["offset", "near_duplicates", "clustered", "scale_mix"])
+def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
+    """The MFMA pre-filter may only drop pairs that provably cannot enter a list.  Stress the cancellation in
+    |q|^2+|s|^2-2q.s: a huge common offset, near-duplicate points, tight clusters, wildly different norms.  The result
+    must be bit-identical to the oracle for the default all-VALU kernel AND the opt-in MFMA-filtered kernel."""
+    from livingscenes_amd import _lib, ops
+    from oracle import canon
+    rng = np.random.default_rng({"offset": 1, "near_duplicates": 2, "clustered": 3, "scale_mix": 4}[case])
+    B, N, C = 3, 640, 64
+    f = rng.standard_normal((B, N, 3, C)).astype(np.float32)
+    if case == "offset":
+        f = (f * 1e-3 + 50.0).astype(np.float32)            # norms ~ 7e5, spreads ~ 1e-3: d^ is pure cancellation noise
+    elif case == "near_duplicates":
+        f[:, 1::2] = f[:, 0::2] + (rng.standard_normal((B, N // 2, 3, C)) * 1e-6).astype(np.float32)
+        f[:, 10] = f[:, 11]                                   # exact duplicates too
+    elif case == "clustered":
+        cen = rng.standard_normal((B, 8, 3, C)).astype(np.float32) * 5
+        f = (cen[:, rng.integers(0, 8, N)] + f * 1e-2).astype(np.float32)
+    else:
+        f = (f * np.exp(rng.uniform(-6, 6, (B, N, 1, 1)))).astype(np.float32)
+    ref, refd = canon.knn_c(f, f, 16, return_dist=True)
+    ft = torch.from_numpy(f).to(_dev())
+    idx, dist = ops.knn(ft, ft, 16, return_dist=True)
+    assert np.array_equal(idx.cpu().numpy(), ref) and np.array_equal(dist.cpu().numpy(), refd)
+    idx2, dist2 = ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER, return_dist=True)
+    assert np.array_equal(idx2.cpu().numpy(), ref) and np.array_equal(dist2.cpu().numpy(), refd)
 
 
 def test_knn_dst_rows_and_self():
