@@ -101,6 +101,9 @@ def main():
                     help="threads for the CPU baseline: the reference's op sequence peaks at ~16 threads on the GPU box's "
                          "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; scripts/cpu_threads_probe.py)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent steps kept in flight on separate HIP streams (each with its own model handle and "
+                         "workspace): one step's low-occupancy kernels (FPS, heads, matcher) overlap another's big ones")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,13 +132,17 @@ def main():
     sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=dev)
     if world > 1:
         parallel.broadcast_weights(sp, src=0)
+    nfl = max(1, args.inflight)
+    # one model handle (packed weights + side stream + workspace) per in-flight step; weights are shared tensors
+    sps = [sp] + [Shape_Prior.from_state(ecfg, dcfg, sp.encoder.state_dict(), sp.decoder.F.state_dict(), device=dev) for _ in range(nfl - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
 
     B, N = args.batch, args.points
     n_obj = B // 2
     scene = synth.make_scene_pair(n_obj, N, seed=1000 + rank)
     x = torch.cat([scene["ref"], scene["rescan"]], 0).transpose(1, 2).contiguous().to(dev)  # [B,3,N] resident in HBM
 
-    def step():
+    def step(sp=sp):
         emb = sp.encode(x)
         m = sequential_matcher(emb["z_inv"][:n_obj], emb["z_inv"][n_obj:])
         j = m["matches0"].clamp(min=0)
@@ -148,15 +155,22 @@ def main():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
 
+    def run(n):
+        out = None
+        for i in range(n):
+            with torch.cuda.stream(streams[i % nfl]):
+                out = step(sps[i % nfl])
+        return out
+
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out = step()
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        out = run(max(args.warmup, nfl))
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        out = run(args.steps)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -243,6 +257,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]+[2]: batch={B} instances x N={N} pts per GPU = {n_obj}-object scene + rescan; "
                                    f"VN-DGCNN encode, {n_obj}x{n_obj} sequential matching, {n_obj} Kabsch poses",
                        "instances_per_step_per_gpu": B, "points": N, "parallelism": f"instance-sharded x{world}",
+                       "steps_in_flight": nfl,
                        "knn_arithmetic": "canonical (separately rounded mul/add)"},
             "check": {"matches_identity": f"{n_correct}/{n_obj}", "rotations_proper": det_ok},
             "roofline": roof,
