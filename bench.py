@@ -123,6 +123,8 @@ def main():
     from livingscenes_amd.lib_more.pose_estimation import kabsch_transformation_estimation
     from livingscenes_amd.model_utils import Shape_Prior
 
+    if args.inflight > 1:
+        os.environ.setdefault("LS_GEMM_OVERLAP", "0")
     ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
     if rank == 0:
         ew, dw = synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0)
@@ -133,6 +135,10 @@ def main():
     if world > 1:
         parallel.broadcast_weights(sp, src=0)
     nfl = max(1, args.inflight)
+    if nfl > 1:
+        # A/B on MI355X (scripts in DESIGN.md 6): intra-step GEMM||k-NN stream overlap is +5 % for a single in-flight step but
+        # -3.5 % once two whole steps already overlap; the library default stays on, the bench turns it off.
+        os.environ.setdefault("LS_GEMM_OVERLAP", "0")
     # one model handle (packed weights + side stream + workspace) per in-flight step; weights are shared tensors
     sps = [sp] + [Shape_Prior.from_state(ecfg, dcfg, sp.encoder.state_dict(), sp.decoder.F.state_dict(), device=dev) for _ in range(nfl - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]

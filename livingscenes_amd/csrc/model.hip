@@ -2,6 +2,7 @@
 // (ls_encode = Shape_Prior.encode, ls_sdf_decode = FieldWrapper.forward).  Host code only enqueues work on the
 // caller's stream (plus one library-owned side stream for the FPS chain); it never synchronises the device.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -54,8 +55,11 @@ struct ProfRec { int kind, layer; hipEvent_t a, b; };
 struct ls_model {
     ls_model_desc d;
     float* blob = nullptr;
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;    // FPS chain
+    hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
+    bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     bool profiling = false;
     std::vector<ProfRec> prof;          // pending (un-collected) event pairs
     std::vector<hipEvent_t> ev_pool;    // recycled events
@@ -238,10 +242,16 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     LS_REQUIRE(desc->blob_floats > 0, "model_create: empty blob");
     ls_model* m = new ls_model();
     m->d = *desc;
+    if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
     hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
     if (e != hipSuccess) { delete m; set_error("hipMalloc(model blob): %s", hipGetErrorString(e)); return LS_ERR_HIP; }
     e = hipMemcpy(m->blob, blob_host, (size_t)desc->blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking);
+    for (int i = 0; i < LS_MAX_LAYERS && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&m->ev_feat[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_tab[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
@@ -253,6 +263,11 @@ void ls_model_destroy(ls_model_t* m) {
     if (!m) return;
     if (m->blob) (void)hipFree(m->blob);
     if (m->side) (void)hipStreamDestroy(m->side);
+    if (m->side2) (void)hipStreamDestroy(m->side2);
+    for (int i = 0; i < LS_MAX_LAYERS; ++i) {
+        if (m->ev_feat[i]) (void)hipEventDestroy(m->ev_feat[i]);
+        if (m->ev_tab[i]) (void)hipEventDestroy(m->ev_tab[i]);
+    }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -338,26 +353,35 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             if (rc != LS_OK) return rc;
         } else {
             const int Cin = p.Cin[i], nc = p.ncols[i];
-            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, st); }
-            if (rc != LS_OK) return rc;
             const int pc = (attn ? 4 : 2) * Co, qc = nc - pc;  // neighbour-side / destination-side column counts
             const float* Tq;
             int ldp, ldq, NQ, qvr;
+            // fork: the table GEMM(s) depend only on the layer input, like the k-NN -> run them on side2 (matrix cores /
+            // HBM writes) concurrently with the VALU-bound k-NN on the caller's stream; join before the edge kernel.
+            hipStream_t gs = m->overlap_gemm ? m->side2 : st;
+            if (m->overlap_gemm) {
+                LS_HIP_CHECK(hipEventRecord(m->ev_feat[i], st));
+                LS_HIP_CHECK(hipStreamWaitEvent(gs, m->ev_feat[i], 0));
+            }
             if (dst_rows) {
                 // down-sampled layer: P table on all source points, Q table only on the FPS-selected destination points
                 float* Tq_w = T + (size_t)B * Ns * 3 * pc;
-                PROF(LS_K_GEMM_EDGE, i, st);
-                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, st);
+                PROF(LS_K_GEMM_EDGE, i, gs);
+                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
                 if (rc == LS_OK)
                     rc = gemm_dispatch_gather(cur, Cin, W + d.off_edge[i] + (size_t)pc * Cin, Cin, nullptr, Tq_w, qc, B * Nd * 3, qc, Cin,
-                                              0, dst_rows, Nd, Ns, st);
+                                              0, dst_rows, Nd, Ns, gs);
                 Tq = Tq_w; ldp = pc; ldq = qc; NQ = Nd; qvr = 0;
             } else {
-                PROF(LS_K_GEMM_EDGE, i, st);
-                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, st);
+                PROF(LS_K_GEMM_EDGE, i, gs);
+                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, gs);
                 Tq = T + pc; ldp = nc; ldq = nc; NQ = Ns; qvr = 1;
             }
             if (rc != LS_OK) return rc;
+            if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
+            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, st); }
+            if (rc != LS_OK) return rc;
+            if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if (attn) { PROF(LS_K_EDGE_ATTN, i, st); rc = edge_attn_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st); }
             else { PROF(LS_K_EDGE_POOL, i, st); rc = edge_pool_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
