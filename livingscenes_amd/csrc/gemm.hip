@@ -27,8 +27,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
                                                        int ldc, int M, int N, int K, int relu, int ntiles_n,
                                                        const int32_t* __restrict__ a_rows, int gNd, int gNs) {
-    __shared__ __attribute__((aligned(16))) float As[GM * GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GN * GLD];
+    constexpr int STG = 32 * 68;  // epilogue staging: 32 rows x (64 + 4) floats per wave
+    __shared__ __attribute__((aligned(16))) float smem[(4 * STG > (GM + GN) * GLD) ? 4 * STG : (GM + GN) * GLD];
+    float* As = smem;
+    float* Bs = smem + GM * GLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     // consecutive logical ids walk the N tiles of one M tile: they share the A panel in one XCD's L2
@@ -104,25 +106,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Storing straight from
+    // that layout costs 64 global_store_dword per lane (store-issue-bound for the K = 32/64 table GEMMs, whose
+    // epilogue outweighs their main loop).  Instead each wave transposes its 64x64 sub-tile through LDS in two 32-row
+    // halves (the operand buffers are free now) and writes full 256-byte row segments with 16 dwordx4 stores per lane.
+    __syncthreads();  // all waves are done with As / Bs
+    float* stg = smem + wave * STG;  // 8.7 KB per wave
     const int col_l = lane & 31, rowh = (lane >> 5) * 4;
+    const bool vec_ok = (ldc % 4 == 0) && (((uintptr_t)out & 15) == 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + wn * 64 + j * 32 + col_l;
-        if (gn >= N) continue;
-        const float bv = bias ? bias[gn] : 0.0f;
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + wn * 64 + j * 32 + col_l;
+            const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rowh;
-                if (gm < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (relu) v = fmaxf(v, 0.0f);
-                    out[(size_t)gm * ldc + gn] = v;
+                float v = acc[i][j][r] + bv;
+                if (relu) v = fmaxf(v, 0.0f);
+                stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+            }
+        }
+        // wave-local hand-off through LDS: same wave writes and reads, LDS ops of a wave complete in order
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = u * 64 + lane;           // 32 rows x 16 float4
+            const int rr = idx >> 4, c4 = (idx & 15) * 4;
+            const int gm = m0 + wm * 64 + i * 32 + rr;
+            const int gn = n0 + wn * 64 + c4;
+            if (gm < M && gn < N) {
+                const float4 v = *reinterpret_cast<const float4*>(&stg[rr * 68 + c4]);
+                float* op = out + (size_t)gm * ldc + gn;
+                if (vec_ok && gn + 3 < N) {
+                    *reinterpret_cast<float4*>(op) = v;
+                } else {
+                    op[0] = v.x;
+                    if (gn + 1 < N) op[1] = v.y;
+                    if (gn + 2 < N) op[2] = v.z;
+                    if (gn + 3 < N) op[3] = v.w;
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
