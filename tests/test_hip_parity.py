@@ -188,7 +188,8 @@ def test_encoder_layerwise_knn_on_oracle_inputs(which):
         assert np.array_equal(idx.cpu().numpy(), tr[f"knn_idx_{i}"].numpy().astype(np.int32)), f"layer {i}"
 
 
-@pytest.mark.parametrize("which,B,N", [("small", 2, 128), ("small", 5, 256), ("full", 2, 1024), ("full", 3, 1024)])
+@pytest.mark.parametrize("which,B,N", [("small", 2, 128), ("small", 5, 256), ("small", 1, 200), ("small", 3, 333),
+                                       ("full", 2, 1024), ("full", 3, 1024), ("full", 1, 1000)])
 def test_encoder_forward_vs_oracle(which, B, N):
     """VecDGCNN_att.forward (pre-normalised input): FPS and layer-0 k-NN indices bit-exact (identical inputs);
     deeper k-NN layers search in features that differ by fp32 round-off, so they are compared as a match rate;
@@ -336,3 +337,21 @@ def test_icp_vs_oracle():
         Rp, Tp, rp, ip, _ = more.iterative_closest_point(X[p:p + 1], Y[p:p + 1], R0[p:p + 1], T0[p:p + 1])
         assert relerr(R[p:p + 1], Rp) < 1e-3 and relerr(T[p:p + 1], Tp) < 1e-3, p
         assert abs(float(rmse[p]) - float(rp)) < 1e-4 * max(float(rp), 1e-3)
+
+
+def test_sdf_dense_grid_mise_resolution():
+    """A 33^3 grid (MISE resolution0 + 1, mesh_extractor2.py:100-105) for 2 instances through the chunked decoder path."""
+    from oracle import net
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    ew, dw = synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0)
+    m = _hip_model(ecfg, ew, dcfg, dw)
+    g = torch.Generator().manual_seed(5)
+    B, C = 2, 256
+    code = {"z_so3": torch.randn(B, C, 3, generator=g) * 0.03, "z_inv": torch.randn(B, C, generator=g) * 0.003,
+            "s": torch.ones(B), "t": torch.zeros(B, 1, 3)}
+    lin = torch.linspace(-0.55, 0.55, 33)
+    q = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(1, -1, 3).expand(B, -1, -1).contiguous()
+    ref = net.field_query(dw, dcfg, q, code)
+    d = _dev()
+    sdf = m.sdf_decode(q.to(d), code["z_so3"].to(d), code["z_inv"].to(d), code["s"].to(d), code["t"].to(d), max_ws_bytes=64 << 20)
+    assert sdf.shape == (B, 33 ** 3) and relerr(sdf, ref) < TOL
