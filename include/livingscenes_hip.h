@@ -59,10 +59,13 @@ int ls_device_count(void);
  *                            dst_rows[b*Nd + n] of `dst` (which then has Nd' = dst_n rows per instance)
  *   idx_out  [B, Nd, K] int32, ascending (dist, index); -1 padded when Ns < K
  *   dist_out [B, Nd, K] or NULL
+ *   seed_idx [B, Nd, 16] int32 or NULL: optional HINTS, any candidate indices per query (-1 = none), e.g. the
+ *            neighbour list of the same point in the previous encoder layer.  Their exact distances initialise
+ *            the top-K lists (tighter admission threshold, fewer insertions); the RESULT DOES NOT DEPEND on them.
  * Distance = sum_j (a_j-b_j)^2, j = c*3+x ascending, fp32, rounding per `flags`.  K <= 16.
  * C must be 1 or a multiple of 32. */
-int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
-               int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* stream);
+int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, const int32_t* seed_idx, int B, int Nd,
+               int dst_n, int Ns, int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* stream);
 
 /* pytorch3d.ops.sample_farthest_points(points, K=..., random_start_point=False) as called at
  * vec_dgcnn_atten.py:169, model_utils.py:205, lib_more/more_solver.py:107-108.

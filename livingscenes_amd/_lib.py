@@ -71,7 +71,7 @@ SIGNATURES = {
     "ls_version": (_I, []),
     "ls_last_error": (ctypes.c_char_p, []),
     "ls_device_count": (_I, []),
-    "ls_knn_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P, _P, _P]),
+    "ls_knn_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P, _P, _P]),
     "ls_fps_f32": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P]),
     "ls_gemm_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ls_encode_prologue_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),

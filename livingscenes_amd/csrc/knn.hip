@@ -29,7 +29,8 @@ template <int CC, bool FMA>
 __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                   const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int C,
                                                   int K, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-                                                  int qtiles, int splits, int tiles_per_split, u64* __restrict__ partial) {
+                                                  int qtiles, int splits, int tiles_per_split, u64* __restrict__ partial,
+                                                  const int32_t* __restrict__ seed_idx, int seed_n, int seed_by_row) {
     constexpr int ROW = (CC == 1) ? 4 : (3 * CC + 4);  // floats per staged row (ROW/4 odd: conflict-free ds_read_b128)
     constexpr int LC_FLOATS = (KNN_TS * ROW > KNN_TQ * KNN_LD) ? KNN_TS * ROW : KNN_TQ * KNN_LD;
     __shared__ __attribute__((aligned(16))) float lq[KNN_TQ * ROW];
@@ -80,6 +81,18 @@ __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ d
         sq.load(dbase, lqrow, 0, 0, row_f, C, 0, tid);
         sc.load(sbase, nullptr, s_begin, Ns, row_f, C, 0, tid);
         if (q_once) { sq.store(lq, ROW, tid); }
+    }
+    // optional hints (e.g. the previous layer's neighbour list of the same point): start the lists from their exact
+    // canonical distances so that the admission threshold is near-final from the first tile.  Only split 0 is seeded (the
+    // merge kernel drops duplicates); the result does not depend on the hints.
+    const bool seeded = (CC != 1) && seed_idx != nullptr && sp == 0;
+    if constexpr (CC != 1) {
+        if (seeded) {
+            u64* lseed = reinterpret_cast<u64*>(lc);  // 8 KB, lc is not in use before the first tile is stored
+            compute_seed_keys<FMA>(lseed, seed_idx, seed_n, seed_by_row != 0, dbase, sbase, lqrow, b, q0, Ns, C, tid);
+            __syncthreads();
+            seed_lists(lseed, lk, rkey, K, wave, lane);
+        }
     }
 
     for (int s0 = s_begin; s0 < s_end; s0 += KNN_TS) {
@@ -155,7 +168,8 @@ __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ d
             *reinterpret_cast<float4*>(&ldist[(ty * 4 + i) * KNN_LD + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         __syncthreads();
 
-        select_tile(ldist, lk, rkey, s0, Ns, K, wave, lane);
+        if (seeded) select_tile<true>(ldist, lk, rkey, s0, Ns, K, wave, lane);
+        else select_tile<false>(ldist, lk, rkey, s0, Ns, K, wave, lane);
     }
     write_lists(lk, b, q0, Nd, K, wave, lane, splits, sp, partial, idx_out, dist_out);
 }
@@ -178,10 +192,12 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64* __restrict__ 
             const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);
             const u64 cand = bperm64(srclane, k0);
             k0 = (lane == srclane) ? ~0ull : k0;
-            const u64 l64 = __ballot(rowhas & (lkey < cand));
+            const u64 d64 = __ballot(rowhas & (lkey == cand));  // a seeded split may already hold this candidate
+            const bool rowok = rowhas & (((unsigned)(d64 >> rowbase) & 0xFFFFu) == 0u);
+            const u64 l64 = __ballot(rowok & (lkey < cand));
             const int pos = __builtin_popcount((unsigned)(l64 >> rowbase) & 0xFFFFu);
             const u64 up = dpp_row_shr1(lkey);
-            const bool s1 = rowhas & (e16 == pos), s2 = rowhas & (e16 > pos);
+            const bool s1 = rowok & (e16 == pos), s2 = rowok & (e16 > pos);
             lkey = s1 ? cand : (s2 ? up : lkey);
             kk = bperm64(rowbase + K - 1, lkey);
             m64 = __ballot(k0 < kk);
@@ -221,14 +237,15 @@ int knn_mfma_launch(const float*, const float*, const int32_t*, const float*, co
 
 template <int CC, bool FMA>
 static int launch_knn(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
-                      int C, int K, int32_t* idx_out, float* dist_out, void* scratch, hipStream_t st) {
+                      int C, int K, int32_t* idx_out, float* dist_out, void* scratch, const int32_t* seed_idx, int seed_n,
+                      int seed_by_row, hipStream_t st) {
     const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
     int splits = scratch ? knn_choose_splits(B, Nd, Ns) : 1;
     const int tps = cdiv(ctiles, splits);
     splits = cdiv(ctiles, tps);
     dim3 grid(B * qtiles * splits), block(256);
     hipLaunchKernelGGL((knn_kernel<CC, FMA>), grid, block, 0, st, dst, src, dst_rows, Nd, dst_n, Ns, C, K, idx_out,
-                       dist_out, qtiles, splits, tps, (u64*)scratch);
+                       dist_out, qtiles, splits, tps, (u64*)scratch, seed_idx, seed_n, seed_by_row);
     LS_LAUNCH_CHECK();
     if (splits > 1) {
         const int total_q = B * Nd;
@@ -240,7 +257,8 @@ static int launch_knn(const float* dst, const float* src, const int32_t* dst_row
 }
 
 int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C,
-                 int K, unsigned flags, int32_t* idx_out, float* dist_out, void* scratch, hipStream_t st) {
+                 int K, unsigned flags, int32_t* idx_out, float* dist_out, void* scratch, const int32_t* seed_idx, int seed_n,
+                 int seed_by_row, hipStream_t st) {
     LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0 && dst_n > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
@@ -273,11 +291,11 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
         return LS_OK;
     }
     if (C == 1) {
-        return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st)
-                   : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st);
+        return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st)
+                   : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st);
     }
-    return fma ? launch_knn<32, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st)
-               : launch_knn<32, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, st);
+    return fma ? launch_knn<32, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, seed_idx, seed_n, seed_by_row, st)
+               : launch_knn<32, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, seed_idx, seed_n, seed_by_row, st);
 }
 
 }  // namespace ls

@@ -76,16 +76,44 @@ struct Stager {
 };
 
 
-// Row-parallel, branch-free merge of one 64x64 distance tile (LDS, slot layout (c & 15) * 4 + (c >> 4)) into the wave's
-// top-K key lists.  (dist, idx) pairs are packed into one u64 key (non-negative float bits << 32 | idx) so the
-// lexicographic order is a single unsigned compare.  The 16-lane row r of group g owns query wave*16 + g*4 + r; its sorted
-// top-K keys live in the row's lanes (entry e in lane 16r+e).  Each lane sorts its 4 candidate keys once (c = e + 16j);
-// while any lane's smallest pending key beats its row's K-th key: ballot -> first proposing lane per row -> bpermute its
-// key to the row -> ballot of "entry < candidate" gives the insert position -> DPP row_shr:1 shifts the tail.  Four
-// queries advance per wave instruction; the only control flow is the wave-uniform loop exit.
+// One row-parallel merge: every lane offers up to four keys (k0 <= k1 <= k2 <= k3, ~0 = none); while any lane's smallest
+// pending key beats its row's K-th key: ballot -> first proposing lane per row -> bpermute its key to the row -> ballot of
+// "entry < candidate" gives the insert position -> DPP row_shr:1 shifts the tail.  Four queries (one per 16-lane row)
+// advance per wave instruction; the only control flow is the wave-uniform loop exit.  DEDUP: a candidate whose key equals
+// an existing entry (same index, same canonical distance: a seed met again by the scan) is dropped.
+template <bool DEDUP>
+__device__ __forceinline__ void merge_keys(u64 k0, u64 k1, u64 k2, u64 k3, u64& lkg, u64& kk, int K, int lane) {
+    const int e16 = lane & 15, rowbase = lane & 48;
+    u64 m64 = __ballot(k0 < kk);
+    while (m64) {
+        const unsigned rb = (unsigned)(m64 >> rowbase) & 0xFFFFu;
+        bool rowhas = rb != 0;
+        const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);  // rowbase+16 (no lane of this row) if !rowhas
+        const u64 cand = bperm64(srclane, k0);
+        const bool is_src = lane == srclane;
+        k0 = is_src ? k1 : k0; k1 = is_src ? k2 : k1; k2 = is_src ? k3 : k2; k3 = is_src ? ~0ull : k3;
+        if constexpr (DEDUP) {
+            const u64 d64 = __ballot(rowhas & (lkg == cand));
+            rowhas = rowhas & (((unsigned)(d64 >> rowbase) & 0xFFFFu) == 0u);
+        }
+        const u64 l64 = __ballot(rowhas & (lkg < cand));
+        const int pos = __builtin_popcount((unsigned)(l64 >> rowbase) & 0xFFFFu);
+        const u64 up = dpp_row_shr1(lkg);
+        const bool s1 = rowhas & (e16 == pos), s2 = rowhas & (e16 > pos);
+        lkg = s1 ? cand : (s2 ? up : lkg);
+        kk = bperm64(rowbase + K - 1, lkg);
+        m64 = __ballot(k0 < kk);
+    }
+}
+
+// Merge one 64x64 distance tile (LDS, slot layout (c & 15) * 4 + (c >> 4)) into the wave's top-K key lists.  (dist, idx)
+// pairs are packed into one u64 key (non-negative float bits << 32 | idx) so the lexicographic order is a single unsigned
+// compare.  The 16-lane row r of group g owns query wave*16 + g*4 + r; its sorted top-K keys live in the row's lanes
+// (entry e in lane 16r+e).  Each lane sorts its 4 candidate keys once (c = e + 16j), then merge_keys.
+template <bool DEDUP>
 __device__ __forceinline__ void select_tile(const float* ldist, u64 (&lk)[4], u64 (&rkey)[4], int s0, int Ns, int K, int wave,
                                             int lane) {
-    const int e16 = lane & 15, rowbase = lane & 48;
+    const int e16 = lane & 15;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int qrow = wave * 16 + g * 4 + (lane >> 4);
@@ -94,24 +122,53 @@ __device__ __forceinline__ void select_tile(const float* ldist, u64 (&lk)[4], u6
         u64 k0 = make_key(dv.x, cbase, cbase < Ns), k1 = make_key(dv.y, cbase + 16, cbase + 16 < Ns);
         u64 k2 = make_key(dv.z, cbase + 32, cbase + 32 < Ns), k3 = make_key(dv.w, cbase + 48, cbase + 48 < Ns);
         key_cx(k0, k1); key_cx(k2, k3); key_cx(k0, k2); key_cx(k1, k3); key_cx(k1, k2);
-        u64 kk = rkey[g];
-        u64 m64 = __ballot(k0 < kk);
-        while (m64) {
-            const unsigned rb = (unsigned)(m64 >> rowbase) & 0xFFFFu;
-            const bool rowhas = rb != 0;
-            const int srclane = rowbase + __builtin_ctz(rb | 0x10000u);  // rowbase+16 (no lane of this row) if !rowhas
-            const u64 cand = bperm64(srclane, k0);
-            const bool is_src = lane == srclane;
-            k0 = is_src ? k1 : k0; k1 = is_src ? k2 : k1; k2 = is_src ? k3 : k2; k3 = is_src ? ~0ull : k3;
-            const u64 l64 = __ballot(rowhas & (lk[g] < cand));
-            const int pos = __builtin_popcount((unsigned)(l64 >> rowbase) & 0xFFFFu);
-            const u64 up = dpp_row_shr1(lk[g]);
-            const bool s1 = rowhas & (e16 == pos), s2 = rowhas & (e16 > pos);
-            lk[g] = s1 ? cand : (s2 ? up : lk[g]);
-            kk = bperm64(rowbase + K - 1, lk[g]);
-            m64 = __ballot(k0 < kk);
-        }
-        rkey[g] = kk;
+        merge_keys<DEDUP>(k0, k1, k2, k3, lk[g], rkey[g], K, lane);
+    }
+}
+
+// Seed the wave's lists from lseed[64][16] (one key per (query, hint), ~0 = none); repeated hints are dropped.
+__device__ __forceinline__ void seed_lists(const u64* lseed, u64 (&lk)[4], u64 (&rkey)[4], int K, int wave, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int qrow = wave * 16 + g * 4 + (lane >> 4);
+        merge_keys<true>(lseed[qrow * 16 + (lane & 15)], ~0ull, ~0ull, ~0ull, lk[g], rkey[g], K, lane);
+    }
+}
+
+// canonical distance between two feature rows in global memory (x-major [3][C]), same chain as the tile path
+template <bool FMA>
+__device__ __forceinline__ float row_distance(const float* __restrict__ a, const float* __restrict__ b, int C) {
+    float d = 0.0f;
+    for (int c4 = 0; c4 < C; c4 += 4) {
+        const float4 ax = *reinterpret_cast<const float4*>(a + c4), ay = *reinterpret_cast<const float4*>(a + C + c4),
+                     az = *reinterpret_cast<const float4*>(a + 2 * C + c4);
+        const float4 bx = *reinterpret_cast<const float4*>(b + c4), by = *reinterpret_cast<const float4*>(b + C + c4),
+                     bz = *reinterpret_cast<const float4*>(b + 2 * C + c4);
+        d = accq<FMA>(d, ax.x, bx.x); d = accq<FMA>(d, ay.x, by.x); d = accq<FMA>(d, az.x, bz.x);
+        d = accq<FMA>(d, ax.y, bx.y); d = accq<FMA>(d, ay.y, by.y); d = accq<FMA>(d, az.y, bz.y);
+        d = accq<FMA>(d, ax.z, bx.z); d = accq<FMA>(d, ay.z, by.z); d = accq<FMA>(d, az.z, bz.z);
+        d = accq<FMA>(d, ax.w, bx.w); d = accq<FMA>(d, ay.w, by.w); d = accq<FMA>(d, az.w, bz.w);
+    }
+    return d;
+}
+
+// Compute the seed keys of a 64-query workgroup into lseed[64][16]: hint e of query q is seed_idx[(b*seed_n + row)*16 + e]
+// with row = the query's source row (seed_by_row, the previous layer's list of the same point) or its query index.
+template <bool FMA>
+__device__ __forceinline__ void compute_seed_keys(u64* lseed, const int32_t* __restrict__ seed_idx, int seed_n, bool seed_by_row,
+                                                  const float* __restrict__ dbase, const float* __restrict__ sbase, const int* lqrow,
+                                                  int b, int q0, int Ns, int C, int tid) {
+    const size_t row_f = (size_t)3 * C;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int p = tid + u * 256;
+        const int q = p >> 4, e = p & 15;
+        const int r = lqrow[q];
+        int sidx = -1;
+        if (r >= 0) sidx = seed_idx[((size_t)b * seed_n + (seed_by_row ? r : q0 + q)) * 16 + e];
+        u64 key = ~0ull;
+        if (sidx >= 0 && sidx < Ns) key = make_key(row_distance<FMA>(dbase + (size_t)r * row_f, sbase + (size_t)sidx * row_f, C), sidx, true);
+        lseed[q * 16 + e] = key;
     }
 }
 

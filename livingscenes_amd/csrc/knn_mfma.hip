@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         }
         if (tid == 0) lcount = 0;
         __syncthreads();
-        select_tile(ldist, lk, rkey, s0, Ns, K, wave, lane);
+        select_tile<false>(ldist, lk, rkey, s0, Ns, K, wave, lane);
         // refresh the filter thresholds: the row's K-th distance (+inf while the list is not full)
         if ((lane & 15) == 0) {
 #pragma unroll

@@ -19,7 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 
 // kernels / launchers defined in the other translation units
-int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, void*, hipStream_t);
+int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, void*, const int32_t*, int, int,
+                 hipStream_t);
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, unsigned flags);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -59,6 +60,7 @@ struct ls_model {
     hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
+    bool seed_knn = true;          // LS_KNN_SEEDS=0 disables seeding a layer's k-NN lists from the previous layer's graph
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     bool profiling = false;
     std::vector<ProfRec> prof;          // pending (un-collected) event pairs
@@ -97,7 +99,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -151,6 +153,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_scale0 = take((size_t)B * 4);
     p.o_pro = take(prologue_scratch_floats(B) * 4);
     p.o_knn = take((size_t)B * maxKnn * 4);
+    p.o_knn2 = take((size_t)B * maxKnn * 4);
     p.o_knns = take(maxKs + 256);
     p.o_fA = take((size_t)B * maxF * 4);
     p.o_fB = take((size_t)B * maxF * 4);
@@ -177,15 +180,16 @@ int ls_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------------ leaf exports
-int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K,
-               unsigned flags, int32_t* idx_out, float* dist_out, void* stream) {
+int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, const int32_t* seed_idx, int B, int Nd, int dst_n, int Ns,
+               int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* stream) {
     LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0 && dst_n > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
     LS_REQUIRE(K >= 1 && K <= 16, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const size_t sb = knn_scratch_bytes(B, Nd, dst_n, Ns, flags);
     void* scratch = nullptr;
     if (sb) LS_HIP_CHECK(hipMallocAsync(&scratch, sb, (hipStream_t)stream));
-    int rc = knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, scratch, (hipStream_t)stream);
+    int rc = knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, scratch, seed_idx, Nd, 0,
+                          (hipStream_t)stream);
     if (sb) LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
     return rc;
 }
@@ -243,6 +247,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     ls_model* m = new ls_model();
     m->d = *desc;
     if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_KNN_SEEDS")) m->seed_knn = atoi(ev) != 0;
     hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
     if (e != hipSuccess) { delete m; set_error("hipMalloc(model blob): %s", hipGetErrorString(e)); return LS_ERR_HIP; }
     e = hipMemcpy(m->blob, blob_host, (size_t)desc->blob_floats * sizeof(float), hipMemcpyHostToDevice);
@@ -332,6 +337,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     float* T = F(p.o_T);
     bool joined = false;
     size_t knn_off = 0, fps_off = 0;
+    const int32_t* prev_knn = nullptr;
     for (int i = 0; i < p.L; ++i) {
         const int Ns = p.Ns[i], Nd = p.Nd[i], Co = p.Co[i];
         const int32_t* dst_rows = nullptr;
@@ -340,13 +346,13 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             dst_rows = trace_fps ? trace_fps + fps_off : I(p.o_fps[p.level[i] + 1]);
             fps_off += (size_t)B * Nd;
         }
-        int32_t* knn = trace_knn ? trace_knn + knn_off : I(p.o_knn);
+        int32_t* knn = trace_knn ? trace_knn + knn_off : I((i & 1) ? p.o_knn2 : p.o_knn);  // ping-pong: layer i+1 is seeded by layer i
         knn_off += (size_t)B * Nd * 16;
         const bool attn = i >= d.atten_start_layer;
         const bool glob = i >= d.res_global_start_layer;
         float* mp = glob ? msg : nxt;
         if (i == 0) {
-            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, st); }
+            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
             if (rc != LS_OK) return rc;
             LS_REQUIRE(!attn, "encoder: attention at layer 0 unsupported (atten_start_layer >= 1)");
             { PROF(LS_K_EDGE_L0, i, st); rc = edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
@@ -379,7 +385,10 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
-            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, st); }
+            { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
+                // == this layer's source set, so its indices address this layer's candidates directly)
+                const int32_t* seeds = (m->seed_knn && prev_knn && p.level[i - 1] < 0) ? prev_knn : nullptr;
+                rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if (attn) { PROF(LS_K_EDGE_ATTN, i, st); rc = edge_attn_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st); }
@@ -403,6 +412,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             if (rc != LS_OK) return rc;
         }
         std::swap(cur, nxt);
+        prev_knn = knn;
     }
     if (p.nlevels > 0 && !joined) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
 

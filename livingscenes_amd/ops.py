@@ -14,15 +14,19 @@ def _f32(t):
     return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
 
 
-def knn(dst, src, K=16, dst_rows=None, flags=DEFAULT_FLAGS, return_dist=False):
-    """dst [B,Nd',3,C], src [B,Ns,3,C] -> idx [B,Nd,K] int32 (Nd = dst_rows.shape[1] if given)."""
+def knn(dst, src, K=16, dst_rows=None, flags=DEFAULT_FLAGS, return_dist=False, seeds=None):
+    """dst [B,Nd',3,C], src [B,Ns,3,C] -> idx [B,Nd,K] int32 (Nd = dst_rows.shape[1] if given).
+    seeds [B,Nd,16] int32: optional candidate hints (result independent of them)."""
     dst, src = _f32(dst), _f32(src)
     B, dst_n, _, C = dst.shape
     Ns = src.shape[1]
     Nd = dst_rows.shape[1] if dst_rows is not None else dst_n
     idx = torch.empty(B, Nd, K, dtype=torch.int32, device=src.device)
     dist = torch.empty(B, Nd, K, dtype=torch.float32, device=src.device) if return_dist else None
-    check(load().ls_knn_f32(ptr(dst), ptr(src), ptr(dst_rows), B, Nd, dst_n, Ns, C, K, flags, ptr(idx), ptr(dist),
+    if seeds is not None:
+        seeds = seeds.to(torch.int32).contiguous()
+        assert seeds.shape == (B, Nd, 16)
+    check(load().ls_knn_f32(ptr(dst), ptr(src), ptr(dst_rows), ptr(seeds), B, Nd, dst_n, Ns, C, K, flags, ptr(idx), ptr(dist),
                             stream_ptr(src.device)), "ls_knn_f32")
     return (idx, dist) if return_dist else idx
 

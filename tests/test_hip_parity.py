@@ -90,6 +90,32 @@ def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
     assert np.array_equal(idx2.cpu().numpy(), ref) and np.array_equal(dist2.cpu().numpy(), refd)
 
 
+@pytest.mark.parametrize("shape", [(2, 200, 200, 32), (3, 70, 330, 64), (40, 256, 1024, 32)])
+def test_knn_hints_do_not_change_the_result(shape):
+    """seed_idx are HINTS: exact neighbours, random indices, duplicates of each other's ranges, -1 and out-of-range values
+    must all yield the oracle's answer bit for bit (also through the candidate-split + merge path)."""
+    from livingscenes_amd import ops
+    from oracle import canon
+    B, Nd, Ns, C = shape
+    rng = np.random.default_rng(B * 1000 + Nd)
+    src = rng.standard_normal((B, Ns, 3, C)).astype(np.float32)
+    sel = np.stack([rng.permutation(Ns)[:Nd] for _ in range(B)]).astype(np.int32)
+    dst = np.stack([src[b, sel[b]] for b in range(B)])
+    ref, refd = canon.knn_c(dst, src, 16, return_dist=True)
+    st, dt = torch.from_numpy(src).to(_dev()), torch.from_numpy(dst).to(_dev())
+    hints = {
+        "exact": ref.copy(),
+        "random": rng.integers(0, Ns, (B, Nd, 16)).astype(np.int32),
+        "mixed": np.where(rng.random((B, Nd, 16)) < 0.5, ref, rng.integers(-3, Ns + 5, (B, Nd, 16))).astype(np.int32),
+        "none": -np.ones((B, Nd, 16), np.int32),
+    }
+    hints["random"][:, :, 1] = hints["random"][:, :, 0]  # duplicate hints inside a row
+    for name, h in hints.items():
+        idx, dist = ops.knn(dt, st, 16, seeds=torch.from_numpy(h).to(_dev()), return_dist=True)
+        assert np.array_equal(idx.cpu().numpy(), ref), name
+        assert np.array_equal(dist.cpu().numpy(), refd), name
+
+
 def test_knn_dst_rows_and_self():
     from livingscenes_amd import ops
     from oracle import canon

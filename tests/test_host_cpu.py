@@ -50,9 +50,9 @@ def test_abi_fails_loudly_without_device(lib):
 def test_argument_validation_without_device(lib):
     # shape checks happen on the host before any launch
     P = ctypes.c_void_p
-    assert lib.ls_knn_f32(P(16), P(16), None, 1, 8, 8, 8, 5, 16, 0, P(16), None, None) == -1
+    assert lib.ls_knn_f32(P(16), P(16), None, None, 1, 8, 8, 8, 5, 16, 0, P(16), None, None) == -1
     assert b"multiple of 32" in lib.ls_last_error()
-    assert lib.ls_knn_f32(P(16), P(16), None, 1, 8, 8, 8, 32, 17, 0, P(16), None, None) == -1
+    assert lib.ls_knn_f32(P(16), P(16), None, None, 1, 8, 8, 8, 32, 17, 0, P(16), None, None) == -1
     assert lib.ls_gemm_f32(P(16), 6, P(16), 8, None, P(16), 8, 4, 4, 6, 0, None) == -1
     assert lib.ls_fps_f32(P(16), None, 1, 100000, 8, 0, P(16), None, None) == -1
     assert b"too large" in lib.ls_last_error()
