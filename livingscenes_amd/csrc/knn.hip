@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ d
                                                   int qtiles, int splits, int tiles_per_split, u64* __restrict__ partial,
                                                   const int32_t* __restrict__ seed_idx, int seed_n, int seed_by_row) {
     constexpr int ROW = (CC == 1) ? 4 : (3 * CC + 4);  // floats per staged row (ROW/4 odd: conflict-free ds_read_b128)
+    constexpr int PR = 2 * 3 * CC + 4;                 // floats per candidate-PAIR row (PR/4 odd)
     constexpr int LC_FLOATS = (KNN_TS * ROW > KNN_TQ * KNN_LD) ? KNN_TS * ROW : KNN_TQ * KNN_LD;
     __shared__ __attribute__((aligned(16))) float lq[KNN_TQ * ROW];
     __shared__ __attribute__((aligned(16))) float lc[LC_FLOATS];   // candidate chunk; re-used as the 64x64 distance tile
@@ -96,11 +97,15 @@ __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ d
     }
 
     for (int s0 = s_begin; s0 < s_end; s0 += KNN_TS) {
-        float acc[4][4];
+        float acc[4][4];      // raw clouds (CC == 1)
+        f32x2 acc2[4][2];     // feature layers: [query][candidate pair] x (even, odd candidate)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc2[i][j] = f32x2{0.0f, 0.0f};
+        }
 
         if constexpr (CC == 1) {
             __syncthreads();  // previous selection finished with ldist (== lc)
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ d
             for (int ch = 0; ch < nchunks; ++ch) {
                 __syncthreads();  // previous chunk's compute / previous tile's selection done with lq, lc
                 if (!q_once) sq.store(lq, ROW, tid);
-                sc.store(lc, ROW, tid);
+                sc.store_pairs(lc, PR, tid);
                 __syncthreads();
                 // prefetch the next chunk (or the next tile's first chunk) into registers
                 {
@@ -142,30 +147,46 @@ __global__ __launch_bounds__(256, 3) void knn_kernel(const float* __restrict__ d
                 }
 #pragma unroll 1
                 for (int d4 = 0; d4 < 3 * CC; d4 += 4) {
-                    float4 qv[4], cv[4];
+                    float4 qv[4];
+                    f32x2 cp[2][4];  // [candidate pair][dim] = (c_{2pm}.d, c_{2pm+1}.d)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        qv[i] = *reinterpret_cast<const float4*>(&lq[(ty * 4 + i) * ROW + d4]);
-                        cv[i] = *reinterpret_cast<const float4*>(&lc[(tx + 16 * i) * ROW + d4]);
+                    for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(&lq[(ty * 4 + i) * ROW + d4]);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const float4 lo = *reinterpret_cast<const float4*>(&lc[(tx + 16 * jj) * PR + d4 * 2]);
+                        const float4 hi = *reinterpret_cast<const float4*>(&lc[(tx + 16 * jj) * PR + d4 * 2 + 4]);
+                        cp[jj][0] = f32x2{lo.x, lo.y}; cp[jj][1] = f32x2{lo.z, lo.w};
+                        cp[jj][2] = f32x2{hi.x, hi.y}; cp[jj][3] = f32x2{hi.z, hi.w};
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float a = acc[i][j];  // canonical order j = c*3+x == LDS order
-                            a = accq<FMA>(a, qv[i].x, cv[j].x); a = accq<FMA>(a, qv[i].y, cv[j].y);
-                            a = accq<FMA>(a, qv[i].z, cv[j].z); a = accq<FMA>(a, qv[i].w, cv[j].w);
-                            acc[i][j] = a;
+                        for (int jj = 0; jj < 2; ++jj) {
+                            f32x2 a = acc2[i][jj];  // canonical order j = c*3+x == LDS dim order
+                            a = accq2<FMA>(a, qv[i].x, cp[jj][0]); a = accq2<FMA>(a, qv[i].y, cp[jj][1]);
+                            a = accq2<FMA>(a, qv[i].z, cp[jj][2]); a = accq2<FMA>(a, qv[i].w, cp[jj][3]);
+                            acc2[i][jj] = a;
                         }
                 }
             }
             __syncthreads();  // everyone is done reading lc before it becomes the distance tile
         }
-        // distance tile -> LDS, candidate c of a query row stored at slot (c & 15) * 4 + (c >> 4): the four distances a
-        // thread owns for one query are contiguous (one ds_write_b128) and so are the four a selection lane reads.
+        // distance tile -> LDS, candidate c of a query row stored at slot (c & 15) * 4 + (c >> 4) (what a selection lane
+        // reads with one ds_read_b128).  Feature layers own candidates c = 2*tx + 32*jj + h (pair-interleaved).
+        if constexpr (CC == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&ldist[(ty * 4 + i) * KNN_LD + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(&ldist[(ty * 4 + i) * KNN_LD + tx * 4]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int c0 = 2 * tx + 32 * jj;
+                    ldist[(ty * 4 + i) * KNN_LD + (c0 & 15) * 4 + (c0 >> 4)] = acc2[i][jj].x;
+                    ldist[(ty * 4 + i) * KNN_LD + ((c0 + 1) & 15) * 4 + ((c0 + 1) >> 4)] = acc2[i][jj].y;
+                }
+        }
         __syncthreads();
 
         if (seeded) select_tile<true>(ldist, lk, rkey, s0, Ns, K, wave, lane);

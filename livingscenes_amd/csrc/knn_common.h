@@ -22,6 +22,21 @@ __device__ __forceinline__ float accq(float d, float a, float b) {
 }
 
 typedef unsigned long long u64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two canonical accumulations at once (two candidates, same query value): maps onto v_pk_add / v_pk_mul (/ v_pk_fma)
+template <bool FMA>
+__device__ __forceinline__ f32x2 accq2(f32x2 d, float q, f32x2 c) {
+#pragma clang fp contract(off)
+    const f32x2 qq = {q, q};
+    const f32x2 diff = qq - c;
+    if constexpr (FMA) {
+        return __builtin_elementwise_fma(diff, diff, d);
+    } else {
+        const f32x2 p = diff * diff;
+        return d + p;
+    }
+}
 
 // (dist >= 0, idx) -> sortable key; invalid candidates get the "empty" key ~0
 __device__ __forceinline__ u64 make_key(float d, int idx, bool valid) {
@@ -62,6 +77,17 @@ struct Stager {
         for (int u = 0; u < PER; ++u) {
             const float4 v = *reinterpret_cast<const float4*>(p + (size_t)(u / U2) * C + (u % U2) * 16);
             r[u] = gr >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // candidate-PAIR interleaved image: rows 2m and 2m+1 share one LDS row of stride PR, element (dim dd, parity h) at
+    // dd*2 + h, so that one ds_read_b128 yields (c0.d, c1.d, c0.d+1, c1.d+1): natural operand pairs for v_pk_* math.
+    __device__ __forceinline__ void store_pairs(float* lds, int PR, int tid) const {
+        const int rr = tid >> 2, q = tid & 3;
+        float* p0 = lds + (rr >> 1) * PR + (rr & 1) + 2 * (q * 12);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            float* p = p0 + 2 * ((u % U2) * 48 + (u / U2));
+            p[0] = r[u].x; p[6] = r[u].y; p[12] = r[u].z; p[18] = r[u].w;
         }
     }
     __device__ __forceinline__ void store(float* lds, int ROW, int tid) const {
