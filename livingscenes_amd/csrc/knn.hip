@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64* __restrict__ 
 static int knn_choose_splits(int B, int Nd, int Ns) {
     const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
     const int blocks = B * qtiles;
-    if (blocks >= 768 || ctiles < 2) return 1;
+    if (blocks >= 512 || ctiles < 2) return 1;  // >= 2 workgroups per CU: splitting would only add merge work (and un-seeded splits)
     int sp = cdiv(1024, blocks);
     if (sp > ctiles) sp = ctiles;
     if (sp > 16) sp = 16;
@@ -254,7 +254,7 @@ size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, unsigned flags) {
 }
 int row_norms_launch(const float*, int, long long, float*, hipStream_t);
 int knn_mfma_launch(const float*, const float*, const int32_t*, const float*, const float*, int, int, int, int, int, int, bool, int32_t*,
-                    float*, int, int, u64*, hipStream_t);
+                    float*, int, int, u64*, const int32_t*, int, int, hipStream_t);
 
 template <int CC, bool FMA>
 static int launch_knn(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
@@ -284,7 +284,7 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
-    if (C >= 32 && scratch && (flags & LS_FLAG_KNN_MFMA_FILTER)) {
+    if (C == 32 && scratch && (flags & LS_FLAG_KNN_MFMA_FILTER)) {
         // opt-in MFMA-filtered kernel (knn_mfma.hip): same result, ~10 % of the canonical distance work, but slower in practice
         const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
         int splits = knn_choose_splits(B, Nd, Ns);
@@ -301,7 +301,8 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
             rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
             if (rc != LS_OK) return rc;
         }
-        rc = knn_mfma_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, splits, tps, partial, st);
+        rc = knn_mfma_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, splits, tps, partial, seed_idx, seed_n,
+                             seed_by_row, st);
         if (rc != LS_OK) return rc;
         if (splits > 1) {
             const int total_q = B * Nd;

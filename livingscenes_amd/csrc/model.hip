@@ -60,6 +60,7 @@ struct ls_model {
     hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
+    bool knn_filter = false;       // LS_KNN_FILTER=1: MFMA pre-filtered k-NN kernel on the seeded C == 32 layers
     bool seed_knn = true;          // LS_KNN_SEEDS=0 disables seeding a layer's k-NN lists from the previous layer's graph
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     bool profiling = false;
@@ -248,6 +249,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     m->d = *desc;
     if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_SEEDS")) m->seed_knn = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_KNN_FILTER")) m->knn_filter = atoi(ev) != 0;
     hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
     if (e != hipSuccess) { delete m; set_error("hipMalloc(model blob): %s", hipGetErrorString(e)); return LS_ERR_HIP; }
     e = hipMemcpy(m->blob, blob_host, (size_t)desc->blob_floats * sizeof(float), hipMemcpyHostToDevice);
@@ -388,7 +390,8 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
                 // == this layer's source set, so its indices address this layer's candidates directly)
                 const int32_t* seeds = (m->seed_knn && prev_knn && p.level[i - 1] < 0) ? prev_knn : nullptr;
-                rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
+                const unsigned kflags = flags | ((m->knn_filter && seeds && Cin == 32) ? LS_FLAG_KNN_MFMA_FILTER : 0u);
+                rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if (attn) { PROF(LS_K_EDGE_ATTN, i, st); rc = edge_attn_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st); }

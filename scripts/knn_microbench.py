@@ -12,11 +12,15 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
 src = torch.randn(a.B, a.Ns, 3, a.C, generator=g).to(dev)
 dst = src[:, :a.Nd].contiguous()
-for _ in range(2): ops.knn(dst, src, 16, flags=a.flags)
+seeds = None
+if a.flags & 4:  # bit 2: use the exact answer of a first run as hints (upper bound of what seeding can give)
+    seeds = ops.knn(dst, src, 16)
+    a.flags &= ~4
+for _ in range(2): ops.knn(dst, src, 16, flags=a.flags, seeds=seeds)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(a.iters): ops.knn(dst, src, 16, flags=a.flags)
+for _ in range(a.iters): ops.knn(dst, src, 16, flags=a.flags, seeds=seeds)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 fl = 3.0 * a.B * a.Nd * a.Ns * 3 * a.C

@@ -70,7 +70,7 @@ def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
     from livingscenes_amd import _lib, ops
     from oracle import canon
     rng = np.random.default_rng({"offset": 1, "near_duplicates": 2, "clustered": 3, "scale_mix": 4}[case])
-    B, N, C = 3, 640, 64
+    B, N, C = 3, 640, 32
     f = rng.standard_normal((B, N, 3, C)).astype(np.float32)
     if case == "offset":
         f = (f * 1e-3 + 50.0).astype(np.float32)            # norms ~ 7e5, spreads ~ 1e-3: d^ is pure cancellation noise
@@ -110,10 +110,12 @@ def test_knn_hints_do_not_change_the_result(shape):
         "none": -np.ones((B, Nd, 16), np.int32),
     }
     hints["random"][:, :, 1] = hints["random"][:, :, 0]  # duplicate hints inside a row
+    from livingscenes_amd import _lib
     for name, h in hints.items():
-        idx, dist = ops.knn(dt, st, 16, seeds=torch.from_numpy(h).to(_dev()), return_dist=True)
-        assert np.array_equal(idx.cpu().numpy(), ref), name
-        assert np.array_equal(dist.cpu().numpy(), refd), name
+        for fl in (0, _lib.FLAG_KNN_MFMA_FILTER):   # all-VALU kernel and the MFMA-filtered kernel (C == 32 only)
+            idx, dist = ops.knn(dt, st, 16, seeds=torch.from_numpy(h).to(_dev()), return_dist=True, flags=fl)
+            assert np.array_equal(idx.cpu().numpy(), ref), (name, fl)
+            assert np.array_equal(dist.cpu().numpy(), refd), (name, fl)
 
 
 def test_knn_dst_rows_and_self():
