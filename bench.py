@@ -289,6 +289,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier(device_ids=[local_rank])  # rank 0 may still be in its profiled pass / JSON print
         dist.destroy_process_group()
 
 
