@@ -46,6 +46,20 @@ def layer_plan(cfg, N):
     return out
 
 
+def committed_pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_latest.json, produced by
+    scripts/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command; counters cannot be
+    read from inside the process).  None when no committed measurement names this kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        e = pmc[kernel]
+        return e["hbm_read_bytes"] + e["hbm_write_bytes"], "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def algorithmic_cost(kind, layer, cfg, B, N):
     """(bytes, flops) one launch of kernel `kind` at `layer` must move / execute."""
     pl = layer_plan(cfg, N)
@@ -215,8 +229,8 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=abytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
         roof["kernel"] = f"{dom['kind']}[layer {dom['layer']}]"
+        roof["traffic"], roof["traffic_source"] = committed_pmc_traffic(roof["kernel"])
         roof["avg_launch_us"] = avg_s * 1e6
         roof["algorithmic_bytes_per_launch"] = abytes
         roof["algorithmic_flops_per_launch"] = aflops
