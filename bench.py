@@ -115,6 +115,7 @@ def main():
                     help="threads for the CPU baseline: the reference's op sequence peaks at ~16 threads on the GPU box's "
                          "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; scripts/cpu_threads_probe.py)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-fma-variant", action="store_true", help="skip the secondary fused-multiply-add k-NN timing")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent steps kept in flight on separate HIP streams (each with its own model handle and "
                          "workspace): one step's low-occupancy kernels (FPS, heads, matcher) overlap another's big ones")
@@ -199,6 +200,28 @@ def main():
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
+
+    # secondary figure (never `value`): the same K steps with LS_FLAG_CONTRACT_FMA, i.e. dist = fmaf(diff, diff, dist) as nvcc
+    # compiles pytorch3d's knn.cu -- the rounding the reference's CUDA deployment runs with
+    dt_fma = None
+    if not args.no_fma_variant:
+        for s_ in sps:
+            s_.knn_flags = 1
+        with torch.no_grad():
+            run(nfl)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize()
+            barrier()
+            dt_fma = time.perf_counter() - t0
+        for s_ in sps:
+            s_.knn_flags = 0
+        dt_f = torch.tensor([dt_fma], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt_f, op=dist.ReduceOp.MAX)
+        dt_fma = float(dt_f.item())
 
     emb, m, R, t = out
     # sanity of the measured work (outside the timed region): matches are the identity permutation, poses are rotations
@@ -298,6 +321,10 @@ def main():
                        "steps_in_flight": nfl,
                        "knn_arithmetic": "canonical (separately rounded mul/add)"},
             "check": {"matches_identity": f"{n_correct}/{n_obj}", "rotations_proper": det_ok},
+            "variants": None if dt_fma is None else {
+                "knn_fused_multiply_add": {"value": total_objects / dt_fma, "ms_per_step": dt_fma / args.steps * 1e3,
+                                           "note": "same steps with LS_FLAG_CONTRACT_FMA (nvcc-style rounding of dist += diff*diff); "
+                                                   "bit-exact against the oracle's contract=1 mode; not the headline value"}},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

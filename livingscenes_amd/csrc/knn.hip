@@ -255,6 +255,8 @@ size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, unsigned flags) {
 int row_norms_launch(const float*, int, long long, float*, hipStream_t);
 int knn_mfma_launch(const float*, const float*, const int32_t*, const float*, const float*, int, int, int, int, int, int, bool, int32_t*,
                     float*, int, int, u64*, const int32_t*, int, int, hipStream_t);
+int knn_sweep_launch(const float*, const float*, const int32_t*, const float*, const float*, int, int, int, int, int, int, bool, int32_t*,
+                     float*, const int32_t*, int, int, hipStream_t);
 
 template <int CC, bool FMA>
 static int launch_knn(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
@@ -301,6 +303,8 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
             rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
             if (rc != LS_OK) return rc;
         }
+        if (seed_idx && Ns <= 65535)  // seeded: un-split sweep kernel (thresholds are near-final from the start)
+            return knn_sweep_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, st);
         rc = knn_mfma_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, splits, tps, partial, seed_idx, seed_n,
                              seed_by_row, st);
         if (rc != LS_OK) return rc;

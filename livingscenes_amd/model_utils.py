@@ -134,7 +134,7 @@ class Shape_Prior(nn.Module):
 
     def encode(self, x):
         """x [B,3,N] -> {'z_so3' [B,256,3], 'z_inv' [B,256], 's' [B], 't' [B,1,3]}   (model_utils.py:165-197)"""
-        z_so3, z_inv, s, t = self.hip_model().encode(x)
+        z_so3, z_inv, s, t = self.hip_model().encode(x, flags=getattr(self, "knn_flags", 0))
         return {"z_so3": z_so3, "z_inv": z_inv, "s": s, "t": t.unsqueeze(1)}
 
     def encode_fps(self, batch_pc, batch_mask, n_fps=1):

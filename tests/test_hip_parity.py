@@ -60,6 +60,10 @@ def test_knn_large_batch_unsplit_path():
     ft = torch.from_numpy(f).to(_dev())
     assert np.array_equal(ops.knn(ft, ft, 16).cpu().numpy(), ref)
     assert np.array_equal(ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER).cpu().numpy(), ref)
+    # seeded MFMA sweep kernel: hints = the lists of a perturbed copy of the features (what the previous layer's graph is)
+    hints = canon.knn_c((f + 0.3 * rng.standard_normal(f.shape)).astype(np.float32), f, 16)
+    got = ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER, seeds=torch.from_numpy(hints).to(_dev()))
+    assert np.array_equal(got.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("case", ["offset", "near_duplicates", "clustered", "scale_mix"])
@@ -88,6 +92,14 @@ def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
     assert np.array_equal(idx.cpu().numpy(), ref) and np.array_equal(dist.cpu().numpy(), refd)
     idx2, dist2 = ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER, return_dist=True)
     assert np.array_equal(idx2.cpu().numpy(), ref) and np.array_equal(dist2.cpu().numpy(), refd)
+    # seeded sweep kernel (thresholds from hints): exact hints, hints shifted to other points' lists, half-garbage hints
+    hints = {"exact": ref, "shifted": np.roll(ref, 7, axis=1),
+             "mixed": np.where(rng.random(ref.shape) < 0.5, ref, rng.integers(0, N, ref.shape)).astype(np.int32)}
+    for name, h in hints.items():
+        for fl in (_lib.FLAG_KNN_MFMA_FILTER, _lib.FLAG_KNN_MFMA_FILTER | _lib.FLAG_CONTRACT_FMA):
+            r2, d2 = (ref, refd) if not (fl & _lib.FLAG_CONTRACT_FMA) else canon.knn_c(f, f, 16, contract=1, return_dist=True)
+            i3, d3 = ops.knn(ft, ft, 16, flags=fl, seeds=torch.from_numpy(np.ascontiguousarray(h)).to(_dev()), return_dist=True)
+            assert np.array_equal(i3.cpu().numpy(), r2) and np.array_equal(d3.cpu().numpy(), d2), (name, fl)
 
 
 @pytest.mark.parametrize("shape", [(2, 200, 200, 32), (3, 70, 330, 64), (40, 256, 1024, 32)])
