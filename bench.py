@@ -241,8 +241,12 @@ def main():
         prof = hip.profile_end()
         tot = sum(p["total_ms"] for p in prof)
         by = sorted(prof, key=lambda p: -p["total_ms"])
-        # dominant kernel = the (kind, layer) launch with the largest total time
-        dom = by[0]
+        # dominant kernel = the largest launch of the kernel family with the largest share of device time
+        fam = {}
+        for q in prof:
+            fam[q["kind"]] = fam.get(q["kind"], 0.0) + q["total_ms"]
+        dom_kind = max(fam, key=fam.get)
+        dom = max((q for q in prof if q["kind"] == dom_kind), key=lambda q: q["total_ms"])
         abytes, aflops = algorithmic_cost(dom["kind"], dom["layer"], ecfg, B, N)
         avg_s = dom["total_ms"] / dom["launches"] * 1e-3
         t_hbm, t_fl = abytes / (HBM_PEAK_GBS * 1e9), aflops / (FP32_PEAK_TFLOPS * 1e12)

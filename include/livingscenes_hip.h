@@ -38,8 +38,9 @@ typedef enum {
 
 /* flags for the integer-exact ops: how `dist += diff*diff` is rounded (oracle/ls_oracle.c header) */
 #define LS_FLAG_CONTRACT_FMA 1u /* d = fmaf(diff,diff,d); default (0) = separately rounded mul, add */
-#define LS_FLAG_KNN_MFMA_FILTER 2u /* k-NN: opt-in MFMA pre-filter kernel (knn_mfma.hip): bit-identical result; measured
-                                     slower than the all-VALU kernel on MI355X, kept for A/B work */
+#define LS_FLAG_KNN_MFMA_FILTER 2u /* k-NN: accepted for compatibility, no effect: the MFMA sweep kernel (knn_mfma.hip) is the
+                                     default wherever it applies (seed_idx given, C == 32); result is bit-identical */
+#define LS_FLAG_KNN_VALU_ONLY 4u   /* k-NN: force the all-VALU kernel (knn.hip) even where the MFMA sweep applies (A/B work) */
 
 #define LS_MAX_LAYERS 8
 

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "liblivingscenes_hip.so")
 LS_MAX_LAYERS = 8
 FLAG_CONTRACT_FMA = 1
 FLAG_KNN_MFMA_FILTER = 2
+FLAG_KNN_VALU_ONLY = 4
 
 
 class LsError(RuntimeError):

@@ -247,14 +247,15 @@ static size_t knn_partial_bytes(int B, int Nd, int Ns) {
     const int sp = knn_choose_splits(B, Nd, Ns);
     return sp > 1 ? (size_t)B * Nd * sp * 16 * sizeof(u64) : 0;
 }
-size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, unsigned flags) {
-    size_t b = knn_partial_bytes(B, Nd, Ns);
-    if (flags & LS_FLAG_KNN_MFMA_FILTER) b += ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256;
-    return b;
+// the MFMA sweep kernel (knn_mfma.hip) takes the seeded C == 32 launches unless the caller forces the all-VALU kernel
+static bool knn_uses_sweep(int C, bool seeded, int Ns, unsigned flags) {
+    return C == 32 && seeded && Ns <= 65535 && !(flags & LS_FLAG_KNN_VALU_ONLY);
+}
+size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags) {
+    if (knn_uses_sweep(C, seeded, Ns, flags)) return ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256;  // row norms
+    return knn_partial_bytes(B, Nd, Ns);
 }
 int row_norms_launch(const float*, int, long long, float*, hipStream_t);
-int knn_mfma_launch(const float*, const float*, const int32_t*, const float*, const float*, int, int, int, int, int, int, bool, int32_t*,
-                    float*, int, int, u64*, const int32_t*, int, int, hipStream_t);
 int knn_sweep_launch(const float*, const float*, const int32_t*, const float*, const float*, int, int, int, int, int, int, bool, int32_t*,
                      float*, const int32_t*, int, int, hipStream_t);
 
@@ -286,15 +287,9 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
-    if (C == 32 && scratch && (flags & LS_FLAG_KNN_MFMA_FILTER)) {
-        // opt-in MFMA-filtered kernel (knn_mfma.hip): same result, ~10 % of the canonical distance work, but slower in practice
-        const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
-        int splits = knn_choose_splits(B, Nd, Ns);
-        const int tps = cdiv(ctiles, splits);
-        splits = cdiv(ctiles, tps);
-        char* sc = (char*)scratch;
-        u64* partial = (u64*)sc;
-        float* nsrc = (float*)(sc + knn_partial_bytes(B, Nd, Ns));
+    if (scratch && knn_uses_sweep(C, seed_idx != nullptr, Ns, flags)) {
+        // seeded C == 32 layer: un-split MFMA sweep kernel (knn_mfma.hip); same result as the all-VALU kernel below
+        float* nsrc = (float*)scratch;
         float* ndst = nsrc;
         int rc = row_norms_launch(src, 3 * C, (long long)B * Ns, nsrc, st);
         if (rc != LS_OK) return rc;
@@ -303,18 +298,7 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
             rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
             if (rc != LS_OK) return rc;
         }
-        if (seed_idx && Ns <= 65535)  // seeded: un-split sweep kernel (thresholds are near-final from the start)
-            return knn_sweep_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, st);
-        rc = knn_mfma_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, splits, tps, partial, seed_idx, seed_n,
-                             seed_by_row, st);
-        if (rc != LS_OK) return rc;
-        if (splits > 1) {
-            const int total_q = B * Nd;
-            hipLaunchKernelGGL(knn_merge_kernel, dim3(cdiv(total_q, 16)), dim3(256), 0, st, (const u64*)partial, total_q, splits, K,
-                               idx_out, dist_out);
-            LS_LAUNCH_CHECK();
-        }
-        return LS_OK;
+        return knn_sweep_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, st);
     }
     if (C == 1) {
         return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st)

@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
 // kernels / launchers defined in the other translation units
 int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, void*, const int32_t*, int, int,
                  hipStream_t);
-size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, unsigned flags);
+size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
@@ -60,7 +60,7 @@ struct ls_model {
     hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
-    bool knn_filter = false;       // LS_KNN_FILTER=1: MFMA pre-filtered k-NN kernel on the seeded C == 32 layers
+    bool knn_filter = true;        // LS_KNN_FILTER=0: all-VALU k-NN kernel on the seeded C == 32 layers too (A/B timing)
     bool seed_knn = true;          // LS_KNN_SEEDS=0 disables seeding a layer's k-NN lists from the previous layer's graph
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     bool profiling = false;
@@ -138,7 +138,8 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
         maxC = std::max(maxC, (size_t)p.Co[i]);
         maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
-        maxKs = std::max(maxKs, knn_scratch_bytes(B, p.Nd[i], p.Ns[i], p.Ns[i], LS_FLAG_KNN_MFMA_FILTER));
+        maxKs = std::max(maxKs, std::max(knn_scratch_bytes(B, p.Nd[i], p.Ns[i], p.Ns[i], p.Cin[i], true, 0u),
+                                        knn_scratch_bytes(B, p.Nd[i], p.Ns[i], p.Ns[i], p.Cin[i], false, 0u)));
     }
     LS_REQUIRE(d.num_knn == 16, "encoder: num_knn=%d unsupported (16)", d.num_knn);
     LS_REQUIRE(p.Ns[p.L - 1] >= 1, "encoder: bad schedule");
@@ -186,7 +187,7 @@ int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, cons
     LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0 && dst_n > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
     LS_REQUIRE(K >= 1 && K <= 16, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
-    const size_t sb = knn_scratch_bytes(B, Nd, dst_n, Ns, flags);
+    const size_t sb = knn_scratch_bytes(B, Nd, dst_n, Ns, C, seed_idx != nullptr, flags);
     void* scratch = nullptr;
     if (sb) LS_HIP_CHECK(hipMallocAsync(&scratch, sb, (hipStream_t)stream));
     int rc = knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, scratch, seed_idx, Nd, 0,
@@ -390,7 +391,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
                 // == this layer's source set, so its indices address this layer's candidates directly)
                 const int32_t* seeds = (m->seed_knn && prev_knn && p.level[i - 1] < 0) ? prev_knn : nullptr;
-                const unsigned kflags = flags | ((m->knn_filter && seeds && Cin == 32) ? LS_FLAG_KNN_MFMA_FILTER : 0u);
+                const unsigned kflags = flags | (m->knn_filter ? 0u : LS_FLAG_KNN_VALU_ONLY);
                 rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));

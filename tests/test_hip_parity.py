@@ -59,18 +59,18 @@ def test_knn_large_batch_unsplit_path():
     ref = canon.knn_c(f, f, 16)
     ft = torch.from_numpy(f).to(_dev())
     assert np.array_equal(ops.knn(ft, ft, 16).cpu().numpy(), ref)
-    assert np.array_equal(ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER).cpu().numpy(), ref)
-    # seeded MFMA sweep kernel: hints = the lists of a perturbed copy of the features (what the previous layer's graph is)
-    hints = canon.knn_c((f + 0.3 * rng.standard_normal(f.shape)).astype(np.float32), f, 16)
-    got = ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER, seeds=torch.from_numpy(hints).to(_dev()))
-    assert np.array_equal(got.cpu().numpy(), ref)
+    # seeded launches take the MFMA sweep kernel (knn_mfma.hip) unless FLAG_KNN_VALU_ONLY forces the all-VALU kernel:
+    # hints = the lists of a perturbed copy of the features (what the previous layer's graph is to the next layer)
+    hints = torch.from_numpy(canon.knn_c((f + 0.3 * rng.standard_normal(f.shape)).astype(np.float32), f, 16)).to(_dev())
+    assert np.array_equal(ops.knn(ft, ft, 16, seeds=hints).cpu().numpy(), ref)
+    assert np.array_equal(ops.knn(ft, ft, 16, seeds=hints, flags=_lib.FLAG_KNN_VALU_ONLY).cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("case", ["offset", "near_duplicates", "clustered", "scale_mix"])
 def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
-    """The MFMA pre-filter may only drop pairs that provably cannot enter a list.  Stress the cancellation in
+    """The MFMA sweep kernel may only drop pairs that provably cannot enter a list.  Stress the cancellation in
     |q|^2+|s|^2-2q.s: a huge common offset, near-duplicate points, tight clusters, wildly different norms.  The result
-    must be bit-identical to the oracle for the default all-VALU kernel AND the opt-in MFMA-filtered kernel."""
+    must be bit-identical to the oracle for the all-VALU kernel (un-seeded) AND the seeded MFMA sweep kernel."""
     from livingscenes_amd import _lib, ops
     from oracle import canon
     rng = np.random.default_rng({"offset": 1, "near_duplicates": 2, "clustered": 3, "scale_mix": 4}[case])
@@ -90,13 +90,11 @@ def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
     ft = torch.from_numpy(f).to(_dev())
     idx, dist = ops.knn(ft, ft, 16, return_dist=True)
     assert np.array_equal(idx.cpu().numpy(), ref) and np.array_equal(dist.cpu().numpy(), refd)
-    idx2, dist2 = ops.knn(ft, ft, 16, flags=_lib.FLAG_KNN_MFMA_FILTER, return_dist=True)
-    assert np.array_equal(idx2.cpu().numpy(), ref) and np.array_equal(dist2.cpu().numpy(), refd)
     # seeded sweep kernel (thresholds from hints): exact hints, hints shifted to other points' lists, half-garbage hints
     hints = {"exact": ref, "shifted": np.roll(ref, 7, axis=1),
              "mixed": np.where(rng.random(ref.shape) < 0.5, ref, rng.integers(0, N, ref.shape)).astype(np.int32)}
     for name, h in hints.items():
-        for fl in (_lib.FLAG_KNN_MFMA_FILTER, _lib.FLAG_KNN_MFMA_FILTER | _lib.FLAG_CONTRACT_FMA):
+        for fl in (0, _lib.FLAG_CONTRACT_FMA):
             r2, d2 = (ref, refd) if not (fl & _lib.FLAG_CONTRACT_FMA) else canon.knn_c(f, f, 16, contract=1, return_dist=True)
             i3, d3 = ops.knn(ft, ft, 16, flags=fl, seeds=torch.from_numpy(np.ascontiguousarray(h)).to(_dev()), return_dist=True)
             assert np.array_equal(i3.cpu().numpy(), r2) and np.array_equal(d3.cpu().numpy(), d2), (name, fl)
@@ -124,7 +122,7 @@ def test_knn_hints_do_not_change_the_result(shape):
     hints["random"][:, :, 1] = hints["random"][:, :, 0]  # duplicate hints inside a row
     from livingscenes_amd import _lib
     for name, h in hints.items():
-        for fl in (0, _lib.FLAG_KNN_MFMA_FILTER):   # all-VALU kernel and the MFMA-filtered kernel (C == 32 only)
+        for fl in (0, _lib.FLAG_KNN_VALU_ONLY):   # MFMA sweep kernel (C == 32) / all-VALU kernel
             idx, dist = ops.knn(dt, st, 16, seeds=torch.from_numpy(h).to(_dev()), return_dist=True, flags=fl)
             assert np.array_equal(idx.cpu().numpy(), ref), (name, fl)
             assert np.array_equal(dist.cpu().numpy(), refd), (name, fl)
