@@ -267,7 +267,7 @@ def main():
         for p in prof:
             kinds[p["kind"]] = kinds.get(p["kind"], 0.0) + p["total_ms"]
         roof["breakdown_ms_per_step"] = {k: round(v / args.steps, 4) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])}
-        roof["per_layer_ms_per_step"] = {f"{p['kind']}{p['layer']}": round(p["total_ms"] / args.steps, 4) for p in by[:12]}
+        roof["per_layer_ms_per_step"] = {f"{p['kind']}{p['layer']}": round(p["total_ms"] / args.steps, 4) for p in by[:40]}
         # the other two kernel families north_star names, on their largest launch: the VN edge-conv gather kernel
         # (HBM/L2-gather-bound) and the fp32-MFMA VN-Linear GEMM
         extra = []

@@ -205,11 +205,7 @@ int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* b
 }
 int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out, void* stream) {
     LS_REQUIRE(B > 0, "prologue: empty batch");
-    float* scratch = nullptr;
-    LS_HIP_CHECK(hipMallocAsync((void**)&scratch, prologue_scratch_floats(B) * sizeof(float), (hipStream_t)stream));
-    int rc = prologue_launch(x, B, N, pts_out, centroid_out, scale0_out, scratch, (hipStream_t)stream);
-    LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
-    return rc;
+    return prologue_launch(x, B, N, pts_out, centroid_out, scale0_out, nullptr, (hipStream_t)stream);
 }
 int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* stream) {
     LS_REQUIRE(n > 0 && m > 0 && D > 0, "cosine_scores: empty problem");

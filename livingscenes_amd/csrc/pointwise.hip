@@ -16,9 +16,7 @@ __device__ __forceinline__ void top3_insert(float v, float& a, float& b, float& 
     }
 }
 
-constexpr int PRO_SPLIT = 16;  // workgroups per instance for the N^2/2 pair scan
-
-// centroid of instance b, cloud staged (un-centred) into sp[3][N]; identical summation order in every caller
+// centroid of instance b, cloud staged (un-centred) into sp[3][N]
 __device__ __forceinline__ void stage_and_centroid(const float* __restrict__ xb, int N, float* sp, float* red, float c[3]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float s[3] = {0.f, 0.f, 0.f};
@@ -34,53 +32,93 @@ __device__ __forceinline__ void stage_and_centroid(const float* __restrict__ xb,
     __syncthreads();
 }
 
-// grid (B, PRO_SPLIT): block `by` scans rows i = by, by+PRO_SPLIT, ... against j > i (lanes stride over j: coalesced,
-// conflict-free LDS reads) and writes its private top-3 squared pair distances to partial[b][by][3].
-__global__ __launch_bounds__(256) void prologue_pairs_kernel(const float* __restrict__ x, int N, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N]
-    __shared__ float red[12 + 12];
-    const int b = blockIdx.x, by = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float c[3];
-    stage_and_centroid(x + (size_t)b * 3 * N, N, sp, red, c);
-    for (int n = tid; n < N; n += 256) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) sp[a * N + n] -= c[a];
-    }
-    __syncthreads();
-    float t0 = -1.f, t1 = -1.f, t2 = -1.f;
-    for (int i = by; i < N; i += PRO_SPLIT) {
-        const float px = sp[i], py = sp[N + i], pz = sp[2 * N + i];
-        for (int j = i + 1 + tid; j < N; j += 256) {
-            const float dx = px - sp[j], dy = py - sp[N + j], dz = pz - sp[2 * N + j];
-            top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
-        }
-    }
+// block-wide top-3 of per-thread (t0 >= t1 >= t2); result broadcast to every thread
+__device__ __forceinline__ void block_top3(float& t0, float& t1, float& t2, float* red12) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float u0 = __shfl_xor(t0, o, 64), u1 = __shfl_xor(t1, o, 64), u2 = __shfl_xor(t2, o, 64);
         top3_insert(u0, t0, t1, t2); top3_insert(u1, t0, t1, t2); top3_insert(u2, t0, t1, t2);
     }
-    if (lane == 0) { red[12 + wave * 3] = t0; red[12 + wave * 3 + 1] = t1; red[12 + wave * 3 + 2] = t2; }
     __syncthreads();
-    if (tid == 0) {
-        t0 = t1 = t2 = -1.f;
-        for (int i = 0; i < 12; ++i) top3_insert(red[12 + i], t0, t1, t2);
-        float* po = partial + ((size_t)b * PRO_SPLIT + by) * 3;
-        po[0] = t0; po[1] = t1; po[2] = t2;
-    }
+    if (lane == 0) { red12[wave * 3] = t0; red12[wave * 3 + 1] = t1; red12[wave * 3 + 2] = t2; }
+    __syncthreads();
+    t0 = t1 = t2 = -1.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) top3_insert(red12[i], t0, t1, t2);
 }
 
-// grid (B): merge the partial top-3, scale_0, centroid, normalised cloud [B,N,3]
-__global__ __launch_bounds__(256) void prologue_finish_kernel(const float* __restrict__ x, int N, const float* __restrict__ partial,
-                                                              float* __restrict__ pts_out, float* __restrict__ centroid_out,
-                                                              float* __restrict__ scale0_out) {
-    extern __shared__ __attribute__((aligned(16))) float sp[];
+// One workgroup per instance.  The three largest pair distances only involve points near the hull, so the N^2/2 pair scan is
+// pruned EXACTLY: with a = the point farthest from the centroid and LB = the third largest squared distance from a (three
+// real pairs, so the overall third largest is >= LB), a pair (i, j) can reach the top three only if
+// |p_i| + |p_j| >= sqrt(LB), hence only if both |p_i| and |p_j| are >= sqrt(LB) - max|p|  (triangle inequality about the
+// centroid).  Those "outer" points are compacted and scanned pairwise with the same fp32 formula as the full scan, so the
+// three values (and scale_0) are bit-identical to it; a cloud whose points all lie on a sphere degenerates to the full scan.
+__global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__ x, int N, float* __restrict__ pts_out,
+                                                       float* __restrict__ centroid_out, float* __restrict__ scale0_out) {
+    extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N] centred cloud, then [N] outer-point indices
     __shared__ float red[12];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    __shared__ int nouter;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* outer = reinterpret_cast<int*>(sp + 3 * N);
     float c[3];
     stage_and_centroid(x + (size_t)b * 3 * N, N, sp, red, c);
+    // centre; squared norms; a = arg-max norm (first index on ties)
+    float best = -1.f;
+    int besti = 0;
+    for (int n = tid; n < N; n += 256) {
+        float r2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = sp[a * N + n] - c[a]; sp[a * N + n] = v; r2 += v * v; }
+        if (r2 > best) { best = r2; besti = n; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (lane == 0) { redv[wave] = best; redi[wave] = besti; }
+    if (tid == 0) nouter = 0;
+    __syncthreads();
+    best = redv[0]; besti = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (redv[w] > best || (redv[w] == best && redi[w] < besti)) { best = redv[w]; besti = redi[w]; }
+    const float rmax = sqrtf(best);
+    // LB = third largest squared distance from a
     float t0 = -1.f, t1 = -1.f, t2 = -1.f;
-    for (int i = 0; i < PRO_SPLIT * 3; ++i) top3_insert(partial[(size_t)b * PRO_SPLIT * 3 + i], t0, t1, t2);
+    {
+        const float px = sp[besti], py = sp[N + besti], pz = sp[2 * N + besti];
+        for (int j = tid; j < N; j += 256) {
+            if (j == besti) continue;
+            const float dx = px - sp[j], dy = py - sp[N + j], dz = pz - sp[2 * N + j];
+            top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
+        }
+    }
+    block_top3(t0, t1, t2, red);
+    // outer points: |p| >= sqrt(LB) (1 - 1e-4) - max|p|   (t2 < 0 when N < 4: keep everything)
+    const float cut = t2 > 0.f ? sqrtf(t2) * (1.0f - 1e-4f) - rmax : -1.f;
+    for (int n = tid; n < N; n += 256) {
+        const float r = sqrtf(sp[n] * sp[n] + sp[N + n] * sp[N + n] + sp[2 * N + n] * sp[2 * N + n]);
+        if (r >= cut) outer[atomicAdd(&nouter, 1)] = n;
+    }
+    __syncthreads();
+    const int M = nouter;
+    // all pairs among the outer points: thread -> rows i = tid/32 + 8k of the pair matrix, columns strided by 32
+    t0 = t1 = t2 = -1.f;
+    for (int i = tid >> 5; i < M; i += 8) {
+        const int pi = outer[i];
+        const float px = sp[pi], py = sp[N + pi], pz = sp[2 * N + pi];
+        for (int j = i + 1 + (tid & 31); j < M; j += 32) {
+            const int pj = outer[j];
+            const float dx = px - sp[pj], dy = py - sp[N + pj], dz = pz - sp[2 * N + pj];
+            top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
+        }
+    }
+    block_top3(t0, t1, t2, red);
     const float d1 = sqrtf(fmaxf(t0, 0.f)), d2 = sqrtf(fmaxf(t1, 0.f)), d3 = sqrtf(fmaxf(t2, 0.f));
     const float sc = ((((d1 + d1) + d2) + d2) + d3) / 5.0f;
     if (tid == 0) {
@@ -88,7 +126,7 @@ __global__ __launch_bounds__(256) void prologue_finish_kernel(const float* __res
         centroid_out[b * 3 + 0] = c[0]; centroid_out[b * 3 + 1] = c[1]; centroid_out[b * 3 + 2] = c[2];
     }
     float* po = pts_out + (size_t)b * N * 3;
-    for (int t = tid; t < N * 3; t += 256) { const int n = t / 3, a = t % 3; po[t] = (sp[a * N + n] - c[a]) / sc; }
+    for (int t = tid; t < N * 3; t += 256) { const int n = t / 3, a = t % 3; po[t] = sp[a * N + n] / sc; }
 }
 
 // [B,3,N] -> [B,N,3] without normalisation (pre_normalised path)
@@ -276,11 +314,10 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     }
 }
 
-size_t prologue_scratch_floats(int B) { return (size_t)B * PRO_SPLIT * 3; }
-int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, float* partial, hipStream_t st) {
+size_t prologue_scratch_floats(int B) { (void)B; return 0; }
+int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, float* /*unused*/, hipStream_t st) {
     LS_REQUIRE(N >= 3 && N <= 8192, "prologue: N=%d out of range (3..8192)", N);
-    hipLaunchKernelGGL(prologue_pairs_kernel, dim3(B, PRO_SPLIT), dim3(256), (size_t)3 * N * sizeof(float), st, x, N, partial);
-    hipLaunchKernelGGL(prologue_finish_kernel, dim3(B), dim3(256), (size_t)3 * N * sizeof(float), st, x, N, partial, pts, centroid, scale0);
+    hipLaunchKernelGGL(prologue_kernel, dim3(B), dim3(256), (size_t)4 * N * sizeof(float), st, x, N, pts, centroid, scale0);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

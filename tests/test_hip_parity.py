@@ -199,6 +199,33 @@ def test_prologue():
     assert relerr(pts, (xc / s0[:, None, None].float()).transpose(1, 2)) < 2e-6
 
 
+@pytest.mark.parametrize("case", ["sphere", "tiny", "duplicates", "line", "ragged_n"])
+def test_prologue_pruned_pair_scan_edge_cases(case):
+    """The prologue prunes the N^2 pair scan to hull-side points; the pruning must be exact: points on a sphere (nothing can
+    be pruned), N = 3 / 4 (fewer than three partners), exact duplicates of the extreme points, a collinear cloud."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(5)
+    if case == "sphere":
+        x = torch.randn(3, 3, 700, generator=g); x = x / x.norm(dim=1, keepdim=True) + torch.tensor([0.3, -0.2, 0.1])[None, :, None]
+    elif case == "tiny":
+        x = torch.randn(2, 3, 3, generator=g)
+    elif case == "duplicates":
+        x = torch.randn(2, 3, 256, generator=g); x[:, :, 1] = x[:, :, 0] = 4.0; x[:, :, 5] = x[:, :, 4] = -4.0
+    elif case == "line":
+        t = torch.linspace(-1, 1, 333)[None, None, :]; x = torch.tensor([1.0, 2.0, -0.5])[None, :, None] * t + 0.25
+        x = x.repeat(2, 1, 1).contiguous()
+    else:
+        x = torch.randn(2, 3, 1001, generator=g) * torch.tensor([3.0, 1.0, 0.3])[None, :, None]
+    B = x.shape[0]
+    pts, cen, sc = ops.encode_prologue(x.to(_dev()))
+    c = x.mean(-1)
+    xc = x - c[..., None]
+    d = torch.cdist(xc.transpose(1, 2).double(), xc.transpose(1, 2).double())
+    s0 = d.view(B, -1).topk(5, dim=-1)[0].mean(-1)
+    assert relerr(cen, c) < 1e-6 and relerr(sc, s0) < 2e-6
+    assert relerr(pts, (xc / s0[:, None, None].float()).transpose(1, 2)) < 4e-6
+
+
 # ------------------------------------------------------------------------------------------------ encoder
 def _hip_model(ecfg, ew, dcfg=None, dw=None):
     from livingscenes_amd import ops, packing
