@@ -251,13 +251,13 @@ static size_t knn_partial_bytes(int B, int Nd, int Ns) {
 static bool knn_uses_sweep(int C, bool seeded, int Ns, unsigned flags) {
     return C == 32 && seeded && Ns <= 65535 && !(flags & LS_FLAG_KNN_VALU_ONLY);
 }
+size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns);
+int knn_sweep_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, bool, int32_t*, float*, const int32_t*, int,
+                     int, void*, hipStream_t);
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags) {
-    if (knn_uses_sweep(C, seeded, Ns, flags)) return ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256;  // row norms
+    if (knn_uses_sweep(C, seeded, Ns, flags)) return knn_sweep_scratch_bytes(B, Nd, dst_n, Ns);
     return knn_partial_bytes(B, Nd, Ns);
 }
-int row_norms_launch(const float*, int, long long, float*, hipStream_t);
-int knn_sweep_launch(const float*, const float*, const int32_t*, const float*, const float*, int, int, int, int, int, int, bool, int32_t*,
-                     float*, const int32_t*, int, int, hipStream_t);
 
 template <int CC, bool FMA>
 static int launch_knn(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns,
@@ -287,19 +287,8 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
-    if (scratch && knn_uses_sweep(C, seed_idx != nullptr, Ns, flags)) {
-        // seeded C == 32 layer: un-split MFMA sweep kernel (knn_mfma.hip); same result as the all-VALU kernel below
-        float* nsrc = (float*)scratch;
-        float* ndst = nsrc;
-        int rc = row_norms_launch(src, 3 * C, (long long)B * Ns, nsrc, st);
-        if (rc != LS_OK) return rc;
-        if (dst != src) {
-            ndst = nsrc + (size_t)B * Ns;
-            rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
-            if (rc != LS_OK) return rc;
-        }
-        return knn_sweep_launch(dst, src, dst_rows, ndst, nsrc, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, st);
-    }
+    if (scratch && knn_uses_sweep(C, seed_idx != nullptr, Ns, flags))   // seeded C == 32 layer: seed / MFMA sweep / finish (knn_mfma.hip)
+        return knn_sweep_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
     if (C == 1) {
         return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st)
                    : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st);

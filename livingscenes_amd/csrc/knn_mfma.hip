@@ -41,18 +41,21 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// "sweep" kernel (C == 32 layers, seeded, un-split): the candidate sweep is a pure MFMA GEMM with a filtering epilogue.
-//   * lists are seeded from the previous layer's graph (knn_common.h), so each query's admission threshold kth (its exact
-//     K-th canonical distance so far) is near-final before the sweep starts: ~25 of 1024 candidates pass;
-//   * the query fragments of S = q . s stay in registers (48 VGPRs), candidates stream through LDS in 64-row x 32-dim
-//     chunks (double buffered, one barrier per chunk), three chunks = one 64x64 tile of S;
-//   * the epilogue of a tile appends the candidates that pass  d^ - eps <= kth  to a per-query survivor buffer (u16
-//     indices, KS_CAP slots) -- no canonical arithmetic, no sorting inside the sweep;
-//   * survivors get their CANONICAL distance (quad_pair_distance, rows re-read from L2) and are merged into the row-parallel
-//     lists only when a buffer could overflow during the next tile (rare; tightens kth) and once at the end.
-// Exactness: a dropped pair has canonical distance > kth >= final K-th distance; everything else is decided by canonical
-// keys.  Worst case (all-equal points, repeated hints) every tile flushes: slow but still exact.
-constexpr int KS_CAP = 128;   // survivor slots per query; a flush is forced once a buffer holds more than KS_CAP - 64
+// Three launches per seeded C == 32 layer (all on the caller's stream):
+//   1. knn_seed_kernel    exact canonical keys of each query's hints (the previous layer's list of the same point), sorted
+//                         and de-duplicated: seedkeys[B*Nd][16]; the K-th key is the query's admission threshold kth.
+//   2. knn_sweep_kernel   S = q . s for ALL pairs on the matrix cores; a candidate that passes  d^ - eps <= kth  and is not a
+//                         hint is appended to the query's survivor list (u16 indices in global memory, ~8 of 1024 on real
+//                         features).  No canonical arithmetic, no sorting, no lists: 100 VGPRs, 21 KB LDS, four workgroups
+//                         per CU, the whole layer-1 grid (1024 workgroups) resident in one round.
+//   3. knn_finish_kernel  canonical keys of the survivors, merged into the seeded list (knn_common.h) -> idx / dist.
+// The sweep is matrix-core bound, 1. and 3. are L2-gather-latency bound (tiny VALU load, high occupancy): as separate kernels
+// they overlap with whatever the other in-flight stream runs, instead of serialising inside every workgroup (a fused version
+// measured 83 k + 154 k + 50 k cycles per workgroup for the three phases).
+// Exactness: thresholds are static (kth of the hints); a dropped pair has canonical distance > kth >= the final K-th
+// distance; everything kept is decided by canonical keys.  A query whose hints give no finite threshold (fewer than K
+// distinct valid hints) or more than KS_CAP survivors is finished by brute force over all candidates: slow, still exact.
+constexpr int KS_CAP = 256;   // survivor slots per query (u16 indices in the workspace)
 constexpr int KS_LD = 36;     // chunk row stride (floats): 32 dims + 4, 9 x 16 B -> conflict-free ds_read_b128
 
 // Canonical distance of 16 (query row, candidate row) pairs per wave-instruction stream.  A lane that walks its own 384-byte
@@ -64,25 +67,25 @@ constexpr int KS_LD = 36;     // chunk row stride (floats): 32 dims + 4, 9 x 16 
 // the value one lane up (DPP quad_perm); after stage s lane s holds the exact prefix over runs 0..s.  96 dependent adds per
 // 16 pairs instead of 96 per 64 pairs -- 2x the VALU work of the lane-per-pair form, 8x fewer L1 line accesses.
 // Result valid in lanes with (lane & 3) == 3.
+struct QuadRow {   // one lane's share of a feature row: channels 8i..8i+7 of the x, y, z segments (i = lane & 3)
+    float4 v[6];
+    __device__ __forceinline__ void load(const float* __restrict__ row, int lane) {
+        const int off = (lane & 3) * 8;
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[x * 2 + h] = *reinterpret_cast<const float4*>(row + x * KM_CC + off + 4 * h);
+    }
+};
 template <bool FMA>
-__device__ __forceinline__ float quad_pair_distance(const float* __restrict__ qrow, const float* __restrict__ crow, int lane) {
+__device__ __forceinline__ float quad_pair_distance(const QuadRow& q, const QuadRow& c) {
 #pragma clang fp contract(off)
-    constexpr int C = KM_CC;
-    const int off = (lane & 3) * 8;
-    float4 qv[6], cv[6];
-#pragma unroll
-    for (int x = 0; x < 3; ++x)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            qv[x * 2 + h] = *reinterpret_cast<const float4*>(qrow + x * C + off + 4 * h);
-            cv[x * 2 + h] = *reinterpret_cast<const float4*>(crow + x * C + off + 4 * h);
-        }
     float t[24];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-            const float4 a = qv[x * 2 + h], b = cv[x * 2 + h];
+            const float4 a = q.v[x * 2 + h], b = c.v[x * 2 + h];
             const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
             t[(h * 4 + 0) * 3 + x] = FMA ? d0 : d0 * d0;
             t[(h * 4 + 1) * 3 + x] = FMA ? d1 : d1 * d1;
@@ -100,19 +103,60 @@ __device__ __forceinline__ float quad_pair_distance(const float* __restrict__ qr
     return d;
 }
 
+int row_norms_launch(const float* f, int row_f, long long npts, float* norms, hipStream_t st);
+
+// ---- 1. seeds.  One wave per four queries (row r of the wave = query 4*wave_id + r), four quad-steps of four hints.
 template <bool FMA>
-__global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+__global__ __launch_bounds__(256, 4) void knn_seed_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+                                                          const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
+                                                          const int32_t* __restrict__ seed_idx, int seed_n, int seed_by_row,
+                                                          u64* __restrict__ seedkeys, int groups_per_inst, int total_groups) {
+    constexpr int RF = 3 * KM_CC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x * 4 + wave;                     // global wave id
+    if (wg >= total_groups) return;                           // (wave-uniform; no workgroup barrier in this kernel)
+    const int b = wg / groups_per_inst, q = (wg % groups_per_inst) * 4 + (lane >> 4);
+    const float* dbase = dstf + (size_t)b * dst_n * RF;
+    const float* sbase = srcf + (size_t)b * Ns * RF;
+    const bool live = q < Nd;
+    const int r = live ? (dst_rows ? dst_rows[(size_t)b * Nd + q] : q) : -1;
+    const int quad = (lane >> 2) & 3;
+    const bool qlast = (lane & 3) == 3;
+    const int32_t* hp = seed_idx + ((size_t)b * seed_n + (seed_by_row ? max(r, 0) : min(q, seed_n - 1))) * 16;
+    int sidx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int si = hp[u * 4 + quad];
+        sidx[u] = (r >= 0 && si >= 0 && si < Ns) ? si : -1;
+    }
+    QuadRow qv;
+    qv.load(dbase + (size_t)max(r, 0) * RF, lane);
+    u64 ks[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        QuadRow cv;
+        cv.load(sbase + (size_t)max(sidx[u], 0) * RF, lane);
+        ks[u] = make_key(quad_pair_distance<FMA>(qv, cv), sidx[u], (sidx[u] >= 0) & qlast);
+    }
+    key_cx(ks[0], ks[1]); key_cx(ks[2], ks[3]); key_cx(ks[0], ks[2]); key_cx(ks[1], ks[3]); key_cx(ks[1], ks[2]);
+    u64 lk = ~0ull, rkey = ~0ull;
+    merge_keys<true>(ks[0], ks[1], ks[2], ks[3], lk, rkey, 16, lane);   // all distinct valid hints, sorted (K applies later)
+    if (live) seedkeys[((size_t)b * Nd + q) * 16 + (lane & 15)] = lk;
+}
+
+// ---- 2. sweep.  64 queries x all candidates per workgroup; wave (wm, wn) owns the 32x32 block of S for queries wm*32..,
+// candidates wn*32.. of each 64-candidate tile; the query fragments stay in registers, candidates stream through LDS in
+// 64-row x 32-dim chunks (double buffered, one barrier per chunk, three chunks = one tile).
+__global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                            const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
                                                            const float* __restrict__ nrm_src, int Nd, int dst_n, int Ns, int K,
-                                                           int32_t* __restrict__ idx_out, float* __restrict__ dist_out, int qtiles,
-                                                           float epsE, const int32_t* __restrict__ seed_idx, int seed_n, int seed_by_row) {
+                                                           int qtiles, float epsE, const u64* __restrict__ seedkeys,
+                                                           int32_t* __restrict__ surv_cnt, unsigned short* __restrict__ surv) {
     constexpr int C = KM_CC, RF = 3 * KM_CC;
     __shared__ __attribute__((aligned(16))) float lc[2][KNN_TS * KS_LD];              // 18 KB: two candidate chunks
-    __shared__ __attribute__((aligned(16))) unsigned short lbuf[KNN_TQ * KS_CAP];     // 16 KB: survivor indices
     __shared__ __attribute__((aligned(16))) unsigned short lseedidx[KNN_TQ * 16];     // 2 KB: the hints (0xFFFF = none)
     __shared__ float lnq[KNN_TQ], lkth[KNN_TQ];
     __shared__ int lqrow[KNN_TQ], lcnt[KNN_TQ];
-    __shared__ int lflush;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -128,98 +172,36 @@ __global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restri
         if (q < Nd) r = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
         lqrow[tid] = r;
         lnq[tid] = r >= 0 ? nrm_dst[(size_t)b * dst_n + r] : 0.f;
-        lkth[tid] = r >= 0 ? INFINITY : -INFINITY;  // padding queries never pass the filter
+        float kth = -INFINITY;                                  // padding queries never pass the filter
+        if (r >= 0) {
+            const unsigned hi = (unsigned)(seedkeys[((size_t)b * Nd + q) * 16 + (K - 1)] >> 32);
+            kth = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);   // fewer than K distinct hints: everything passes
+        }
+        lkth[tid] = kth;
         lcnt[tid] = 0;
     }
-    if (tid == 0) lflush = 0;
+    for (int i = tid; i < KNN_TQ * 16; i += 256) {
+        const int q = q0 + (i >> 4);
+        unsigned short h = 0xFFFFu;
+        if (q < Nd) {
+            const u64 k = seedkeys[((size_t)b * Nd + q) * 16 + (i & 15)];
+            if ((unsigned)(k >> 32) != 0xFFFFFFFFu) h = (unsigned short)(unsigned)k;
+        }
+        lseedidx[i] = h;
+    }
     __syncthreads();
 
-    const int wm = wave >> 1, wn = wave & 1;            // MFMA tile: queries wm*32.., candidates wn*32..
+    const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    u64 lk[4], rkey[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { lk[i] = ~0ull; rkey[i] = ~0ull; }
-
-    auto refresh_kth = [&]() {  // the row's K-th canonical distance (+inf while the list is not full)
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int qr = wave * 16 + g * 4 + (lane >> 4);
-                const unsigned hi = (unsigned)(rkey[g] >> 32);
-                if (lqrow[qr] >= 0) lkth[qr] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
-            }
-        }
-    };
-    // Quad-cooperative exact phase (quad_pair_distance): in group g the 16-lane row r of the wave belongs to query
-    // wave*16 + g*4 + r; its four quads take four candidates per step, four steps feed one merge_keys call (<= 16 keys a row).
-    const int quad = (lane >> 2) & 3;              // quad index inside the 16-lane row
-    const bool qlast = (lane & 3) == 3;            // the lane of a quad that ends up with the distance
-    // canonical keys for the buffered survivors of this wave's 16 queries -> merged into the lists; buffers emptied
-    auto flush_own = [&]() {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int qr = wave * 16 + g * 4 + (lane >> 4);
-            const int cnt = lcnt[qr];
-            const int r = lqrow[qr];
-            const float* qp = dbase + (size_t)(r >= 0 ? r : 0) * RF;
-            for (int base = 0; __any(base < cnt); base += 16) {
-                u64 ks[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = base + u * 4 + quad;
-                    const bool v = j < cnt;
-                    ks[u] = ~0ull;
-                    if (__any(v)) {   // wave-uniform: skip steps no row needs
-                        const int c = v ? (int)lbuf[qr * KS_CAP + j] : 0;
-                        const float d = quad_pair_distance<FMA>(qp, sbase + (size_t)c * RF, lane);
-                        ks[u] = make_key(d, c, v & qlast);
-                    }
-                }
-                key_cx(ks[0], ks[1]); key_cx(ks[2], ks[3]); key_cx(ks[0], ks[2]); key_cx(ks[1], ks[3]); key_cx(ks[1], ks[2]);
-                merge_keys<true>(ks[0], ks[1], ks[2], ks[3], lk[g], rkey[g], K, lane);
-            }
-            if ((lane & 15) == 0) lcnt[qr] = 0;
-        }
-        refresh_kth();
-    };
-
-    {   // seed the lists with the exact keys of the hints; remember the hint indices (they are not buffered again)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int qr = wave * 16 + g * 4 + (lane >> 4);
-            const int r = lqrow[qr];
-            const float* qp = dbase + (size_t)(r >= 0 ? r : 0) * RF;
-            const int32_t* hp = seed_idx + ((size_t)b * seed_n + (seed_by_row ? (r >= 0 ? r : 0) : min(q0 + qr, seed_n - 1))) * 16;
-            u64 ks[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = u * 4 + quad;
-                const int sidx = hp[e];
-                const bool v = r >= 0 && sidx >= 0 && sidx < Ns;
-                const int c = v ? sidx : 0;
-                const float d = quad_pair_distance<FMA>(qp, sbase + (size_t)c * RF, lane);
-                ks[u] = make_key(d, c, v & qlast);
-                if (qlast) lseedidx[qr * 16 + e] = v ? (unsigned short)c : (unsigned short)0xFFFFu;
-            }
-            key_cx(ks[0], ks[1]); key_cx(ks[2], ks[3]); key_cx(ks[0], ks[2]); key_cx(ks[1], ks[3]); key_cx(ks[1], ks[2]);
-            merge_keys<true>(ks[0], ks[1], ks[2], ks[3], lk[g], rkey[g], K, lane);
-        }
-        refresh_kth();
-    }
-
-    // loop-invariant A fragments: query row wm*32 + l31, dims k*32 + j*8 + lh*4 .. +3
+    // loop-invariant A fragments: query row wm*32 + l31, dims k*32 + j*8 + lh*4 .. +3 (padding queries: row 0, kth = -inf)
     float4 a[12];
-    float nqv[16];
-    auto load_query_frags = [&]() {   // (re)loaded after a mid-sweep flush so that nothing has to live across it
+    {
         const int r = lqrow[wm * 32 + l31];
         const float* qp = dbase + (size_t)(r >= 0 ? r : 0) * RF + lh * 4;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) a[i] = *reinterpret_cast<const float4*>(qp + i * 8);  // padding queries: row 0, kth = -inf
-#pragma unroll
-        for (int r2 = 0; r2 < 16; ++r2) nqv[r2] = lnq[wm * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * lh];
-    };
-    load_query_frags();
+        for (int i = 0; i < 12; ++i) a[i] = *reinterpret_cast<const float4*>(qp + i * 8);
+    }
 
     // chunk staging: chunk g = (tile g/3, xyz component g%3); thread -> rows sr and sr+32, float4 column sc4
     const int sr = tid >> 3, sc4 = (tid & 7) * 4;
@@ -237,13 +219,13 @@ __global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restri
         *reinterpret_cast<float4*>(&lc[buf][(sr + 32) * KS_LD + sc4]) = st1;
     };
 
-    __syncthreads();  // lkth and lseedidx visible to all waves
     gload(0, 0);
     lstore(0);
     gload(0, 1);
     __syncthreads();
 
     const int cc = wn * 32 + l31;
+    unsigned short* sv = surv + ((size_t)b * Nd + q0) * KS_CAP;
 #pragma unroll 1
     for (int t = 0; t < ntiles; ++t) {
         // candidate norm of this lane's column, consumed two chunks later (clamped: columns past Ns are masked by cvalid).
@@ -255,7 +237,7 @@ __global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restri
         for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int g = t * 3 + k, buf = (t + k) & 1;
+            const int buf = (t + k) & 1;
             const float* bp = &lc[buf][(wn * 32 + l31) * KS_LD + lh * 4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -275,7 +257,7 @@ __global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int qr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float nn = nqv[r] + nsv;
+                    const float nn = lnq[qr] + nsv;
                     const float dh = nn - 2.0f * S[r];
                     const bool pass = cvalid & !((dh - epsE * nn) > lkth[qr]);
                     mask |= pass ? (1u << r) : 0u;
@@ -284,7 +266,7 @@ __global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restri
                     const int r = __builtin_ctz(mask);
                     mask &= mask - 1;
                     const int qr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    // a hint's exact key is in the list already: do not buffer it again
+                    // a hint's exact key is in the seeded list already: do not record it again
                     const uint4 h0 = *reinterpret_cast<const uint4*>(&lseedidx[qr * 16]);
                     const uint4 h1 = *reinterpret_cast<const uint4*>(&lseedidx[qr * 16 + 8]);
                     const unsigned cg = (unsigned)cglob;
@@ -292,8 +274,7 @@ __global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restri
                     const bool hinted = has(h0.x) | has(h0.y) | has(h0.z) | has(h0.w) | has(h1.x) | has(h1.y) | has(h1.z) | has(h1.w);
                     if (!hinted) {
                         const int pos = atomicAdd(&lcnt[qr], 1);
-                        if (pos < KS_CAP) lbuf[qr * KS_CAP + pos] = (unsigned short)cglob;
-                        if (pos >= KS_CAP - KNN_TS) lflush = 1;
+                        if (pos < KS_CAP) sv[(size_t)qr * KS_CAP + pos] = (unsigned short)cglob;
                     }
                 }
             }
@@ -306,34 +287,115 @@ __global__ __launch_bounds__(256, 3) void knn_sweep_kernel(const float* __restri
             }
             __syncthreads();
         }
-        if (lflush) {   // block-uniform (read after the barrier): some buffer could overflow during the next tile
-            flush_own();
-            __syncthreads();
-            if (tid == 0) lflush = 0;
-            load_query_frags();
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): leave this rare branch with nothing in flight, so that the
-                                                 // common path keeps exact load counts at the join
-        }
     }
-    flush_own();
-    write_lists(lk, b, q0, Nd, K, wave, lane, 1, 0, nullptr, idx_out, dist_out);
+    if (tid < KNN_TQ && q0 + tid < Nd) surv_cnt[(size_t)b * Nd + q0 + tid] = lcnt[tid];   // > KS_CAP: finish by brute force
 }
 
-int knn_sweep_launch(const float* dst, const float* src, const int32_t* dst_rows, const float* nrm_dst, const float* nrm_src, int B,
-                     int Nd, int dst_n, int Ns, int C, int K, bool fma, int32_t* idx_out, float* dist_out, const int32_t* seed_idx,
-                     int seed_n, int seed_by_row, hipStream_t st) {
+// ---- 3. finish.  Same wave layout as the seed kernel; the seeded list is reloaded, survivors get canonical keys in rounds of
+// 16 per query (four quad-steps), a query flagged as overflowed scans every candidate the same way.
+template <bool FMA>
+__global__ __launch_bounds__(256, 4) void knn_finish_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+                                                            const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
+                                                            const u64* __restrict__ seedkeys, const int32_t* __restrict__ surv_cnt,
+                                                            const unsigned short* __restrict__ surv, int32_t* __restrict__ idx_out,
+                                                            float* __restrict__ dist_out, int groups_per_inst, int total_groups) {
+    constexpr int RF = 3 * KM_CC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x * 4 + wave;
+    if (wg >= total_groups) return;
+    const int b = wg / groups_per_inst, q = (wg % groups_per_inst) * 4 + (lane >> 4);
+    const float* dbase = dstf + (size_t)b * dst_n * RF;
+    const float* sbase = srcf + (size_t)b * Ns * RF;
+    const bool live = q < Nd;
+    const int r = live ? (dst_rows ? dst_rows[(size_t)b * Nd + q] : q) : -1;
+    const int quad = (lane >> 2) & 3, e16 = lane & 15;
+    const bool qlast = (lane & 3) == 3;
+    const size_t qg = (size_t)b * Nd + (live ? q : 0);
+    // the seeded list, truncated to K entries (entry e in lane e of the row)
+    u64 lk = (live && e16 < K) ? seedkeys[qg * 16 + e16] : ~0ull;
+    u64 rkey = bperm64((lane & 48) + K - 1, lk);
+    int cnt = live ? surv_cnt[qg] : 0;
+    const bool brute = cnt > KS_CAP;
+    if (brute) cnt = Ns;
+    const unsigned short* sp = surv + qg * KS_CAP;
+    QuadRow qv;
+    qv.load(dbase + (size_t)max(r, 0) * RF, lane);
+    for (int base = 0; __any(base < cnt); base += 16) {
+        u64 ks[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = base + u * 4 + quad;
+            const bool v = j < cnt;
+            if (__any(v)) {   // wave-uniform: skip the steps no row of the wave needs
+                const int c = v ? (brute ? j : (int)sp[j]) : 0;
+                QuadRow cv;
+                cv.load(sbase + (size_t)c * RF, lane);
+                ks[u] = make_key(quad_pair_distance<FMA>(qv, cv), c, v & qlast);
+            }
+        }
+        key_cx(ks[0], ks[1]); key_cx(ks[2], ks[3]); key_cx(ks[0], ks[2]); key_cx(ks[1], ks[3]); key_cx(ks[1], ks[2]);
+        merge_keys<true>(ks[0], ks[1], ks[2], ks[3], lk, rkey, K, lane);
+    }
+    if (live && e16 < K) {
+        const size_t o = qg * K + e16;
+        const unsigned hi = (unsigned)(lk >> 32), lo = (unsigned)lk;
+        idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lo;
+        if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
+    }
+}
+
+size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns) {
+    const size_t nq = (size_t)B * Nd;
+    return ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256      // row norms
+           + nq * 16 * sizeof(u64) + nq * sizeof(int32_t) + nq * KS_CAP * sizeof(unsigned short) + 256;
+}
+
+int knn_sweep_launch(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K,
+                     bool fma, int32_t* idx_out, float* dist_out, const int32_t* seed_idx, int seed_n, int seed_by_row, void* scratch,
+                     hipStream_t st) {
     LS_REQUIRE(C == KM_CC, "knn_sweep: only C == 32 layers are supported (C=%d)", C);
     LS_REQUIRE(seed_idx != nullptr, "knn_sweep: needs seed lists");
     LS_REQUIRE(Ns <= 65535, "knn_sweep: Ns=%d exceeds the 16-bit survivor index", Ns);
+    const size_t nq = (size_t)B * Nd;
+    char* sc = (char*)scratch;
+    float* nsrc = (float*)sc;
+    float* ndst = nsrc;
+    size_t off = (size_t)B * Ns * sizeof(float);
+    int rc = row_norms_launch(src, 3 * C, (long long)B * Ns, nsrc, st);
+    if (rc != LS_OK) return rc;
+    if (dst != src) {
+        ndst = (float*)(sc + off);
+        rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
+        if (rc != LS_OK) return rc;
+    }
+    off += (size_t)B * dst_n * sizeof(float);
+    off = (off + 255) & ~(size_t)255;
+    u64* seedkeys = (u64*)(sc + off);
+    off += nq * 16 * sizeof(u64);
+    int32_t* surv_cnt = (int32_t*)(sc + off);
+    off += nq * sizeof(int32_t);
+    unsigned short* surv = (unsigned short*)(sc + off);
+
+    const int groups = cdiv(Nd, 4);                 // one wave per four queries
+    const int gblocks = cdiv((long long)B * groups, 4);
     const int qtiles = cdiv(Nd, KNN_TQ);
     const float epsE = 6.0f * (float)(3 * C + 4) * 5.9604645e-8f;
-    dim3 grid(B * qtiles), block(256);
     if (fma)
-        hipLaunchKernelGGL(knn_sweep_kernel<true>, grid, block, 0, st, dst, src, dst_rows, nrm_dst, nrm_src, Nd, dst_n, Ns, K, idx_out,
-                           dist_out, qtiles, epsE, seed_idx, seed_n, seed_by_row);
+        hipLaunchKernelGGL(knn_seed_kernel<true>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
+                           seed_by_row, seedkeys, groups, B * groups);
     else
-        hipLaunchKernelGGL(knn_sweep_kernel<false>, grid, block, 0, st, dst, src, dst_rows, nrm_dst, nrm_src, Nd, dst_n, Ns, K, idx_out,
-                           dist_out, qtiles, epsE, seed_idx, seed_n, seed_by_row);
+        hipLaunchKernelGGL(knn_seed_kernel<false>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
+                           seed_by_row, seedkeys, groups, B * groups);
+    LS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_sweep_kernel, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles, epsE,
+                       seedkeys, surv_cnt, surv);
+    LS_LAUNCH_CHECK();
+    if (fma)
+        hipLaunchKernelGGL(knn_finish_kernel<true>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seedkeys, surv_cnt,
+                           surv, idx_out, dist_out, groups, B * groups);
+    else
+        hipLaunchKernelGGL(knn_finish_kernel<false>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seedkeys, surv_cnt,
+                           surv, idx_out, dist_out, groups, B * groups);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

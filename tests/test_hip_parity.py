@@ -100,7 +100,7 @@ def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
             assert np.array_equal(i3.cpu().numpy(), r2) and np.array_equal(d3.cpu().numpy(), d2), (name, fl)
 
 
-@pytest.mark.parametrize("shape", [(2, 200, 200, 32), (3, 70, 330, 64), (40, 256, 1024, 32)])
+@pytest.mark.parametrize("shape", [(2, 200, 200, 32), (3, 70, 330, 64), (40, 256, 1024, 32), (3, 70, 330, 32), (1, 33, 100, 32)])
 def test_knn_hints_do_not_change_the_result(shape):
     """seed_idx are HINTS: exact neighbours, random indices, duplicates of each other's ranges, -1 and out-of-range values
     must all yield the oracle's answer bit for bit (also through the candidate-split + merge path)."""
