@@ -21,12 +21,47 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 
+// Write one wave's staged 32x64 half-tile (LDS rows of 68 floats) to out[gm0.., gn0..].  Interior tiles (the common case)
+// take the predicate-free path: all eight LDS reads in flight, then eight 16-byte stores per lane (each store = four
+// 256-byte row segments per wave); per-element branches around the LDS read -> store pairs cost 12 % on the K <= 64 GEMMs.
+__device__ __forceinline__ void store_half_tile(const float* stg, float* __restrict__ out, int ldc, int M, int N, int gm0, int gn0,
+                                                int lane, bool full_tile, bool vec_ok) {
+    if (full_tile) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(&stg[(u * 4 + (lane >> 4)) * 68 + (lane & 15) * 4]);
+        float* op = out + (size_t)(gm0 + (lane >> 4)) * ldc + gn0 + (lane & 15) * 4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(op + (size_t)(u * 4) * ldc) = v[u];
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx = u * 64 + lane;           // 32 rows x 16 float4
+        const int rr = idx >> 4, c4 = (idx & 15) * 4;
+        const int gm = gm0 + rr, gn = gn0 + c4;
+        if (gm < M && gn < N) {
+            const float4 v = *reinterpret_cast<const float4*>(&stg[rr * 68 + c4]);
+            float* op = out + (size_t)gm * ldc + gn;
+            if (vec_ok && gn + 3 < N) {
+                *reinterpret_cast<float4*>(op) = v;
+            } else {
+                op[0] = v.x;
+                if (gn + 1 < N) op[1] = v.y;
+                if (gn + 2 < N) op[2] = v.z;
+                if (gn + 3 < N) op[3] = v.w;
+            }
+        }
+    }
+}
+
 // Optional row gather (down-sampled encoder layers): output row m = (b*gNd + n)*3 + x reads A row
 // (b*gNs + a_rows[b*gNd + n])*3 + x, i.e. the GEMM runs only on the FPS-selected points of each instance.
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
                                                        int ldc, int M, int N, int K, int relu, int ntiles_n,
-                                                       const int32_t* __restrict__ a_rows, int gNd, int gNs) {
+                                                       const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk,
+                                                       size_t slab_stride) {
     constexpr int STG = 32 * 68;  // epilogue staging: 32 rows x (64 + 4) floats per wave
     __shared__ __attribute__((aligned(16))) float smem[(4 * STG > (GM + GN) * GLD) ? 4 * STG : (GM + GN) * GLD];
     float* As = smem;
@@ -37,6 +72,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int tm = logical / ntiles_n, tn = logical % ntiles_n;
     const int m0 = tm * GM, n0 = tn * GN;
     const int wm = wave >> 1, wn = wave & 1;
+    // split-K (blockIdx.y = slice): this workgroup covers k in [kbeg, kend) and writes an un-activated partial slab
+    const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+    out += (size_t)blockIdx.y * slab_stride;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -66,8 +104,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int h = 0; h < 2; ++h) {
             const int r = sr0 + h * 64;
             const int gn = n0 + r, gk = k0 + sk;
-            ra[h] = (arow[h] >= 0 && gk < K) ? *reinterpret_cast<const float4*>(A + (size_t)arow[h] * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[h] = (gn < N && gk < K) ? *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[h] = (arow[h] >= 0 && gk < kend) ? *reinterpret_cast<const float4*>(A + (size_t)arow[h] * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[h] = (gn < N && gk < kend) ? *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&]() {
@@ -79,12 +117,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
     };
 
-    gload(0);
-    for (int k0 = 0; k0 < K; k0 += GK) {
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
         __syncthreads();
         lstore();
         __syncthreads();
-        if (k0 + GK < K) gload(k0 + GK);  // in flight under the MFMA block
+        if (k0 + GK < kend) gload(k0 + GK);  // in flight under the MFMA block
         const int lr = lane & 31, lk = (lane >> 5) * 4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -114,6 +152,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     float* stg = smem + wave * STG;  // 8.7 KB per wave
     const int col_l = lane & 31, rowh = (lane >> 5) * 4;
     const bool vec_ok = (ldc % 4 == 0) && (((uintptr_t)out & 15) == 0);
+    const bool full_tile = vec_ok && (m0 + GM <= M) && (n0 + GN <= N);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -130,45 +169,219 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         // wave-local hand-off through LDS: same wave writes and reads, LDS ops of a wave complete in order
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = u * 64 + lane;           // 32 rows x 16 float4
-            const int rr = idx >> 4, c4 = (idx & 15) * 4;
-            const int gm = m0 + wm * 64 + i * 32 + rr;
-            const int gn = n0 + wn * 64 + c4;
-            if (gm < M && gn < N) {
-                const float4 v = *reinterpret_cast<const float4*>(&stg[rr * 68 + c4]);
-                float* op = out + (size_t)gm * ldc + gn;
-                if (vec_ok && gn + 3 < N) {
-                    *reinterpret_cast<float4*>(op) = v;
-                } else {
-                    op[0] = v.x;
-                    if (gn + 1 < N) op[1] = v.y;
-                    if (gn + 2 < N) op[2] = v.z;
-                    if (gn + 3 < N) op[3] = v.w;
-                }
-            }
-        }
+        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-int gemm_dispatch_gather(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
-                         int K, int relu, const int32_t* a_rows, int gNd, int gNs, hipStream_t st);
-int gemm_dispatch(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
-                  int K, int relu, hipStream_t st) {
-    return gemm_dispatch_gather(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, st);
+// ---------------------------------------------------------------------------------------------------------------------
+// K = 32: the per-point table GEMMs of encoder layers 1-2 (M = B*N*3 up to 196 608 rows, N = 128..384 columns).
+// With two to four k-steps per 128x128 tile the kernel above is all prologue and epilogue: measured per workgroup (K = 64)
+// 6.6 k cycles waiting for the first operand tile + 21.6 k in the k-loop (8.2 k of MFMA) + 21 k issuing the stores, with
+// nothing of one tile overlapping anything of the next.  Here a workgroup is PERSISTENT over the M-tiles of one N-tile:
+// the W tile (128 x K) is staged once, the whole-K A tile of M-tile t+1 is in flight (registers) under the MFMA block and
+// the stores of tile t, one barrier pair per tile, and the staging area of the epilogue aliases the A buffer.
+// whole-K A tile of M-tile TM into registers ra0..ra7: thread -> rows TM*128 + srow + u*RSTEP, 16 bytes at column scol.  Rows
+// past M are clamped (computed, never stored); GATHER maps output row (b*gNd + n)*3 + x to source row
+// (b*gNs + a_rows[b*gNd + n])*3 + x.  Named scalars, not an array: hipcc kept a 16-/32-float prefetch ARRAY in scratch memory
+// (it is written in one loop iteration and read in the next; promote-alloca gave up on it).
+#define LS_LOAD_A1(RA, U, TM)                                                               \
+    {                                                                                       \
+        const int gm = min((TM) * GM + srow + (U) * RSTEP, M - 1);                          \
+        size_t r_ = (size_t)gm;                                                             \
+        if constexpr (GATHER) {                                                             \
+            const int pt = gm / 3, x = gm - pt * 3, bb = pt / gNd;                          \
+            r_ = ((size_t)bb * gNs + a_rows[pt]) * 3 + x;                                   \
+        }                                                                                   \
+        RA = *reinterpret_cast<const float4*>(A + r_ * lda + scol);                         \
+    }
+#define LS_LOAD_A_TILE(TM)                                                                  \
+    {                                                                                       \
+        LS_LOAD_A1(ra0, 0, TM) LS_LOAD_A1(ra1, 1, TM) LS_LOAD_A1(ra2, 2, TM) LS_LOAD_A1(ra3, 3, TM) \
+        if constexpr (PER == 8) { LS_LOAD_A1(ra4, 4, TM) LS_LOAD_A1(ra5, 5, TM) LS_LOAD_A1(ra6, 6, TM) LS_LOAD_A1(ra7, 7, TM) } \
+    }
+#define LS_STORE_A1(RA, U) *reinterpret_cast<float4*>(&As[(srow + (U) * RSTEP) * LD + scol]) = RA;
+
+template <int KK, bool GATHER>
+__global__ __launch_bounds__(256) void gemm_smallk_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldc, int M,
+                                                          int N, int relu, int ntiles_m, int per_n,
+                                                          const int32_t* __restrict__ a_rows, int gNd, int gNs) {
+    constexpr int LD = KK + 4;                       // 36 / 68 floats: odd multiple of 16 bytes -> conflict-free ds_read_b128
+    constexpr int STG = 32 * 68;
+    constexpr int AS_FLOATS = (GM * LD > 4 * STG) ? GM * LD : 4 * STG;
+    constexpr int F4_ROW = KK / 4;                   // float4 per operand row
+    constexpr int PER = GM * F4_ROW / 256;           // float4 per thread per operand tile (4 / 8)
+    __shared__ __attribute__((aligned(16))) float smem[AS_FLOATS + GN * LD];
+    float* As = smem;                                // A tile, then the epilogue staging area
+    float* Bs = smem + AS_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tn = blockIdx.x / per_n, slot = blockIdx.x % per_n;   // N-tile, and which M-tiles (slot, slot + per_n, ...)
+    const int n0 = tn * GN;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lk = (lane >> 5) * 4;
+    const int srow = tid / F4_ROW, scol = (tid % F4_ROW) * 4;       // staging: rows srow + (256 / F4_ROW) u
+    constexpr int RSTEP = 256 / F4_ROW;
+    const bool vec_ok = (ldc % 4 == 0) && (((uintptr_t)out & 15) == 0);
+
+    // W tile once
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int r = srow + u * RSTEP, gn = n0 + r;
+        // columns past N: clamped row, computed and never stored (a conditional load would be turned into a pointer select
+        // through scratch memory by the compiler)
+        *reinterpret_cast<float4*>(&Bs[r * LD + scol]) = *reinterpret_cast<const float4*>(W + (size_t)min(gn, N - 1) * ldw + scol);
+    }
+    float bv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gn = n0 + wn * 64 + j * 32 + lr;
+        bv[j] = (bias && gn < N) ? bias[gn] : 0.0f;
+    }
+
+    float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7;
+    ra4 = ra5 = ra6 = ra7 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int tm = slot;
+    LS_LOAD_A_TILE(min(tm, ntiles_m - 1))
+    for (; tm < ntiles_m; tm += per_n) {
+        const int m0 = tm * GM;
+        __syncthreads();                               // previous tile's staging reads are done (and Bs is written)
+        LS_STORE_A1(ra0, 0) LS_STORE_A1(ra1, 1) LS_STORE_A1(ra2, 2) LS_STORE_A1(ra3, 3)
+        if constexpr (PER == 8) { LS_STORE_A1(ra4, 4) LS_STORE_A1(ra5, 5) LS_STORE_A1(ra6, 6) LS_STORE_A1(ra7, 7) }
+        __syncthreads();
+        // next A tile in flight under the MFMA block and the stores
+        // (unconditional: the last iteration re-reads its own tile rather than branching around the loads)
+        LS_LOAD_A_TILE(min(tm + per_n, ntiles_m - 1))
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+        for (int h = 0; h < KK / 8; ++h) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + lr) * LD + h * 8 + lk]);
+                b[i] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + i * 32 + lr) * LD + h * 8 + lk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();                               // every wave is done with As: it becomes the staging area
+        float* stg = As + wave * STG;
+        const int col_l = lane & 31, rowh = (lane >> 5) * 4;
+        const bool full_tile = vec_ok && (m0 + GM <= M) && (n0 + GN <= N);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bv[j];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
-int gemm_dispatch_gather(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
-                         int K, int relu, const int32_t* a_rows, int gNd, int gNs, hipStream_t st) {
+
+// split-K combine: out[m][n] = act(sum_s slab[s][m][n] + bias[n]), slices summed in ascending order (deterministic)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nsplit,
+                                                                const float* __restrict__ bias, float* __restrict__ out, int ldc,
+                                                                int M, int N, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one float4 of a row (N is a multiple of 4 here)
+    const int n4 = N / 4;
+    if (i >= (long long)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    float4 a = *reinterpret_cast<const float4*>(slabs + (size_t)m * N + n);
+    for (int s2 = 1; s2 < nsplit; ++s2) {
+        const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)s2 * slab_stride + (size_t)m * N + n);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (bias) { a.x += bias[n]; a.y += bias[n + 1]; a.z += bias[n + 2]; a.w += bias[n + 3]; }
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    float* op = out + (size_t)m * ldc + n;
+    op[0] = a.x; op[1] = a.y; op[2] = a.z; op[3] = a.w;
+}
+
+// Under-filled grids with a long K loop (the per-instance "mean" rows of the residual global conv: M = 3B rows against
+// K = C up to 512; conv_c) are pure latency: 32 workgroups x 16 dependent k-steps = 44 us for 0.2 GFLOP.  They are split
+// along K into slices written as partial slabs and combined by a second launch.
+static int gemm_choose_splits(int M, int N, int K) {
+    const int tiles = cdiv(M, GM) * cdiv(N, GN);
+    if (tiles >= 192 || K < 128 || N % 4 != 0) return 1;
+    int s2 = 512 / tiles;
+    if (s2 > K / 32) s2 = K / 32;
+    return s2 < 2 ? 1 : s2;
+}
+size_t gemm_scratch_floats(int M, int N, int K) {
+    const int s2 = gemm_choose_splits(M, N, K);
+    return s2 > 1 ? (size_t)s2 * M * N : 0;
+}
+
+int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
+                       int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st) {
     LS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem (M=%d N=%d K=%d)", M, N, K);
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
     const int tm = cdiv(M, GM), tn = cdiv(N, GN);
+    if (K == 32 && tm >= 16) {
+        // persistent small-K kernel: ~3 resident workgroups per CU, spread evenly over the N-tiles.  (The K = 64 instantiation
+        // needs 70 KB of LDS -> 2 workgroups per CU and measured SLOWER than the tiled kernel: 138 vs 110 us at the layer-3 shape.)
+        int per_n = cdiv(768, tn);
+        if (per_n > tm) per_n = tm;
+#define LS_SMALLK(KK, G)                                                                                                          \
+    hipLaunchKernelGGL((gemm_smallk_kernel<KK, G>), dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, relu, tm, \
+                       per_n, a_rows, gNd, gNs)
+        if (a_rows) LS_SMALLK(32, true); else LS_SMALLK(32, false);
+#undef LS_SMALLK
+        LS_LAUNCH_CHECK();
+        return LS_OK;
+    }
+    const int nsplit = scratch ? gemm_choose_splits(M, N, K) : 1;
+    if (nsplit > 1) {
+        int kchunk = cdiv(cdiv(K, nsplit), GK) * GK;
+        const int ns = cdiv(K, kchunk);
+        const size_t slab = (size_t)M * N;
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn, a_rows,
+                           gNd, gNs, kchunk, slab);
+        LS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv((long long)M * (N / 4), 256)), dim3(256), 0, st, scratch, slab, ns, bias, out,
+                           ldc, M, N, relu);
+        LS_LAUNCH_CHECK();
+        return LS_OK;
+    }
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                       gNd, gNs);
+                       gNd, gNs, K, (size_t)0);
     LS_LAUNCH_CHECK();
     return LS_OK;
+}
+int gemm_dispatch_gather(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
+                         int K, int relu, const int32_t* a_rows, int gNd, int gNs, hipStream_t st) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, a_rows, gNd, gNs, nullptr, st);
+}
+int gemm_dispatch(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
+                  int K, int relu, hipStream_t st) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, nullptr, st);
+}
+int gemm_dispatch_ws(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
+                     int K, int relu, float* scratch, hipStream_t st) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, scratch, st);
 }
 
 }  // namespace ls

@@ -28,6 +28,8 @@ int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, fl
 int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
 int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
 int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t);
+int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
+size_t gemm_scratch_floats(int M, int N, int K);
 int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipStream_t);
 size_t prologue_scratch_floats(int B);
 int transpose_cloud_launch(const float*, int, int, float*, hipStream_t);
@@ -100,7 +102,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -109,7 +111,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     int cur = N;
     p.nlevels = 0;
     p.levelN[0] = N;
-    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0, maxKs = 0;
+    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0, maxKs = 0, maxGws = 0;
     for (int i = 0; i < p.L; ++i) {
         p.Ns[i] = cur;
         const int f = d.down_factor[i] > 1 ? d.down_factor[i] : 1;
@@ -137,6 +139,8 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         }
         maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
         maxC = std::max(maxC, (size_t)p.Co[i]);
+        // split-K slabs of the under-filled GEMMs (residual global conv: per-point part and per-instance mean part)
+        maxGws = std::max(maxGws, std::max(gemm_scratch_floats(B * p.Nd[i] * 3, 2 * p.Co[i], p.Co[i]), gemm_scratch_floats(B * 3, 4 * p.Co[i], p.Co[i])));
         maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
         maxKs = std::max(maxKs, std::max(knn_scratch_bytes(B, p.Nd[i], p.Ns[i], p.Ns[i], p.Cin[i], true, 0u),
                                         knn_scratch_bytes(B, p.Nd[i], p.Ns[i], p.Ns[i], p.Cin[i], false, 0u)));
@@ -165,6 +169,8 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_g = take((size_t)B * 3 * maxC * 4);
     p.o_G = take((size_t)B * 3 * 4 * maxC * 4);
     p.o_Tc = take((size_t)B * p.NP * 3 * p.Cdp * 4);
+    maxGws = std::max(maxGws, gemm_scratch_floats(B * p.NP * 3, p.Cdp, p.Co[p.L - 1]));
+    p.o_gws = take(maxGws * 4 + 256);
     p.total = off;
     return LS_OK;
 }
@@ -201,7 +207,13 @@ int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, un
 }
 int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
                 int relu, void* stream) {
-    return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream);
+    const size_t sf = (M > 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0) ? gemm_scratch_floats(M, N, K) : 0;
+    if (!sf) return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream);
+    float* scratch = nullptr;   // split-K slabs of an under-filled, long-K problem
+    LS_HIP_CHECK(hipMallocAsync((void**)&scratch, sf * sizeof(float), (hipStream_t)stream));
+    const int rc = gemm_dispatch_ws(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, scratch, (hipStream_t)stream);
+    LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
+    return rc;
 }
 int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out, void* stream) {
     LS_REQUIRE(B > 0, "prologue: empty batch");
@@ -404,8 +416,8 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             if (rc != LS_OK) return rc;
             {
                 PROF(LS_K_GEMM_GLOB, i, st);
-                rc = gemm_dispatch(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, st);
-                if (rc == LS_OK) rc = gemm_dispatch(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, st);
+                rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, F(p.o_gws), st);
+                if (rc == LS_OK) rc = gemm_dispatch_ws(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, F(p.o_gws), st);
             }
             if (rc != LS_OK) return rc;
             { PROF(LS_K_VN_ACT, i, st); rc = vn_act_rows_launch(TG, 2 * Co, G, 4 * Co, B, Nd, Co, d.neg_slope, nxt, st); }
@@ -419,7 +431,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     // ---- tail
     const int Cl = p.Co[p.L - 1];
     float* Tc = F(p.o_Tc);
-    { PROF(LS_K_GEMM_TAIL, 0, st); rc = gemm_dispatch(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, p.Cdp, B * p.NP * 3, p.Cdp, Cl, 0, st); }
+    { PROF(LS_K_GEMM_TAIL, 0, st); rc = gemm_dispatch_ws(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, p.Cdp, B * p.NP * 3, p.Cdp, Cl, 0, F(p.o_gws), st); }
     if (rc != LS_OK) return rc;
     PROF(LS_K_TAIL, 0, st);
     rc = tail_launch(Tc, p.Cdp, B, p.NP, d.c_dim, W + d.off_inv_t, W + d.off_c_fc0_t, W + d.off_c_misc, d.neg_slope,

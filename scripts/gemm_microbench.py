@@ -1,0 +1,21 @@
+"""fp32-MFMA GEMM micro-benchmark at the encoder's table-GEMM shapes (out[M,N] = A[M,K] W[N,K]^T)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from livingscenes_amd import ops
+dev = torch.device("cuda:0")
+shapes = [("L1 table", 196608, 128, 32), ("L2 P", 196608, 256, 32), ("L2 Q", 98304, 384, 32), ("L3 table", 98304, 640, 64),
+          ("L4 P", 98304, 512, 64), ("L4 Q", 24576, 768, 64), ("L5 P", 24576, 1024, 128), ("L5 Q", 6144, 1536, 128),
+          ("L6 table", 6144, 5120, 256), ("glob6", 6144, 1024, 512), ("mean-part 6", 192, 1024, 512), ("decoder", 262144, 768, 768)]
+if len(sys.argv) > 1: shapes = [s for s in shapes if sys.argv[1] in s[0]]
+for name, M, N, K in shapes:
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
+    for _ in range(3): ops.gemm(A, W)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): ops.gemm(A, W)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    wr = M * N * 4 / ms / 1e9; fl = 2.0 * M * N * K / ms / 1e9
+    print(f"{name:12s} M={M:7d} N={N:5d} K={K:4d}: {ms*1e3:8.1f} us   write {wr:6.2f} TB/s   {fl:6.1f} TFLOP/s")
