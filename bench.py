@@ -106,7 +106,7 @@ def algorithmic_cost(kind, layer, cfg, B, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="instances per step per GPU (two scenes of batch/2 objects)")
     ap.add_argument("--points", type=int, default=1024)
@@ -116,7 +116,7 @@ def main():
                          "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; scripts/cpu_threads_probe.py)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fma-variant", action="store_true", help="skip the secondary fused-multiply-add k-NN timing")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent steps kept in flight on separate HIP streams (each with its own model handle and "
                          "workspace): one step's low-occupancy kernels (FPS, heads, matcher) overlap another's big ones")
     args = ap.parse_args()
