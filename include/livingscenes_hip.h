@@ -185,6 +185,29 @@ int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const f
                   const float* t, int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SURVEY.md 8 (f-2), first half: the MISE octree that decides WHICH lattice points of the (R+1)^3 grid the decoder has to
+ * evaluate (R = resolution_0 << depth) and assembles the dense value grid -- class MISE of
+ * occnet_utils/utils/libmise/mise.pyx, driven by the loop of occnet_utils/mesh_extractor2.py:116-131:
+ *     init;  loop { query -> n points; if n == 0 break; values = decoder(points); update(points, values) };  to_dense
+ * `state` is caller-allocated device memory of ls_mise_state_bytes(); lattice index = (x*(R+1) + y)*(R+1) + z.
+ * Marching cubes (libmcubes) is not part of this library yet.
+ * ---------------------------------------------------------------------------------------------- */
+size_t ls_mise_state_bytes(int resolution_0, int depth);
+long long ls_mise_lattice_points(int resolution_0, int depth);   /* (R+1)^3: upper bound for a query */
+/* MISE.__cinit__, mise.pyx:43-85 */
+int ls_mise_init(void* state, size_t state_bytes, int resolution_0, int depth, void* stream);
+/* MISE.query, mise.pyx:104-126 (+ the coordinate normalisation of mesh_extractor2.py:122-124, box_size = 1 + padding):
+ * unknown points in ascending lattice order -> idx_out [cap] int32, pts_out [cap,3]; *count_out (DEVICE int32) = number of
+ * unknown points (nothing is written past cap). */
+int ls_mise_query(void* state, int resolution_0, int depth, float box_size, int32_t* idx_out, float* pts_out, int cap,
+                  int32_t* count_out, void* stream);
+/* MISE.update, mise.pyx:87-102 + subdivide_voxels :188-236; threshold = logit of the occupancy threshold (double, as the reference) */
+int ls_mise_update(void* state, int resolution_0, int depth, double threshold, const int32_t* idx, const float* values, int n,
+                   void* stream);
+/* MISE.to_dense, mise.pyx:128-165 -> grid_out [(R+1)^3] float32 (the reference's float64 grid holds float32 values) */
+int ls_mise_to_dense(void* state, int resolution_0, int depth, float* grid_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Live per-kernel timing (bench.py's roofline leg): while enabled, every kernel ls_encode / ls_sdf_decode
  * launches is bracketed by hipEvents on the stream it is launched on.  ls_profile_end synchronises those
  * streams and returns, per (kind, layer), the number of launches and their summed duration.

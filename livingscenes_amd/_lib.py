@@ -88,6 +88,12 @@ SIGNATURES = {
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ls_sdf_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_sdf_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "ls_mise_state_bytes": (_SZ, [_I, _I]),
+    "ls_mise_lattice_points": (ctypes.c_longlong, [_I, _I]),
+    "ls_mise_init": (_I, [_P, _SZ, _I, _I, _P]),
+    "ls_mise_query": (_I, [_P, _I, _I, _F, _P, _P, _I, _P, _P]),
+    "ls_mise_update": (_I, [_P, _I, _I, ctypes.c_double, _P, _P, _I, _P]),
+    "ls_mise_to_dense": (_I, [_P, _I, _I, _P, _P]),
     "ls_profile_begin": (_I, [_P]),
     "ls_profile_end": (_I, [_P, ctypes.POINTER(ProfileEntry), _I, ctypes.POINTER(ctypes.c_int)]),
 }

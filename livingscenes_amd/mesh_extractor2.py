@@ -1,0 +1,124 @@
+"""Mirror of the reference's ``occnet_utils/mesh_extractor2.py`` up to the dense value grid (first half).
+
+``MISE`` mirrors ``libmise.MISE`` (query / update / to_dense, mise.pyx) with the octree state resident in HBM
+(csrc/mise.hip); ``Generator3D.eval_grid`` is the loop of ``__generate_from_latent__`` (mesh_extractor2.py:94-131): per
+round the unknown lattice points go straight from the MISE kernels into ``ls_sdf_decode`` and back -- no host round trip
+except the 4-byte point count.  Marching cubes (libmcubes) is not implemented yet: ``extract_mesh`` raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import check, load, ptr, stream_ptr
+
+
+class MISE:
+    """libmise.MISE(resolution_0, depth, threshold) on the device.  Points are lattice coordinates [n,3] int64, as in the
+    reference; ``query_device`` / ``update_device`` are the zero-copy forms used by Generator3D."""
+
+    def __init__(self, resolution_0, depth, threshold, device="cuda"):
+        self.resolution_0, self.depth, self.threshold = int(resolution_0), int(depth), float(threshold)
+        self.resolution = self.resolution_0 << self.depth
+        self.device = torch.device(device)
+        nbytes = load().ls_mise_state_bytes(self.resolution_0, self.depth)
+        if nbytes == 0:
+            raise ValueError(f"MISE: resolution_0={resolution_0} depth={depth} unsupported")
+        self._state = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._cap = int(load().ls_mise_lattice_points(self.resolution_0, self.depth))
+        self._idx = torch.empty(self._cap, dtype=torch.int32, device=self.device)
+        self._pts = torch.empty(self._cap, 3, dtype=torch.float32, device=self.device)
+        check(load().ls_mise_init(ptr(self._state), nbytes, self.resolution_0, self.depth, stream_ptr(self.device)), "ls_mise_init")
+
+    def query_device(self, box_size=1.0):
+        """-> (idx [n] int32 lattice indices, pts [n,3] float32 = box_size * (p / resolution - 0.5)), device tensors (views)."""
+        check(load().ls_mise_query(ptr(self._state), self.resolution_0, self.depth, float(box_size), ptr(self._idx), ptr(self._pts),
+                                   self._cap, ptr(self._count), stream_ptr(self.device)), "ls_mise_query")
+        n = int(self._count.item())   # the only host round trip of a round
+        return self._idx[:n], self._pts[:n]
+
+    def update_device(self, idx, values):
+        values = values.to(torch.float32).contiguous()
+        idx = idx.to(torch.int32).contiguous()
+        assert idx.shape[0] == values.shape[0]
+        check(load().ls_mise_update(ptr(self._state), self.resolution_0, self.depth, ctypes.c_double(self.threshold), ptr(idx),
+                                    ptr(values), int(idx.shape[0]), stream_ptr(self.device)), "ls_mise_update")
+
+    # ---- the reference's host-side surface (mise.pyx:87-165)
+    def query(self):
+        idx, _ = self.query_device()
+        G = self.resolution + 1
+        i = idx.long().cpu().numpy()
+        return np.stack([i // (G * G), (i // G) % G, i % G], 1).astype(np.int64)
+
+    def update(self, points, values):
+        points = np.asarray(points, np.int64)
+        G = self.resolution + 1
+        idx = torch.from_numpy(((points[:, 0] * G + points[:, 1]) * G + points[:, 2]).astype(np.int32)).to(self.device)
+        self.update_device(idx, torch.as_tensor(np.asarray(values, np.float32)).to(self.device))
+
+    def to_dense_device(self):
+        G = self.resolution + 1
+        out = torch.empty(G, G, G, dtype=torch.float32, device=self.device)
+        check(load().ls_mise_to_dense(ptr(self._state), self.resolution_0, self.depth, ptr(out), stream_ptr(self.device)), "ls_mise_to_dense")
+        return out
+
+    def to_dense(self):
+        return self.to_dense_device().cpu().numpy().astype(np.float64)
+
+
+class Generator3D:
+    """mesh_extractor2.py:17-58 (constructor arguments kept); ``eval_grid`` = everything of ``__generate_from_latent__`` before
+    ``extract_mesh``."""
+
+    def __init__(self, points_batch_size=100000, threshold=0.5, refinement_step=0, resolution0=16, upsampling_steps=3,
+                 with_normals=False, padding=0.1, sample=False, simplify_nfaces=None):
+        self.implicit_F = None
+        self.device = "cuda"
+        self.points_batch_size = points_batch_size
+        self.refinement_step = refinement_step
+        self.threshold = threshold
+        self.resolution0 = resolution0
+        self.upsampling_steps = upsampling_steps
+        self.with_normals = with_normals
+        self.padding = padding
+        self.sample = sample
+        self.simplify_nfaces = simplify_nfaces
+
+    def eval_points(self, p, z, c=None, **kwargs):
+        """mesh_extractor2.py:136-159: logits at points p [n,3] (device tensor), in chunks of points_batch_size."""
+        outs = []
+        for pi in torch.split(p, self.points_batch_size):
+            with torch.no_grad():
+                outs.append(self.implicit_F(pi.unsqueeze(0), z, c, **kwargs).logits.squeeze(0))
+        return torch.cat(outs, 0) if outs else p.new_zeros(0)
+
+    def eval_grid(self, c, F, stats_dict=None, **kwargs):
+        """-> value grid float64 [(R+1)^3] as numpy (what the reference hands to marching cubes), R = resolution0 << steps."""
+        self.implicit_F = F
+        z = torch.zeros(1, 0, device=self.device)
+        threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
+        box_size = 1 + self.padding
+        if self.upsampling_steps == 0:
+            nx = self.resolution0
+            lin = torch.linspace(-0.5, 0.5, nx, device=self.device)
+            g = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)   # make_3d_grid, common.py:157
+            return self.eval_points(box_size * g, z, c, **kwargs).reshape(nx, nx, nx).cpu().numpy().astype(np.float64)
+        mise = MISE(self.resolution0, self.upsampling_steps, threshold, device=self.device)
+        rounds = []
+        idx, pts = mise.query_device(box_size)
+        while idx.shape[0] != 0:
+            rounds.append(int(idx.shape[0]))
+            mise.update_device(idx, self.eval_points(pts, z, c, **kwargs))
+            idx, pts = mise.query_device(box_size)
+        if stats_dict is not None:
+            stats_dict["mise rounds"] = rounds
+        return mise.to_dense()
+
+    def generate_from_latent(self, c, F, **kwargs):
+        return self.extract_mesh(self.eval_grid(c, F, **kwargs), None, c)
+
+    def extract_mesh(self, occ_hat, z, c=None, stats_dict=None):
+        raise NotImplementedError("marching cubes (libmcubes) is the second half of the SURVEY.md 8(f-2) 'next' row; "
+                                  "Generator3D.eval_grid returns the dense value grid it would consume")

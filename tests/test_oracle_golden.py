@@ -127,3 +127,25 @@ def test_registration(golden):
     close(more.se3_concatenate(T1, T2), g["se3_cat"], 1e-6, "concatenate")
     close(more.se3_transform(T1, x1), g["se3_tf"], 1e-6, "transform")
     close(more.compute_transformation_error(x1[:1], x2[:1], T1[:1], T2[:1]), g["rmse"], 1e-6, "rmse")
+
+
+def test_mise_oracle_matches_reference_golden():
+    """oracle/mise.py (dense restatement of libmise.MISE) vs the reference's own Cython MISE (tests/golden/mise.npz, generated by
+    tests/golden/make_golden_mise.py): identical query SETS in every round, identical dense grid."""
+    import os
+    from oracle import mise as om
+    from livingscenes_amd.mise_fields import FIELDS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mise.npz"))
+    keys = sorted(k[:-4] for k in g.files if k.endswith("_cfg"))
+    assert len(keys) >= 6
+    for key in keys:
+        res0, depth, thr = g[key + "_cfg"]
+        name = key.rsplit("_", 2)[0]
+        tr = []
+        dense = om.run(FIELDS[name], int(res0), int(depth), float(thr), trace=tr)
+        assert len(tr) == int(g[key + "_nrounds"]), key
+        G = dense.shape[0]
+        for i, r in enumerate(tr):
+            assert np.array_equal(np.sort((r[:, 0] * G + r[:, 1]) * G + r[:, 2]), g[key + f"_round{i}"]), (key, i)
+        assert not np.isnan(dense).any()
+        assert np.array_equal(dense.astype(np.float32), g[key + "_dense"]), key
