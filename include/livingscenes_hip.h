@@ -207,6 +207,17 @@ int ls_mise_update(void* state, int resolution_0, int depth, double threshold, c
 /* MISE.to_dense, mise.pyx:128-165 -> grid_out [(R+1)^3] float32 (the reference's float64 grid holds float32 values) */
 int ls_mise_to_dense(void* state, int resolution_0, int depth, float* grid_out, void* stream);
 
+/* SURVEY.md 8 (f-2), second half: libmcubes.marching_cubes(volume, isovalue) as called by Generator3D.extract_mesh
+ * (occnet_utils/mesh_extractor2.py:161-176; occnet_utils/utils/libmcubes/marchingcubes.h:23-196, marchingcubes.cpp:290-326,
+ * pywrapper.cpp:90-108): volume [nx,ny,nz] float64 -> vertices [nv,3] float64 (with the library's +0.5 offset) and faces
+ * [nf,3] int64, in the reference's vertex and face ORDER.  counts_out = DEVICE long long[2] {nv, nf}; call once with
+ * vertices = faces = NULL to size the outputs (nothing past cap_v vertices / cap_f faces is written).  isovalue: the
+ * reference narrows it to float (mcubes.pyx:22) -- pass the narrowed value. */
+size_t ls_mcubes_workspace_bytes(int nx, int ny, int nz);
+int ls_marching_cubes_f64(const double* volume, int nx, int ny, int nz, double isovalue, double* vertices, long long cap_v,
+                          long long* faces, long long cap_f, long long* counts_out, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Live per-kernel timing (bench.py's roofline leg): while enabled, every kernel ls_encode / ls_sdf_decode
  * launches is bracketed by hipEvents on the stream it is launched on.  ls_profile_end synchronises those

@@ -94,6 +94,8 @@ SIGNATURES = {
     "ls_mise_query": (_I, [_P, _I, _I, _F, _P, _P, _I, _P, _P]),
     "ls_mise_update": (_I, [_P, _I, _I, ctypes.c_double, _P, _P, _I, _P]),
     "ls_mise_to_dense": (_I, [_P, _I, _I, _P, _P]),
+    "ls_mcubes_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "ls_marching_cubes_f64": (_I, [_P, _I, _I, _I, ctypes.c_double, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _SZ, _P]),
     "ls_profile_begin": (_I, [_P]),
     "ls_profile_end": (_I, [_P, ctypes.POINTER(ProfileEntry), _I, ctypes.POINTER(ctypes.c_int)]),
 }

@@ -2,14 +2,16 @@
 _solve_object_matching, _solve_pairwise_registration(optim=False), _transform_latent and the encode / match / register
 part of _solve_end2end, plus batched variants the reference lacks (it registers one pair at a time with B=1 encoder
 calls, eval_flyingshape.py:130).  The optimisation-based branches (optim=True: torchlie + geomloss + decoder backward;
-_optimize_code) and mesh extraction are SURVEY.md 8(f) "next" rows and raise NotImplementedError."""
+_optimize_code) are a SURVEY.md 8(f-1) "next" row and raise NotImplementedError; mesh extraction (_mesh_from_latent /
+_mesh_from_pc, 8 f-2) runs MISE and marching cubes on the device (livingscenes_amd/mesh_extractor2.py)."""
 import logging
 
 import torch
 
 from .. import ops
 from ..lib_math.torch_se3 import Rt_to_SE3, inverse, transform
-from ..model_utils import fps, load_ckpt_from_log
+from ..mesh_extractor2 import Generator3D as Generator3D_MC
+from ..model_utils import fps, load_ckpt_from_log, mesh_from_latent
 from .matcher_new import eq_seq_matcher, nn_matcher, sequential_matcher, sim3_seq_matcher, sinkhorn_matcher
 from .pose_estimation import kabsch_transformation_estimation
 
@@ -20,7 +22,8 @@ class More_Solver:
         cfg['shape_priors']['ckpt_dir'] (more_solver.py:26-34)."""
         logging.info("Configuring MoRE solver")
         self.cfg = cfg
-        self.mesh_extractor = None  # Generator3D (MISE + marching cubes): SURVEY.md 8(f-2), not on the accelerated path
+        # Generator3D (device MISE + marching cubes, SURVEY.md 8 f-2): more_solver.py:30
+        self.mesh_extractor = Generator3D_MC(**cfg["mesh_extractor"]) if "mesh_extractor" in cfg else None
         if model is None:
             model = load_ckpt_from_log(cfg["shape_priors"]["ckpt_dir"])[cfg["shape_priors"]["prior_name"]]
         self.model = model
@@ -88,10 +91,15 @@ class More_Solver:
         raise NotImplementedError("latent-code optimisation (decoder backward + Adam) is a SURVEY.md 8(f-1) 'next' row")
 
     def _mesh_from_latent(self, latent_code):
-        raise NotImplementedError("MISE / marching-cubes mesh extraction is a SURVEY.md 8(f-2) 'next' row")
+        """more_solver.py:37-58: mesh of the canonical shape (t = 0, s = 1), then scaled and moved to the instance pose."""
+        if self.mesh_extractor is None:
+            raise ValueError("More_Solver: cfg has no 'mesh_extractor' section")
+        return mesh_from_latent(self.mesh_extractor, latent_code, self.model.decoder)
 
     def _mesh_from_pc(self, pc):
-        raise NotImplementedError("MISE / marching-cubes mesh extraction is a SURVEY.md 8(f-2) 'next' row")
+        """more_solver.py:60-69."""
+        pc_down, _ = fps(pc, K=self.cfg["shape_priors"]["n_input_point"])
+        return self._mesh_from_latent(self.model.encode(pc_down.transpose(-1, -2)))
 
     def _transform_latent(self, code, tsfm):
         """more_solver.py:230-244: rotate z_so3, move t."""

@@ -1,9 +1,11 @@
-"""Mirror of the reference's ``occnet_utils/mesh_extractor2.py`` up to the dense value grid (first half).
+"""Mirror of the reference's ``occnet_utils/mesh_extractor2.py``: MISE-driven value grid + marching cubes.
 
 ``MISE`` mirrors ``libmise.MISE`` (query / update / to_dense, mise.pyx) with the octree state resident in HBM
 (csrc/mise.hip); ``Generator3D.eval_grid`` is the loop of ``__generate_from_latent__`` (mesh_extractor2.py:94-131): per
 round the unknown lattice points go straight from the MISE kernels into ``ls_sdf_decode`` and back -- no host round trip
-except the 4-byte point count.  Marching cubes (libmcubes) is not implemented yet: ``extract_mesh`` raises.
+except the 4-byte point count.  ``marching_cubes`` mirrors ``libmcubes.marching_cubes`` (csrc/mcubes.hip: same vertex and
+face order, float64 coordinates); ``extract_mesh`` is mesh_extractor2.py:161-214 without normals / simplification / refinement
+(all off in the released settings).
 """
 import ctypes
 
@@ -117,8 +119,72 @@ class Generator3D:
         return mise.to_dense()
 
     def generate_from_latent(self, c, F, **kwargs):
+        """mesh_extractor2.py:60-74."""
         return self.extract_mesh(self.eval_grid(c, F, **kwargs), None, c)
 
     def extract_mesh(self, occ_hat, z, c=None, stats_dict=None):
-        raise NotImplementedError("marching cubes (libmcubes) is the second half of the SURVEY.md 8(f-2) 'next' row; "
-                                  "Generator3D.eval_grid returns the dense value grid it would consume")
+        """mesh_extractor2.py:161-214: pad with -1e6 (watertight), marching cubes at the logit threshold, undo the library's 0.5
+        shift and the padding, normalise to the bounding box."""
+        if self.with_normals or self.simplify_nfaces is not None or self.refinement_step > 0:
+            raise NotImplementedError("normals / simplification / refinement are off in the released extraction settings and "
+                                      "not implemented")
+        n_x, n_y, n_z = occ_hat.shape
+        box_size = 1 + self.padding
+        threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
+        vol = torch.as_tensor(np.asarray(occ_hat, np.float64), device=self.device)
+        vol = torch.nn.functional.pad(vol, (1, 1, 1, 1, 1, 1), value=-1e6)
+        vertices, triangles = marching_cubes(vol, threshold)
+        vertices = vertices.cpu().numpy()
+        triangles = triangles.cpu().numpy()
+        vertices -= 0.5
+        vertices -= 1
+        vertices /= np.array([n_x - 1, n_y - 1, n_z - 1])
+        vertices = box_size * (vertices - 0.5)
+        return make_mesh(vertices, triangles)
+
+
+def marching_cubes(volume, isovalue):
+    """libmcubes.marching_cubes(volume [nx,ny,nz], isovalue) on the device -> (vertices [nv,3] float64, faces [nf,3] int64),
+    device tensors, in the reference's vertex / face order (coordinates carry the library's +0.5 offset)."""
+    vol = torch.as_tensor(volume)
+    if not vol.is_cuda:
+        raise ValueError("marching_cubes: the volume must live on the GPU (no CPU fallback)")
+    vol = vol.to(torch.float64).contiguous()
+    assert vol.dim() == 3, "Only three-dimensional arrays are supported."
+    nx, ny, nz = vol.shape
+    iso = float(np.float32(isovalue))   # mcubes.pyx:22 declares `float isovalue`
+    dev = vol.device
+    ws_bytes = load().ls_mcubes_workspace_bytes(nx, ny, nz)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    args = (ptr(vol), nx, ny, nz, ctypes.c_double(iso))
+    check(load().ls_marching_cubes_f64(*args, None, 0, None, 0, ptr(counts), ptr(ws), ws_bytes, stream_ptr(dev)), "ls_marching_cubes_f64")
+    nv, nf = (int(v) for v in counts.cpu())
+    verts = torch.empty(nv, 3, dtype=torch.float64, device=dev)
+    faces = torch.empty(nf, 3, dtype=torch.int64, device=dev)
+    if nv:
+        check(load().ls_marching_cubes_f64(*args, ptr(verts), nv, ptr(faces), nf, ptr(counts), ptr(ws), ws_bytes, stream_ptr(dev)),
+              "ls_marching_cubes_f64")
+    return verts, faces
+
+
+class SimpleMesh:
+    """Stand-in for trimesh.Trimesh(vertices, faces, process=False) when trimesh is not installed."""
+
+    def __init__(self, vertices, faces):
+        self.vertices, self.faces = np.asarray(vertices, np.float64), np.asarray(faces, np.int64)
+
+    def export_obj(self, path):
+        with open(path, "w") as f:
+            for v in self.vertices:
+                f.write(f"v {v[0]:.9g} {v[1]:.9g} {v[2]:.9g}\n")
+            for t in self.faces:
+                f.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
+
+
+def make_mesh(vertices, faces):
+    try:
+        import trimesh
+        return trimesh.Trimesh(vertices, faces, process=False)   # mesh_extractor2.py:193
+    except ImportError:
+        return SimpleMesh(vertices, faces)

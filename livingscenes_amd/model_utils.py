@@ -198,6 +198,27 @@ def wrap_encoder_output(outputs):
     return {"z_so3": outputs[2], "z_inv": outputs[-1], "s": outputs[1], "t": outputs[0]}
 
 
+def mesh_from_latent(extractor, latent_code, decoder):
+    """model_utils.py:293-305: extract the canonical mesh (t = 0, s = 1), then apply scale and translation."""
+    import numpy as np
+    centroid = latent_code["t"].detach().clone()
+    scale = latent_code["s"].detach().clone()
+    latent_code["t"] = torch.zeros_like(centroid)
+    latent_code["s"] = torch.ones_like(scale)
+    try:
+        mesh = extractor.generate_from_latent(latent_code, decoder)
+    finally:
+        latent_code["t"], latent_code["s"] = centroid, scale
+    tsfm = np.eye(4) * scale.squeeze().item()
+    tsfm[-1, -1] = 1
+    tsfm[:3, 3] = centroid.squeeze().view(-1).detach().cpu().numpy()
+    if hasattr(mesh, "apply_transform"):
+        mesh.apply_transform(tsfm)                                   # trimesh
+    else:
+        mesh.vertices = mesh.vertices @ tsfm[:3, :3].T + tsfm[:3, 3]
+    return mesh
+
+
 def slice_code_dict(code_dict, index):
     """model_utils.py:308-318."""
     return {k: code_dict[k][index][None] for k in ("z_inv", "z_so3", "s", "t")}

@@ -149,3 +149,16 @@ def test_mise_oracle_matches_reference_golden():
             assert np.array_equal(np.sort((r[:, 0] * G + r[:, 1]) * G + r[:, 2]), g[key + f"_round{i}"]), (key, i)
         assert not np.isnan(dense).any()
         assert np.array_equal(dense.astype(np.float32), g[key + "_dense"]), key
+
+
+def test_marching_cubes_oracle_matches_reference_golden():
+    """oracle/mcubes.py vs the reference's libmcubes (tests/golden/mcubes.npz): vertices (float64) and faces bit-identical,
+    including their order; random volumes, samples exactly at the iso-value, the padded sphere of extract_mesh, flat volumes."""
+    import os
+    from oracle import mcubes as om
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mcubes.npz"))
+    names = sorted(k[:-4] for k in g.files if k.endswith("_vol"))
+    assert len(names) >= 7
+    for name in names:
+        v, f = om.marching_cubes(g[name + "_vol"], float(g[name + "_iso"]))
+        assert np.array_equal(v, g[name + "_v"]) and np.array_equal(f, g[name + "_f"]), name
