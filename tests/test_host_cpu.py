@@ -223,3 +223,25 @@ def test_world_size_2_sharding_over_gloo(tmp_path):
     for r, p in enumerate(procs):
         out, err = p.communicate(timeout=180)
         assert p.returncode == 0 and f"rank {r} ok" in out, err[-3000:]
+
+
+def test_flyingshape_disk_format_round_trip(tmp_path):
+    """livingscenes_amd.datasets.FlyingShape walks <root>/<.._n>/<scene>/*.npz like eval_flyingshape.py:33-60: sorted
+    directories, reference scan first, 'pc' / 'transform' arrays intact."""
+    import numpy as np
+    from livingscenes_amd import datasets, synth
+    root = str(tmp_path)
+    scenes = []
+    for n_obj, name in ((3, "scene_b"), (3, "scene_a"), (5, "scene_c")):
+        sc = synth.make_scene_pair(n_obj, 64, seed=n_obj * 7 + len(name))
+        scenes.append((n_obj, name, sc))
+        datasets.write_scene(root, f"n_shape_{n_obj}", name,
+                             [{"pc": sc["ref"].numpy(), "transform": sc["ref_T"].numpy()},
+                              {"pc": sc["rescan"].numpy(), "transform": sc["rescan_T"].numpy()}])
+    ds = datasets.FlyingShape(root)
+    assert len(ds) == 3 and [p.split("/")[-1] for p in ds.scene_lst] == ["scene_a", "scene_b", "scene_c"]
+    got = datasets.scene_from_scans(ds[0])
+    want = [s for s in scenes if s[1] == "scene_a"][0][2]
+    for k in ("ref", "rescan", "ref_T", "rescan_T"):
+        assert np.array_equal(got[k].numpy(), want[k].numpy().astype(np.float32)), k
+    assert len(list(ds)) == 3
