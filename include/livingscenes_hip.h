@@ -184,6 +184,18 @@ size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M);
 int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s,
                   const float* t, int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream);
 
+/* SURVEY.md 8 (f-1), the autograd half: what `loss.backward()` computes in More_Solver._optimize_code
+ * (lib_more/more_solver.py:191-228) through FieldWrapper.forward (model_utils.py:230-263) and DeepSDF_Decoder.forward
+ * (deepsdf_decoder.py:78-123).  ls_sdf_decode_train = ls_sdf_decode keeping every layer's activations in `workspace`
+ * (ls_sdf_train_workspace_bytes); ls_sdf_backward, called with the SAME arguments and workspace, returns the gradients of
+ * sum(grad_sdf * sdf):  grad_query [B,M,3] (nullable), grad_z_so3 [B,c,3], grad_z_inv [B,c], grad_s [B], grad_t [B,3]. */
+size_t ls_sdf_train_workspace_bytes(const ls_model_t* m, int B, int M);
+int ls_sdf_decode_train(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s,
+                        const float* t, int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream);
+int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s, const float* t,
+                    int B, int M, const float* sdf, const float* grad_sdf, void* workspace, size_t workspace_bytes,
+                    float* grad_query, float* grad_z_so3, float* grad_z_inv, float* grad_s, float* grad_t, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md 8 (f-2), first half: the MISE octree that decides WHICH lattice points of the (R+1)^3 grid the decoder has to
  * evaluate (R = resolution_0 << depth) and assembles the dense value grid -- class MISE of

@@ -42,6 +42,14 @@ int sdf_prep_launch(const float*, const float*, const float*, const float*, cons
 int sdf_affine_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
                       hipStream_t);
 int sdf_out_launch(const float*, int, int, const float*, const float*, long long, float*, hipStream_t);
+int sdf_out_bwd_launch(const float*, const float*, const float*, const float*, int, int, long long, float*, hipStream_t);
+int relu_mask_launch(float*, const float*, long long, int, int, hipStream_t);
+int sdf_affine_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*, float*,
+                          float*, hipStream_t);
+int sdf_code_grad_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                         int, int, int, float*, float*, hipStream_t);
+int sdf_query_grad_launch(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
+int transpose_launch(const float*, int, int, float*, hipStream_t);
 int cosine_scores_launch(const float*, const float*, int, int, int, float*, float*, hipStream_t);
 int greedy_match_launch(float*, int, int, long long*, long long*, hipStream_t);
 int kabsch_launch(const float*, const float*, const float*, int, int, int, float*, float*, float*, float*, int32_t*, hipStream_t);
@@ -58,6 +66,8 @@ struct ProfRec { int kind, layer; hipEvent_t a, b; };
 struct ls_model {
     ls_model_desc d;
     float* blob = nullptr;
+    float* dec_wt = nullptr;            // transposed decoder weights [kin_l][out_l], built by the first backward call
+    size_t dec_wt_off[12] = {};
     hipStream_t side = nullptr;    // FPS chain
     hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -278,6 +288,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
 void ls_model_destroy(ls_model_t* m) {
     if (!m) return;
     if (m->blob) (void)hipFree(m->blob);
+    if (m->dec_wt) (void)hipFree(m->dec_wt);
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->side2) (void)hipStreamDestroy(m->side2);
     for (int i = 0; i < LS_MAX_LAYERS; ++i) {
@@ -448,6 +459,19 @@ static int dec_out(const ls_model_desc& d, int l) {  // padded output width of l
     return d.dec_width;
 }
 
+// split-K scratch (floats) that covers every GEMM of the decoder forward and backward at `rows` query rows
+static size_t sdf_gemm_scratch(const ls_model_desc& d, long long rows) {
+    size_t mx = 0;
+    int kin = d.dec_width;
+    for (int l = 1; l < d.dec_num_linear - 1; ++l) {
+        const int outw = dec_out(d, l);
+        mx = std::max(mx, gemm_scratch_floats((int)rows, outw, kin));   // forward: [rows,kin] x [outw,kin]^T
+        mx = std::max(mx, gemm_scratch_floats((int)rows, kin, outw));   // backward: [rows,outw] x [kin,outw]^T
+        kin = outw;
+    }
+    return mx;
+}
+
 size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M) {
     if (!m || m->d.dec_num_linear <= 0) return 0;
     const size_t w = (size_t)m->d.dec_width;
@@ -455,7 +479,96 @@ size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M) {
     b += 2 * align_up((size_t)B * w * 4 * 4, 256);   // A0, A4
     b += 2 * align_up((size_t)B * w * 4, 256);       // beff0, beff4
     b += 2 * align_up((size_t)B * M * w * 4, 256);   // ping-pong activations
+    b += align_up(sdf_gemm_scratch(m->d, (long long)B * M) * 4, 256) + 256;   // split-K slabs (small M only)
     return b;
+}
+// training form: every layer's activations are kept for the backward pass, plus its scratch
+size_t ls_sdf_train_workspace_bytes(const ls_model_t* m, int B, int M) {
+    if (!m || m->d.dec_num_linear <= 0) return 0;
+    const size_t w = (size_t)m->d.dec_width;
+    const int nl = m->d.dec_num_linear;
+    size_t b = 0;
+    b += 2 * align_up((size_t)B * w * 4 * 4, 256) + 2 * align_up((size_t)B * w * 4, 256);      // A0, A4, beff0, beff4
+    b += (size_t)(nl - 1) * align_up((size_t)B * M * w * 4, 256);                               // h_0 .. h_{nl-2}
+    b += 2 * align_up((size_t)B * M * w * 4, 256);                                              // dz ping-pong
+    b += 2 * align_up((size_t)B * w * 4 * 4, 256) + 2 * align_up((size_t)B * w * 4, 256);      // dA0, dA4, dbeff0, dbeff4
+    b += align_up((size_t)B * M * 4 * 4, 256);                                                  // dQ
+    b += align_up(sdf_gemm_scratch(m->d, (long long)B * M) * 4, 256) + 256;                      // split-K slabs (small M only)
+    return b;
+}
+
+struct SdfBuffers {
+    float *A0, *A4, *b0, *b4;
+    float* h[12];       // output of linear layer l (post-ReLU); inference: two ping-pong buffers
+    float *dzA, *dzB, *dA0, *dA4, *db0, *db4, *dQ;
+    float* gws;         // split-K scratch for the under-filled GEMMs (NULL when the grid is large enough)
+};
+static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, int M, bool train) {
+    SdfBuffers sb{};
+    const int w = d.dec_width, nl = d.dec_num_linear;
+    char* ws = (char*)workspace;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { float* p = (float*)(ws + off); off = align_up(off + bytes, 256); return p; };
+    sb.A0 = take((size_t)B * w * 16);
+    sb.A4 = take((size_t)B * w * 16);
+    sb.b0 = take((size_t)B * w * 4);
+    sb.b4 = take((size_t)B * w * 4);
+    if (!train) {
+        float* hA = take((size_t)B * M * w * 4);
+        float* hB = take((size_t)B * M * w * 4);
+        for (int l = 0; l < nl - 1; ++l) sb.h[l] = (l & 1) ? hB : hA;
+        sb.gws = sdf_gemm_scratch(d, (long long)B * M) ? take(sdf_gemm_scratch(d, (long long)B * M) * 4) : nullptr;
+        return sb;
+    }
+    for (int l = 0; l < nl - 1; ++l) sb.h[l] = take((size_t)B * M * w * 4);
+    sb.dzA = take((size_t)B * M * w * 4);
+    sb.dzB = take((size_t)B * M * w * 4);
+    sb.dA0 = take((size_t)B * w * 16);
+    sb.dA4 = take((size_t)B * w * 16);
+    sb.db0 = take((size_t)B * w * 4);
+    sb.db4 = take((size_t)B * w * 4);
+    sb.dQ = take((size_t)B * M * 16);
+    sb.gws = sdf_gemm_scratch(d, (long long)B * M) ? take(sdf_gemm_scratch(d, (long long)B * M) * 4) : nullptr;
+    return sb;
+}
+
+static int sdf_forward(ls_model_t* m, const SdfBuffers& sb, const float* query, const float* z_so3, const float* z_inv, const float* s,
+                       const float* t, int B, int M, float* sdf, hipStream_t st) {
+    const ls_model_desc& d = m->d;
+    const int w = d.dec_width, L = d.c_dim, nl = d.dec_num_linear, li = d.dec_latent_in;
+    const float* W = m->blob;
+    int rc;
+    {
+        PROF(LS_K_SDF_PREP, 0, st);
+        rc = sdf_prep_launch(W + d.off_dec_inv_t[0], W + d.off_dec_so3_t[0], W + d.off_dec_len[0], W + d.off_dec_b[0], z_so3,
+                             z_inv, B, L, w, sb.A0, sb.b0, st);
+        if (rc == LS_OK && li >= 0)
+            rc = sdf_prep_launch(W + d.off_dec_inv_t[li], W + d.off_dec_so3_t[li], W + d.off_dec_len[li], W + d.off_dec_b[li],
+                                 z_so3, z_inv, B, L, w, sb.A4, sb.b4, st);
+    }
+    if (rc != LS_OK) return rc;
+    // layer 0: pure affine in (q, |q|)
+    { PROF(LS_K_SDF_AFFINE, 0, st); rc = sdf_affine_launch(query, s, t, sb.A0, sb.b0, B, M, w, w, 0, sb.h[0], st); }
+    if (rc != LS_OK) return rc;
+    int kin = w;
+    for (int l = 1; l < nl - 1; ++l) {
+        const int outw = dec_out(d, l);
+        const float* cur = sb.h[l - 1];
+        float* nxt = sb.h[l];
+        if (l == li) {
+            { PROF(LS_K_GEMM_SDF, l, st); rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, B * M, outw, kin, 0, sb.gws, st); }
+            if (rc != LS_OK) return rc;
+            PROF(LS_K_SDF_AFFINE, l, st);
+            rc = sdf_affine_launch(query, s, t, sb.A4, sb.b4, B, M, w, w, 1, nxt, st);
+        } else {
+            PROF(LS_K_GEMM_SDF, l, st);
+            rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, B * M, outw, kin, 1, sb.gws, st);
+        }
+        if (rc != LS_OK) return rc;
+        kin = outw;
+    }
+    PROF(LS_K_SDF_OUT, nl - 1, st);
+    return sdf_out_launch(sb.h[nl - 2], w, kin, W + d.off_dec_w[nl - 1], W + d.off_dec_b[nl - 1], (long long)B * M, sdf, st);
 }
 
 int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s, const float* t,
@@ -466,51 +579,87 @@ int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const f
     LS_REQUIRE(B > 0 && M > 0, "sdf_decode: empty problem");
     const size_t need = ls_sdf_workspace_bytes(m, B, M);
     if (workspace_bytes < need) { set_error("sdf_decode: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
-    hipStream_t st = (hipStream_t)stream;
-    const int w = d.dec_width, L = d.c_dim, nl = d.dec_num_linear, li = d.dec_latent_in;
-    char* ws = (char*)workspace;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { float* p = (float*)(ws + off); off = align_up(off + bytes, 256); return p; };
-    float* A0 = take((size_t)B * w * 16);
-    float* A4 = take((size_t)B * w * 16);
-    float* b0 = take((size_t)B * w * 4);
-    float* b4 = take((size_t)B * w * 4);
-    float* hA = take((size_t)B * M * w * 4);
-    float* hB = take((size_t)B * M * w * 4);
-    const float* W = m->blob;
-    int rc;
-    {
-        PROF(LS_K_SDF_PREP, 0, st);
-        rc = sdf_prep_launch(W + d.off_dec_inv_t[0], W + d.off_dec_so3_t[0], W + d.off_dec_len[0], W + d.off_dec_b[0], z_so3,
-                             z_inv, B, L, w, A0, b0, st);
-        if (rc == LS_OK && li >= 0)
-            rc = sdf_prep_launch(W + d.off_dec_inv_t[li], W + d.off_dec_so3_t[li], W + d.off_dec_len[li], W + d.off_dec_b[li],
-                                 z_so3, z_inv, B, L, w, A4, b4, st);
-    }
-    if (rc != LS_OK) return rc;
-    // layer 0: pure affine in (q, |q|)
-    { PROF(LS_K_SDF_AFFINE, 0, st); rc = sdf_affine_launch(query, s, t, A0, b0, B, M, w, w, 0, hA, st); }
-    if (rc != LS_OK) return rc;
-    float* cur = hA;
-    float* nxt = hB;
+    return sdf_forward(m, sdf_buffers(d, workspace, B, M, false), query, z_so3, z_inv, s, t, B, M, sdf, (hipStream_t)stream);
+}
+
+// forward that keeps every layer's activations in `workspace` for ls_sdf_backward
+int ls_sdf_decode_train(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s, const float* t,
+                        int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream) {
+    LS_REQUIRE(m && query && z_so3 && z_inv && s && t && sdf && workspace, "sdf_decode_train: null argument");
+    const ls_model_desc& d = m->d;
+    LS_REQUIRE(d.dec_num_linear >= 3, "sdf_decode_train: model has no decoder packed");
+    LS_REQUIRE(B > 0 && M > 0, "sdf_decode_train: empty problem");
+    const size_t need = ls_sdf_train_workspace_bytes(m, B, M);
+    if (workspace_bytes < need) { set_error("sdf_decode_train: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
+    return sdf_forward(m, sdf_buffers(d, workspace, B, M, true), query, z_so3, z_inv, s, t, B, M, sdf, (hipStream_t)stream);
+}
+
+static int build_dec_wt(ls_model_t* m, hipStream_t st) {   // transposed main weights of layers 1 .. nl-2
+    if (m->dec_wt) return LS_OK;
+    const ls_model_desc& d = m->d;
+    const int nl = d.dec_num_linear, w = d.dec_width;
+    size_t total = 0;
     int kin = w;
+    for (int l = 1; l < nl - 1; ++l) { const int outw = dec_out(d, l); m->dec_wt_off[l] = total; total += (size_t)kin * outw; kin = outw; }
+    LS_HIP_CHECK(hipMalloc((void**)&m->dec_wt, total * sizeof(float)));
+    kin = w;
     for (int l = 1; l < nl - 1; ++l) {
         const int outw = dec_out(d, l);
-        if (l == li) {
-            { PROF(LS_K_GEMM_SDF, l, st); rc = gemm_dispatch(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, B * M, outw, kin, 0, st); }
-            if (rc != LS_OK) return rc;
-            PROF(LS_K_SDF_AFFINE, l, st);
-            rc = sdf_affine_launch(query, s, t, A4, b4, B, M, w, w, 1, nxt, st);
-        } else {
-            PROF(LS_K_GEMM_SDF, l, st);
-            rc = gemm_dispatch(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, B * M, outw, kin, 1, st);
-        }
+        int rc = transpose_launch(m->blob + d.off_dec_w[l], outw, kin, m->dec_wt + m->dec_wt_off[l], st);   // W [out][kin] -> [kin][out]
         if (rc != LS_OK) return rc;
         kin = outw;
-        std::swap(cur, nxt);
     }
-    PROF(LS_K_SDF_OUT, nl - 1, st);
-    return sdf_out_launch(cur, w, kin, W + d.off_dec_w[nl - 1], W + d.off_dec_b[nl - 1], (long long)B * M, sdf, st);
+    return LS_OK;
+}
+
+// Gradients of sum(grad_sdf * sdf) w.r.t. the code and the query points, after ls_sdf_decode_train on the SAME arguments and
+// workspace.  grad_query is optional; the others are required.
+int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s, const float* t, int B,
+                    int M, const float* sdf, const float* grad_sdf, void* workspace, size_t workspace_bytes, float* grad_query,
+                    float* grad_z_so3, float* grad_z_inv, float* grad_s, float* grad_t, void* stream) {
+    LS_REQUIRE(m && query && z_so3 && z_inv && s && t && sdf && grad_sdf && workspace && grad_z_so3 && grad_z_inv && grad_s && grad_t,
+               "sdf_backward: null argument");
+    const ls_model_desc& d = m->d;
+    LS_REQUIRE(d.dec_num_linear >= 3, "sdf_backward: model has no decoder packed");
+    LS_REQUIRE(B > 0 && M > 0, "sdf_backward: empty problem");
+    const size_t need = ls_sdf_train_workspace_bytes(m, B, M);
+    if (workspace_bytes < need) { set_error("sdf_backward: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = build_dec_wt(m, st);
+    if (rc != LS_OK) return rc;
+    const SdfBuffers sb = sdf_buffers(d, workspace, B, M, true);
+    const int w = d.dec_width, L = d.c_dim, nl = d.dec_num_linear, li = d.dec_latent_in;
+    const float* W = m->blob;
+    const long long rows = (long long)B * M;
+    // widths: out_w[l] = padded output width of layer l
+    int outw[12];
+    for (int l = 0; l < nl; ++l) outw[l] = l == 0 ? w : dec_out(d, l);
+    float* dz = sb.dzA;     // dz_l: gradient w.r.t. the pre-activation of layer l, row stride w
+    float* other = sb.dzB;
+    // last layer: dz_{nl-2}
+    rc = sdf_out_bwd_launch(grad_sdf, sdf, W + d.off_dec_w[nl - 1], sb.h[nl - 2], w, outw[nl - 2], rows, dz, st);
+    if (rc != LS_OK) return rc;
+    bool dq_started = false;
+    for (int l = nl - 2; l >= 1; --l) {
+        const int kin = outw[l - 1];          // input width of layer l (= padded output width of layer l-1)
+        if (l == li) {
+            rc = sdf_affine_bwd_launch(query, s, t, dz, sb.A4, B, M, w, w, dq_started ? 1 : 0, sb.dA4, sb.db4, sb.dQ, st);
+            if (rc != LS_OK) return rc;
+            dq_started = true;
+        }
+        // dh_{l-1} [rows, kin] = dz_l [rows, out_l] . W_l [out_l][kin]  ==  dz_l . (Wt_l [kin][out_l])^T
+        rc = gemm_dispatch_ws(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, sb.gws, st);
+        if (rc != LS_OK) return rc;
+        rc = relu_mask_launch(other, sb.h[l - 1], rows, kin, w, st);
+        if (rc != LS_OK) return rc;
+        std::swap(dz, other);
+    }
+    rc = sdf_affine_bwd_launch(query, s, t, dz, sb.A0, B, M, w, w, dq_started ? 1 : 0, sb.dA0, sb.db0, sb.dQ, st);
+    if (rc != LS_OK) return rc;
+    rc = sdf_code_grad_launch(W + d.off_dec_so3_t[0], W + d.off_dec_inv_t[0], sb.dA0, sb.db0, li >= 0 ? W + d.off_dec_so3_t[li] : nullptr,
+                              li >= 0 ? W + d.off_dec_inv_t[li] : nullptr, sb.dA4, sb.db4, B, L, w, grad_z_so3, grad_z_inv, st);
+    if (rc != LS_OK) return rc;
+    return sdf_query_grad_launch(query, s, t, sb.dQ, B, M, grad_query, grad_t, grad_s, st);
 }
 
 // ------------------------------------------------------------------------------------------------ profiling

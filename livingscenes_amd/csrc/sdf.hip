@@ -79,6 +79,208 @@ __global__ __launch_bounds__(256) void sdf_out_kernel(const float* __restrict__ 
     if (lane == 0) sdf[row] = tanhf(acc + bias[0]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the same path w.r.t. the instance code and the query points (the part the reference gets from
+// autograd in More_Solver._optimize_code, /root/reference/lib_more/more_solver.py:191-228: loss.backward() through
+// FieldWrapper.forward + DeepSDF_Decoder.forward).  The 768x768 layers are GEMMs against the transposed weights (gemm.hip);
+// what is left is element-wise or a reduction:
+//   sdf = tanh(<h7, w8> + b8)            dz7 = g (1 - sdf^2) w8 . [h7 > 0]
+//   h_l = relu(z_l)                      dz_l = dh_l . [h_l > 0]
+//   z_l = A (q,|q|) + beff (+ W h)       dA = sum_m dz (q,|q|)^T,  dbeff = sum_m dz,  d(q,|q|) = A^T dz      (l = 0, latent_in)
+//   A = [Wb z_so3 | w_len], beff = b + Wa z_inv      dz_so3 = Wb^T dA[:, :3],  dz_inv = Wa^T dbeff
+//   q = (query - t) / s                  dq = d(q)[:3] + d|q| q/|q|,  dquery = dq / s,  dt = -sum_m dq / s,  ds = -sum_m <dq, q> / s
+
+// dz[row][c] = g[row] (1 - sdf[row]^2) w[c] [h[row][c] > 0]
+__global__ __launch_bounds__(256) void sdf_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ sdf,
+                                                          const float* __restrict__ w, const float* __restrict__ h, int ldh, int width,
+                                                          long long rows, float* __restrict__ dz) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one float4 of a row
+    const int w4 = width / 4;
+    if (i >= rows * w4) return;
+    const long long row = i / w4;
+    const int c = (int)(i % w4) * 4;
+    const float sv = sdf[row], gz = g[row] * (1.0f - sv * sv);
+    const float4 hv = *reinterpret_cast<const float4*>(h + (size_t)row * ldh + c);
+    const float4 wv = *reinterpret_cast<const float4*>(w + c);
+    float4 o;
+    o.x = hv.x > 0.f ? gz * wv.x : 0.f; o.y = hv.y > 0.f ? gz * wv.y : 0.f;
+    o.z = hv.z > 0.f ? gz * wv.z : 0.f; o.w = hv.w > 0.f ? gz * wv.w : 0.f;
+    *reinterpret_cast<float4*>(dz + (size_t)row * ldh + c) = o;
+}
+// dh[row][c] <- dh[row][c] [h[row][c] > 0]   (c < cols, both with row stride ld)
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ dh, const float* __restrict__ h, long long rows, int cols,
+                                                        int ld) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = cols / 4;
+    if (i >= rows * c4n) return;
+    const size_t o = (size_t)(i / c4n) * ld + (size_t)(i % c4n) * 4;
+    float4 d = *reinterpret_cast<float4*>(dh + o);
+    const float4 hv = *reinterpret_cast<const float4*>(h + o);
+    d.x = hv.x > 0.f ? d.x : 0.f; d.y = hv.y > 0.f ? d.y : 0.f; d.z = hv.z > 0.f ? d.z : 0.f; d.w = hv.w > 0.f ? d.w : 0.f;
+    *reinterpret_cast<float4*>(dh + o) = d;
+}
+// code-fed layer, reductions over the queries of an instance: dA[b][o][0..3] = sum_m dz[b,m,o] (q_m, |q_m|), dbeff[b][o] = sum_m dz
+// (fixed summation order: bit-reproducible)
+__global__ __launch_bounds__(256) void sdf_affine_bwd_cols_kernel(const float* __restrict__ query, const float* __restrict__ s,
+                                                                  const float* __restrict__ t, const float* __restrict__ dz, int M,
+                                                                  int out_dim, int ldh, float* __restrict__ dA, float* __restrict__ dbeff) {
+    // workgroup = 64 output channels x 4 row slices (slice w takes rows w, w+4, ...); slices combined in fixed order through LDS
+    __shared__ float red[4][64][5];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + lane;
+    const bool on = o < out_dim;
+    const float sc = s[b], tx = t[b * 3], ty = t[b * 3 + 1], tz = t[b * 3 + 2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, bb = 0.f;
+    for (int r = slice; r < M; r += 4) {
+        const float* qp = query + ((size_t)b * M + r) * 3;
+        const float qx = (qp[0] - tx) / sc, qy = (qp[1] - ty) / sc, qz = (qp[2] - tz) / sc;
+        const float len = sqrtf(qx * qx + qy * qy + qz * qz);
+        const float d = on ? dz[((size_t)b * M + r) * ldh + o] : 0.f;
+        a0 += d * qx; a1 += d * qy; a2 += d * qz; a3 += d * len; bb += d;
+    }
+    red[slice][lane][0] = a0; red[slice][lane][1] = a1; red[slice][lane][2] = a2; red[slice][lane][3] = a3; red[slice][lane][4] = bb;
+    __syncthreads();
+    if (slice == 0 && on) {
+        float v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = ((red[0][lane][k] + red[1][lane][k]) + red[2][lane][k]) + red[3][lane][k];
+        float* Ap = dA + ((size_t)b * out_dim + o) * 4;
+        Ap[0] = v[0]; Ap[1] = v[1]; Ap[2] = v[2]; Ap[3] = v[3];
+        dbeff[(size_t)b * out_dim + o] = v[4];
+    }
+}
+// code-fed layer, reduction over the output channels of a query: dQ[row][0..3] (+)= sum_o dz[row][o] A[b][o][0..3]; one wave per row
+__global__ __launch_bounds__(256) void sdf_affine_bwd_rows_kernel(const float* __restrict__ dz, const float* __restrict__ A, int M,
+                                                                  int out_dim, int ldh, int accumulate, long long rows,
+                                                                  float* __restrict__ dQ) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row / M);
+    const float* Ab = A + (size_t)b * out_dim * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int o = lane; o < out_dim; o += 64) {
+        const float d = dz[(size_t)row * ldh + o];
+        const float4 av = *reinterpret_cast<const float4*>(Ab + (size_t)o * 4);
+        a0 += d * av.x; a1 += d * av.y; a2 += d * av.z; a3 += d * av.w;
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if (lane == 0) {
+        float* p = dQ + (size_t)row * 4;
+        if (accumulate) { a0 += p[0]; a1 += p[1]; a2 += p[2]; a3 += p[3]; }
+        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3;
+    }
+}
+// dz_so3[b][c][x] = sum over the code-fed layers of sum_o so3_t[c][o] dA[b][o][x]; dz_inv[b][c] likewise with inv_t / dbeff
+__global__ __launch_bounds__(256) void sdf_code_grad_kernel(const float* __restrict__ so3_t0, const float* __restrict__ inv_t0,
+                                                            const float* __restrict__ dA0, const float* __restrict__ db0,
+                                                            const float* __restrict__ so3_t1, const float* __restrict__ inv_t1,
+                                                            const float* __restrict__ dA1, const float* __restrict__ db1, int L,
+                                                            int out_dim, float* __restrict__ g_so3, float* __restrict__ g_inv) {
+    // one wave per (instance, latent channel)
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (c >= L) return;
+    float gx = 0.f, gy = 0.f, gz = 0.f, gi = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* so3_t = pass ? so3_t1 : so3_t0;
+        const float* inv_t = pass ? inv_t1 : inv_t0;
+        const float* dA = pass ? dA1 : dA0;
+        const float* db = pass ? db1 : db0;
+        if (!so3_t) continue;
+        for (int o = lane; o < out_dim; o += 64) {
+            const float ws = so3_t[(size_t)c * out_dim + o], wi = inv_t[(size_t)c * out_dim + o];
+            const float4 a = *reinterpret_cast<const float4*>(dA + ((size_t)b * out_dim + o) * 4);
+            gx += ws * a.x; gy += ws * a.y; gz += ws * a.z;
+            gi += wi * db[(size_t)b * out_dim + o];
+        }
+    }
+    gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gi = wave_sum(gi);
+    if (lane == 0) {
+        float* p = g_so3 + ((size_t)b * L + c) * 3;
+        p[0] = gx; p[1] = gy; p[2] = gz;
+        g_inv[(size_t)b * L + c] = gi;
+    }
+}
+// dq = dQ[:3] + dQ[3] q/|q| (0 at q = 0, as torch's norm backward); dquery = dq/s; per instance dt = -sum dq / s, ds = -sum <dq,q> / s
+__global__ __launch_bounds__(256) void sdf_query_grad_kernel(const float* __restrict__ query, const float* __restrict__ s,
+                                                             const float* __restrict__ t, const float* __restrict__ dQ, int M,
+                                                             float* __restrict__ g_query, float* __restrict__ g_t, float* __restrict__ g_s) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float sc = s[b], tx = t[b * 3], ty = t[b * 3 + 1], tz = t[b * 3 + 2];
+    float sx = 0.f, sy = 0.f, sz = 0.f, ss = 0.f;
+    for (int r = tid; r < M; r += 256) {
+        const size_t row = (size_t)b * M + r;
+        const float* qp = query + row * 3;
+        const float qx = (qp[0] - tx) / sc, qy = (qp[1] - ty) / sc, qz = (qp[2] - tz) / sc;
+        const float len = sqrtf(qx * qx + qy * qy + qz * qz);
+        const float4 d = *reinterpret_cast<const float4*>(dQ + row * 4);
+        const float il = len > 0.f ? d.w / len : 0.f;
+        const float dx = d.x + il * qx, dy = d.y + il * qy, dzv = d.z + il * qz;
+        if (g_query) { g_query[row * 3] = dx / sc; g_query[row * 3 + 1] = dy / sc; g_query[row * 3 + 2] = dzv / sc; }
+        sx += dx; sy += dy; sz += dzv; ss += dx * qx + dy * qy + dzv * qz;
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); ss = wave_sum(ss);
+    if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; red[wave][3] = ss; }
+    __syncthreads();
+    if (tid < 4) {
+        const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid < 3) g_t[b * 3 + tid] = -v / sc;
+        else g_s[b] = -v / sc;
+    }
+}
+// Wt[k][o] = W[o][k]
+__global__ void transpose_kernel(const float* __restrict__ W, int rows, int cols, float* __restrict__ Wt) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (by + i < rows && bx + tx < cols) tile[i][tx] = W[(size_t)(by + i) * cols + bx + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (bx + i < cols && by + tx < rows) Wt[(size_t)(bx + i) * rows + by + tx] = tile[tx][i];
+}
+
+int sdf_out_bwd_launch(const float* g, const float* sdf, const float* w, const float* h, int ldh, int width, long long rows, float* dz,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(sdf_out_bwd_kernel, dim3(cdiv(rows * (width / 4), 256)), dim3(256), 0, st, g, sdf, w, h, ldh, width, rows, dz);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int relu_mask_launch(float* dh, const float* h, long long rows, int cols, int ld, hipStream_t st) {
+    LS_REQUIRE(cols % 4 == 0 && ld % 4 == 0, "relu_mask: cols/ld must be multiples of 4");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(cdiv(rows * (cols / 4), 256)), dim3(256), 0, st, dh, h, rows, cols, ld);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int sdf_affine_bwd_launch(const float* query, const float* s, const float* t, const float* dz, const float* A, int B, int M, int out_dim,
+                          int ldh, int accumulate, float* dA, float* dbeff, float* dQ, hipStream_t st) {
+    hipLaunchKernelGGL(sdf_affine_bwd_cols_kernel, dim3(cdiv(out_dim, 64), B), dim3(256), 0, st, query, s, t, dz, M, out_dim, ldh, dA, dbeff);
+    hipLaunchKernelGGL(sdf_affine_bwd_rows_kernel, dim3(cdiv((long long)B * M, 4)), dim3(256), 0, st, dz, A, M, out_dim, ldh, accumulate,
+                       (long long)B * M, dQ);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int sdf_code_grad_launch(const float* so3_t0, const float* inv_t0, const float* dA0, const float* db0, const float* so3_t1,
+                         const float* inv_t1, const float* dA1, const float* db1, int B, int L, int out_dim, float* g_so3, float* g_inv,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(sdf_code_grad_kernel, dim3(cdiv(L, 4), B), dim3(256), 0, st, so3_t0, inv_t0, dA0, db0, so3_t1, inv_t1, dA1, db1, L,
+                       out_dim, g_so3, g_inv);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int sdf_query_grad_launch(const float* query, const float* s, const float* t, const float* dQ, int B, int M, float* g_query, float* g_t,
+                          float* g_s, hipStream_t st) {
+    hipLaunchKernelGGL(sdf_query_grad_kernel, dim3(B), dim3(256), 0, st, query, s, t, dQ, M, g_query, g_t, g_s);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int transpose_launch(const float* W, int rows, int cols, float* Wt, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, st, W, rows, cols, Wt);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
 int sdf_prep_launch(const float* inv_t, const float* so3_t, const float* wlen, const float* bias, const float* z_so3,
                     const float* z_inv, int B, int L, int out_dim, float* A, float* beff, hipStream_t st) {
     hipLaunchKernelGGL(sdf_prep_kernel, dim3(cdiv(out_dim, 256), B), dim3(256), 0, st, inv_t, so3_t, wlen, bias, z_so3, z_inv, L,

@@ -1,9 +1,10 @@
 """Mirror of /root/reference/lib_more/more_solver.py (class More_Solver) for the accelerated path:
 _solve_object_matching, _solve_pairwise_registration(optim=False), _transform_latent and the encode / match / register
 part of _solve_end2end, plus batched variants the reference lacks (it registers one pair at a time with B=1 encoder
-calls, eval_flyingshape.py:130).  The optimisation-based branches (optim=True: torchlie + geomloss + decoder backward;
-_optimize_code) are a SURVEY.md 8(f-1) "next" row and raise NotImplementedError; mesh extraction (_mesh_from_latent /
-_mesh_from_pc, 8 f-2) runs MISE and marching cubes on the device (livingscenes_amd/mesh_extractor2.py)."""
+calls, eval_flyingshape.py:130).  _optimize_code (code half) runs with the decoder forward / backward in the
+HIP library; the SE(3) / Sinkhorn registration branch (optim=True: torchlie + geomloss + roma, none installed) raises
+NotImplementedError; mesh extraction (_mesh_from_latent / _mesh_from_pc, 8 f-2) runs MISE and marching cubes on the device
+(livingscenes_amd/mesh_extractor2.py)."""
 import logging
 
 import torch
@@ -87,8 +88,30 @@ class More_Solver:
             R, t = self._icp(pc1, pc2, R, t)
         return R, t
 
-    def _optimize_code(self, code, pc, mask):
-        raise NotImplementedError("latent-code optimisation (decoder backward + Adam) is a SURVEY.md 8(f-1) 'next' row")
+    def _optimize_code(self, code, pc, mask, n_steps=200):
+        """more_solver.py:191-228: Adam on (z_inv, t, z_so3) against MSE(sdf(pc; code), 0), lr 1e-5 / 1e-4 / 5e-4, x0.1 at step
+        160, best-loss snapshot.  The decoder forward / backward run in the HIP library (ls_sdf_decode_train / ls_sdf_backward)."""
+        valid_pc = pc.T[mask.squeeze()].squeeze()[None]
+        pc, _ = fps(valid_pc, K=self.cfg["shape_priors"]["n_input_point"])
+        params = [{"params": code["z_inv"], "lr": 1e-5}, {"params": code["t"], "lr": 1e-4}, {"params": code["z_so3"], "lr": 5e-4}]
+        for p in params:
+            p["params"].requires_grad_(True)
+        optimizer = torch.optim.Adam(params)
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[160], gamma=0.1)
+        loss_fn = torch.nn.MSELoss()
+        min_loss, best_code = 100.0, None
+        for _ in range(n_steps):
+            optimizer.zero_grad()
+            sdf_output = self.model.decoder(pc, None, code, return_sdf=True)
+            loss = loss_fn(sdf_output, torch.zeros_like(sdf_output))
+            loss.backward()
+            optimizer.step()
+            scheduler.step()
+            if loss < min_loss:   # (the snapshot is taken AFTER the step, as in the reference)
+                min_loss = loss.item()
+                best_code = {k: code[k].detach() for k in ("z_inv", "z_so3", "s", "t")}
+            optimizer.zero_grad()
+        return best_code
 
     def _mesh_from_latent(self, latent_code):
         """more_solver.py:37-58: mesh of the canonical shape (t = 0, s = 1), then scaled and moved to the instance pose."""

@@ -68,10 +68,31 @@ class FieldWrapper(nn.Module):
 
     def forward(self, query, z_none, c, return_sdf=False):
         hip = self._owner().hip_model()
-        sdf = hip.sdf_decode(query, c["z_so3"], c["z_inv"], c["s"], c["t"])
+        args = (query, c["z_so3"], c["z_inv"], c["s"], c["t"])
+        if torch.is_grad_enabled() and any(torch.is_tensor(a) and a.requires_grad for a in args):
+            sdf = _SdfDecode.apply(hip, *args)      # differentiable w.r.t. the code and the query (csrc: ls_sdf_backward)
+        else:
+            sdf = hip.sdf_decode(*args)
         if return_sdf:
             return sdf
         return dist.Bernoulli(logits=self.sdf2occ_factor * sdf)
+
+
+class _SdfDecode(torch.autograd.Function):
+    """FieldWrapper.forward as an autograd node: what the reference gets from autograd through its PyTorch decoder
+    (more_solver.py:212-216 loss.backward()) is computed by ls_sdf_decode_train / ls_sdf_backward."""
+
+    @staticmethod
+    def forward(ctx, hip, query, z_so3, z_inv, s, t):
+        sdf, saved = hip.sdf_decode_train(query.detach(), z_so3.detach(), z_inv.detach(), s.detach(), t.detach())
+        ctx.hip, ctx.saved, ctx.t_shape = hip, saved, t.shape
+        ctx.need_q = query.requires_grad
+        return sdf
+
+    @staticmethod
+    def backward(ctx, grad_sdf):
+        gq, gso3, ginv, gs, gt = ctx.hip.sdf_backward(ctx.saved, grad_sdf.contiguous(), need_query_grad=ctx.need_q)
+        return None, gq, gso3, ginv, gs, gt.reshape(ctx.t_shape)
 
 
 class Shape_Prior(nn.Module):

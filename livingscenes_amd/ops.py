@@ -230,3 +230,31 @@ class HipModel:
             if mc != M:
                 sdf[:, m0:m0 + mc] = out
         return sdf
+
+    def sdf_decode_train(self, query, z_so3, z_inv, s, t):
+        """Forward that keeps the activations: -> (sdf [B,M], saved) where ``saved`` feeds sdf_backward (its workspace is
+        private to the call, so several graphs can be alive at once)."""
+        query = _f32(query)
+        B, M, _ = query.shape
+        z_so3, z_inv, s, t = _f32(z_so3), _f32(z_inv), _f32(s), _f32(t.reshape(B, 3))
+        sdf = torch.empty(B, M, dtype=torch.float32, device=query.device)
+        need = load().ls_sdf_train_workspace_bytes(self._h, B, M)
+        ws = torch.empty(need, dtype=torch.uint8, device=query.device)
+        with torch.cuda.device(query.device):
+            check(load().ls_sdf_decode_train(self._h, ptr(query), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, M, ptr(sdf), ptr(ws),
+                                             ws.numel(), stream_ptr(query.device)), "ls_sdf_decode_train")
+        return sdf, (query, z_so3, z_inv, s, t, sdf, ws)
+
+    def sdf_backward(self, saved, grad_sdf, need_query_grad=True):
+        """-> (grad_query [B,M,3] or None, grad_z_so3 [B,c,3], grad_z_inv [B,c], grad_s [B], grad_t [B,3])."""
+        query, z_so3, z_inv, s, t, sdf, ws = saved
+        B, M, _ = query.shape
+        dev = query.device
+        g = _f32(grad_sdf).reshape(B, M)
+        gq = torch.empty(B, M, 3, dtype=torch.float32, device=dev) if need_query_grad else None
+        gso3, ginv = torch.empty_like(z_so3), torch.empty_like(z_inv)
+        gs, gt = torch.empty_like(s), torch.empty_like(t)
+        with torch.cuda.device(dev):
+            check(load().ls_sdf_backward(self._h, ptr(query), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, M, ptr(sdf), ptr(g), ptr(ws),
+                                         ws.numel(), ptr(gq), ptr(gso3), ptr(ginv), ptr(gs), ptr(gt), stream_ptr(dev)), "ls_sdf_backward")
+        return gq, gso3, ginv, gs, gt

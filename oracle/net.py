@@ -244,3 +244,19 @@ def field_query(w_dec, cfg_dec, query, code):
     inv_query = torch.cat([inner, length], 1).transpose(2, 1)
     inp = torch.cat([z_inv[:, None, :].expand(-1, M, -1), inv_query], -1)
     return decoder_forward(w_dec, cfg_dec, inp)
+
+
+def field_query_with_grad(w_dec, cfg_dec, query, code):
+    """field_query with autograd enabled (decoder_forward is wrapped in no_grad for inference): the reference's training-time
+    graph through FieldWrapper.forward + DeepSDF_Decoder.forward, used as the oracle of ls_sdf_backward
+    (more_solver.py:212-216: loss.backward() w.r.t. the code)."""
+    B, M, _ = query.shape
+    z_so3, z_inv = code["z_so3"], code["z_inv"]
+    q = (query - code["t"]) / code["s"][:, None, None]
+    inner = (q.unsqueeze(1) * z_so3.unsqueeze(2)).sum(dim=-1)
+    length = q.norm(dim=-1).unsqueeze(1)
+    inv_query = torch.cat([inner, length], 1).transpose(2, 1)
+    inp = torch.cat([z_inv[:, None, :].expand(-1, M, -1), inv_query], -1)
+    with torch.enable_grad():
+        return decoder_forward.__wrapped__(w_dec, cfg_dec, inp)
+

@@ -420,3 +420,36 @@ def test_sdf_dense_grid_mise_resolution():
     d = _dev()
     sdf = m.sdf_decode(q.to(d), code["z_so3"].to(d), code["z_inv"].to(d), code["s"].to(d), code["t"].to(d), max_ws_bytes=64 << 20)
     assert sdf.shape == (B, 33 ** 3) and relerr(sdf, ref) < TOL
+
+
+# ------------------------------------------------------------------------------------------------ decoder backward
+@pytest.mark.parametrize("which,B,M", [("small", 2, 300), ("small", 1, 1024), ("full", 2, 512)])
+def test_sdf_backward_vs_oracle_autograd(which, B, M):
+    """ls_sdf_decode_train / ls_sdf_backward vs torch autograd through the oracle's FieldWrapper + DeepSDF restatement (CPU):
+    gradients of a random linear functional of the SDF w.r.t. query, z_so3, z_inv, s, t within TOL of their max-norm."""
+    from livingscenes_amd import ops, packing
+    from oracle import net
+    ecfg, dcfg = (synth.small_encoder_cfg(), synth.small_decoder_cfg()) if which == "small" else (synth.default_encoder_cfg(), synth.default_decoder_cfg())
+    ew, dw = synth.make_encoder_weights(ecfg, 3), synth.make_decoder_weights(dcfg, 3)
+    desc, blob = packing.pack_model(ew, ecfg, dw, dcfg)
+    m = ops.HipModel(desc, blob, _dev())
+    g = torch.Generator().manual_seed(B * 31 + M)
+    L = dcfg["latent_size"]
+    code = {"z_so3": torch.randn(B, L, 3, generator=g) * 0.05, "z_inv": torch.randn(B, L, generator=g) * 0.05,
+            "s": torch.rand(B, generator=g) * 0.5 + 0.75, "t": torch.randn(B, 1, 3, generator=g) * 0.1}
+    q = synth.make_queries(B, M, seed=5) * code["s"][:, None, None] + code["t"]
+    q[0, 0] = code["t"][0, 0]                      # a query exactly at the instance origin: |q| = 0, norm gradient defined as 0
+    gsdf = torch.randn(B, M, generator=g)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in code.items()}
+    ql = q.clone().requires_grad_(True)
+    sdf_ref = net.field_query_with_grad(dw, dcfg, ql, leaves)
+    (sdf_ref * gsdf).sum().backward()
+    dev = _dev()
+    sdf, saved = m.sdf_decode_train(q.to(dev), code["z_so3"].to(dev), code["z_inv"].to(dev), code["s"].to(dev), code["t"].to(dev))
+    assert relerr(sdf, sdf_ref.detach()) < TOL
+    gq, gso3, ginv, gs, gt = m.sdf_backward(saved, gsdf.to(dev))
+    assert relerr(gso3, leaves["z_so3"].grad) < TOL
+    assert relerr(ginv, leaves["z_inv"].grad) < TOL
+    assert relerr(gt, leaves["t"].grad.reshape(B, 3)) < TOL
+    assert relerr(gs, leaves["s"].grad) < TOL
+    assert relerr(gq, ql.grad) < TOL

@@ -280,3 +280,43 @@ def test_more_solver_mesh_from_latent(small_prior):
     ref = solver.mesh_extractor.extract_mesh(solver.mesh_extractor.eval_grid(canon, sp.decoder), None, canon)
     want = np.asarray(ref.vertices) * float(s0) + t0.view(-1).cpu().numpy()
     assert len(mesh.faces) > 50 and np.allclose(np.asarray(mesh.vertices), want, rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ code optimisation
+@pytest.mark.gpu
+def test_more_solver_optimize_code_vs_oracle_loop(small_prior):
+    """More_Solver._optimize_code (more_solver.py:191-228: Adam on z_inv / t / z_so3 against the SDF at the observed points) with
+    the decoder forward + backward in the HIP library vs the same loop on the CPU oracle with torch autograd."""
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    from oracle import net
+    sp, (ecfg, dcfg, ew, dw) = small_prior
+    dev = _dev()
+    x = synth.make_instances(1, 128, seed=31)
+    code = sp.encode(x.to(dev))
+    pc = x[0].to(dev)                                           # [3, N]
+    mask = torch.ones(1, 128, dtype=torch.bool, device=dev)
+    solver = More_Solver({"shape_priors": {"n_input_point": 128}}, model=sp)
+    start = {k: v.detach().clone() for k, v in code.items()}
+    steps = 25
+    best = solver._optimize_code({k: v.detach().clone() for k, v in code.items()}, pc, mask, n_steps=steps)
+    # oracle loop (same FPS subset: n_input_point == N keeps every point, order by FPS)
+    from livingscenes_amd.model_utils import fps
+    pts, _ = fps(pc.T[None], K=128)
+    c = {k: v.cpu().clone() for k, v in start.items()}
+    params = [{"params": c["z_inv"], "lr": 1e-5}, {"params": c["t"], "lr": 1e-4}, {"params": c["z_so3"], "lr": 5e-4}]
+    for p in params:
+        p["params"].requires_grad_(True)
+    opt = torch.optim.Adam(params)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[160], gamma=0.1)
+    for _ in range(steps):
+        opt.zero_grad()
+        sdf = net.field_query_with_grad(dw, dcfg, pts.cpu(), c)
+        loss = torch.nn.functional.mse_loss(sdf, torch.zeros_like(sdf))
+        loss.backward()
+        opt.step()
+        sched.step()
+    for k in ("z_inv", "z_so3", "t"):
+        moved = float((c[k].detach() - start[k].cpu()).abs().max())
+        assert moved > 0
+        assert float((best[k].cpu() - c[k].detach()).abs().max()) < 2e-3 * moved + 1e-7, k
+    assert torch.equal(best["s"].cpu(), start["s"].cpu())
