@@ -196,6 +196,14 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
                     int B, int M, const float* sdf, const float* grad_sdf, void* workspace, size_t workspace_bytes,
                     float* grad_query, float* grad_z_so3, float* grad_z_inv, float* grad_s, float* grad_t, void* stream);
 
+/* SURVEY.md 8 (f-1), registration half: the log-domain softmin of entropic OT with cost |x-y|^2/2, the primitive of
+ * geomloss.SamplesLoss('sinkhorn', p=2) as used at lib_more/more_solver.py:146,158 (geomloss itself is absent: the
+ * epsilon-scaling loop around this primitive, livingscenes_amd/sinkhorn.py, is restated from memory -- parity unpinned):
+ *   out[i] = -eps log sum_j exp(h[j] - |x_i - y_j|^2 / (2 eps));  grad_x[i] (nullable) = d out[i] / d x_i
+ * x [N,3], y [M,3], h [M] (log-weight + potential / eps). */
+int ls_sinkhorn_softmin_f32(const float* x, const float* y, const float* h, int N, int M, float eps, float* out, float* grad_x,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md 8 (f-2), first half: the MISE octree that decides WHICH lattice points of the (R+1)^3 grid the decoder has to
  * evaluate (R = resolution_0 << depth) and assembles the dense value grid -- class MISE of

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ls_sdf_train_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_sdf_decode_train": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
     "ls_sdf_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
+    "ls_sinkhorn_softmin_f32": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
     "ls_mise_state_bytes": (_SZ, [_I, _I]),
     "ls_mise_lattice_points": (ctypes.c_longlong, [_I, _I]),
     "ls_mise_init": (_I, [_P, _SZ, _I, _I, _P]),

@@ -1,9 +1,9 @@
 """Mirror of /root/reference/lib_more/more_solver.py (class More_Solver) for the accelerated path:
 _solve_object_matching, _solve_pairwise_registration(optim=False), _transform_latent and the encode / match / register
 part of _solve_end2end, plus batched variants the reference lacks (it registers one pair at a time with B=1 encoder
-calls, eval_flyingshape.py:130).  _optimize_code (code half) runs with the decoder forward / backward in the
-HIP library; the SE(3) / Sinkhorn registration branch (optim=True: torchlie + geomloss + roma, none installed) raises
-NotImplementedError; mesh extraction (_mesh_from_latent / _mesh_from_pc, 8 f-2) runs MISE and marching cubes on the device
+calls, eval_flyingshape.py:130).  _optimize_code and the optim=True registration branch run with the decoder
+forward / backward and the Sinkhorn softmins in the HIP library; torchlie / geomloss / roma are not installed, so the SE(3)
+update and the Sinkhorn divergence of that branch follow this build's documented definitions (parity unpinned); mesh extraction (_mesh_from_latent / _mesh_from_pc, 8 f-2) runs MISE and marching cubes on the device
 (livingscenes_amd/mesh_extractor2.py)."""
 import logging
 
@@ -59,9 +59,68 @@ class More_Solver:
     def _solve_pairwise_registration(self, pc1_full, pc2_full, optim=False):
         """more_solver.py:95-189.  pc1 [1,N,3], pc2 [1,M,3] -> R [1,3,3], t [1,3,1] mapping pc1 -> pc2."""
         if optim:
-            raise NotImplementedError("optimisation-based registration (torchlie/geomloss/decoder backward) is a "
-                                      "SURVEY.md 8(f-1) 'next' row; use optim=False")
+            return self._solve_pairwise_registration_optim(pc1_full, pc2_full)
         return self._solve_pairwise_registration_batch([pc1_full[0]], [pc2_full[0]])
+
+    def _solve_pairwise_registration_optim(self, pc1_full, pc2_full):
+        """more_solver.py:118-189 (optim=True): refine the Kabsch pose by Adam on SE(3) against SmoothL1(sdf(g.src; shared code))
+        + Sinkhorn(g.src, tgt), best-loss snapshot, then ICP.  The decoder forward / backward and the Sinkhorn softmins run in the
+        HIP library.  torchlie / geomloss / roma are not installed: the manifold update and the Sinkhorn divergence follow this
+        build's documented definitions (PARITY UNPINNED): left-multiplicative retraction g <- exp(-step) g with Adam
+        moments kept on the 6-vector (v, omega) of the left tangent space; livingscenes_amd/sinkhorn.py."""
+        from ..sinkhorn import sinkhorn_divergence
+        n_in = self.cfg["shape_priors"]["n_input_point"]
+        assert self.cfg.get("fps", {}).get("n_init", 1) == 1, "fps.n_init > 1 is not used by the released configs"
+        pc1, _ = fps(pc1_full, K=n_in)
+        pc2, _ = fps(pc2_full, K=n_in)
+        with torch.no_grad():
+            code1 = self.model.encode(pc1.transpose(-1, -2).contiguous())
+            code2 = self.model.encode(pc2.transpose(-1, -2).contiguous())
+            code1_se3, code2_se3 = code1["z_so3"] + code1["t"], code2["z_so3"] + code2["t"]
+            R, t, _, _ = kabsch_transformation_estimation(code1_se3, code2_se3)
+            sdf_error1 = self.model.decoder(pc1, None, code1, return_sdf=True).abs().mean()
+            sdf_error2 = self.model.decoder(pc2, None, code2, return_sdf=True).abs().mean()
+        reverse = bool(sdf_error1 < sdf_error2)            # keep the code that explains its own points better (:124-135)
+        if reverse:
+            shared_code, src_pc, tgt_pc = code1, pc2, pc1
+            with torch.no_grad():
+                R, t, _, _ = kabsch_transformation_estimation(code2_se3, code1_se3)
+        else:
+            shared_code, src_pc, tgt_pc = code2, pc1, pc2
+        shared_code = {k: v.detach() for k, v in shared_code.items()}
+        reg = self.cfg["registration"]
+        lr0, n_steps, stop = reg["step_size"]["so3"], reg["n_steps"], reg["early_stop_threshold"]
+        g = torch.cat([R, t], 2)[0].detach().clone()        # [3,4]
+        init_R = g[:, :3].clone()
+        m1 = torch.zeros(6, device=g.device)
+        m2 = torch.zeros(6, device=g.device)
+        b1, b2, eps_adam = 0.9, 0.999, 1e-8
+        min_loss, best_g = 100.0, g.clone()
+        src = src_pc[0]
+        for i in range(n_steps):
+            lr = lr0 * (0.1 ** sum(i >= ms for ms in (300, 340, 380)))          # MultiStepLR([300,340,380], 0.1), :143
+            query = (src @ g[:, :3].T + g[:, 3]).detach().requires_grad_(True)
+            sdf = self.model.decoder(query[None], None, shared_code, return_sdf=True)
+            loss = torch.nn.functional.smooth_l1_loss(sdf, torch.zeros_like(sdf)) + sinkhorn_divergence(query[None], tgt_pc)
+            loss.backward()
+            G = query.grad
+            with torch.no_grad():
+                grad = torch.cat([G.sum(0), torch.cross(query.detach(), G, dim=1).sum(0)])   # d loss / d (v, omega), left tangent
+                m1 = b1 * m1 + (1 - b1) * grad
+                m2 = b2 * m2 + (1 - b2) * grad * grad
+                step = lr * (m1 / (1 - b1 ** (i + 1))) / ((m2 / (1 - b2 ** (i + 1))).sqrt() + eps_adam)
+                g = _se3_exp(-step) @ torch.cat([g, g.new_tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+                g = g[:3]
+                if float(loss) < min_loss:                   # snapshot AFTER the step, as the reference (:166-168)
+                    min_loss, best_g = float(loss), g.clone()
+                cosang = ((g[:, :3] @ init_R.T).diagonal().sum() - 1) / 2
+                if float(torch.acos(cosang.clamp(-1, 1))) > stop:   # radians against the configured number, as the reference (:172-173)
+                    break
+        if reverse:
+            Rb = best_g[:, :3].T
+            best_g = torch.cat([Rb, -(Rb @ best_g[:, 3:4])], 1)
+        R, t = best_g[None, :, :3].contiguous(), best_g[None, :, 3:4].contiguous()
+        return self._icp(pc1, pc2, R, t)
 
     def _solve_pairwise_registration_batch(self, pcs1, pcs2, icp=True):
         """Batched form: lists of clouds [Ni,3] / [Mi,3] -> R [P,3,3], t [P,3,1].  One ragged FPS launch per side,
@@ -156,3 +215,21 @@ class More_Solver:
                 cur = {key: res_codes[key][j][None] for key in ("z_so3", "z_inv", "s", "t")}
                 out["codes"][i] = self._transform_latent(cur, inverse(T[k:k + 1]))
         return out
+
+
+def _se3_exp(xi):
+    """exp of the twist (v, omega) in R^6 -> [4,4] (Rodrigues + the left Jacobian for the translation)."""
+    v, w = xi[:3], xi[3:]
+    th = w.norm()
+    K = xi.new_zeros(3, 3)
+    K[0, 1], K[0, 2], K[1, 0], K[1, 2], K[2, 0], K[2, 1] = -w[2], w[1], w[2], -w[0], -w[1], w[0]
+    eye = torch.eye(3, device=xi.device, dtype=xi.dtype)
+    if float(th) < 1e-6:
+        R, V = eye + K, eye + 0.5 * K
+    else:
+        a, b, c = torch.sin(th) / th, (1 - torch.cos(th)) / th ** 2, (th - torch.sin(th)) / th ** 3
+        R, V = eye + a * K + b * (K @ K), eye + b * K + c * (K @ K)
+    out = torch.eye(4, device=xi.device, dtype=xi.dtype)
+    out[:3, :3], out[:3, 3] = R, V @ v
+    return out
+

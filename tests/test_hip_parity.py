@@ -453,3 +453,26 @@ def test_sdf_backward_vs_oracle_autograd(which, B, M):
     assert relerr(gt, leaves["t"].grad.reshape(B, 3)) < TOL
     assert relerr(gs, leaves["s"].grad) < TOL
     assert relerr(gq, ql.grad) < TOL
+
+
+# ------------------------------------------------------------------------------------------------ Sinkhorn (UNPINNED)
+@pytest.mark.parametrize("N,M,shift", [(1024, 1024, 0.05), (300, 517, 0.3), (64, 64, 0.0)])
+def test_sinkhorn_divergence_vs_oracle(N, M, shift):
+    """csrc/sinkhorn.hip + the epsilon-scaling loop vs the torch-CPU restatement of the same definition (PARITY UNPINNED w.r.t.
+    geomloss, see oracle/sinkhorn.py): loss and its gradient w.r.t. the source points; identical clouds give ~0."""
+    from livingscenes_amd.sinkhorn import sinkhorn_divergence
+    from oracle import sinkhorn as osk
+    g = torch.Generator().manual_seed(N + M)
+    y = torch.rand(M, 3, generator=g) - 0.5
+    x = (y[torch.randperm(M, generator=g)[:N] % M] if N <= M else torch.rand(N, 3, generator=g) - 0.5) + shift * torch.randn(N, 3, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = osk.sinkhorn_divergence(xr, y)
+    ref.backward()
+    xh = x.to(_dev()).requires_grad_(True)
+    got = sinkhorn_divergence(xh[None], y.to(_dev())[None])
+    got.backward()
+    scale = max(abs(float(ref)), 1e-6)
+    assert abs(float(got) - float(ref)) < 2e-4 * scale + 2e-7
+    assert relerr(xh.grad, xr.grad) < 5e-4 or float(xr.grad.abs().max()) < 1e-7
+    if shift == 0.0:
+        assert abs(float(got)) < 1e-5

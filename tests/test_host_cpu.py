@@ -245,3 +245,17 @@ def test_flyingshape_disk_format_round_trip(tmp_path):
     for k in ("ref", "rescan", "ref_T", "rescan_T"):
         assert np.array_equal(got[k].numpy(), want[k].numpy().astype(np.float32)), k
     assert len(list(ds)) == 3
+
+
+def test_se3_exp_matches_matrix_exponential():
+    """The retraction of the optimisation-based registration (More_Solver): exp of a twist (v, omega)."""
+    import torch
+    from livingscenes_amd.lib_more.more_solver import _se3_exp
+    g = torch.Generator().manual_seed(0)
+    for scale in (1e-8, 1e-3, 0.3, 2.5):
+        xi = torch.randn(6, generator=g, dtype=torch.float64) * scale
+        A = torch.zeros(4, 4, dtype=torch.float64)
+        w = xi[3:]
+        A[:3, :3] = torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=torch.float64)
+        A[:3, 3] = xi[:3]
+        assert torch.allclose(_se3_exp(xi), torch.matrix_exp(A), atol=1e-12)
