@@ -189,13 +189,15 @@ class More_Solver:
         return {"z_so3": (code["z_so3"] @ R.transpose(-1, -2)).detach().clone(), "z_inv": code["z_inv"].detach().clone(),
                 "t": transform(tsfm, code["t"]).detach().clone(), "s": code["s"].detach().clone()}
 
-    def _solve_end2end(self, ref, rescan, optim=False, mesh=False):
-        """more_solver.py:246-299 without the mesh step: encode both scenes (one batch each), sequential matching,
-        batched registration of the matched pairs, transformed latent codes.  ref / rescan: {'pc' [n,3,Nmax], 'pc_mask'}."""
+    def _solve_end2end(self, ref, rescan, optim=False, mesh=None):
+        """more_solver.py:246-299: encode both scenes (one batch each), sequential matching, registration of the matched pairs,
+        transformed latent codes and (``mesh``, default = whether cfg has a mesh_extractor, as the reference always meshes) their
+        meshes.  ref / rescan: {'pc' [n,3,Nmax], 'pc_mask'}.  optim=False registers all pairs in one batched call; optim=True
+        runs the per-pair optimisation loop like the reference."""
         if ref is None:
             return None
-        if optim or mesh:
-            raise NotImplementedError("optim / mesh branches are SURVEY.md 8(f) 'next' rows")
+        if mesh is None:
+            mesh = self.mesh_extractor is not None
 
         def valid_clouds(scene):
             return [pc.T[mask.reshape(-1).bool()] for pc, mask in zip(scene["pc"], scene["pc_mask"])]
@@ -205,15 +207,21 @@ class More_Solver:
         matches = self._solve_object_matching(ref_codes, res_codes, "sequential")
         m0 = matches["matches0"]
         out = {"ref_pc_lst": ref_full, "rescan_pc_lst": res_full, "matches": m0, "registration": [None] * len(ref_full),
-               "codes": [None] * len(ref_full)}
+               "codes": [None] * len(ref_full), "mesh_lst": [None] * len(ref_full)}
         pairs = [(i, int(j)) for i, j in enumerate(m0.tolist()) if j >= 0]
         if pairs:
-            R, t = self._solve_pairwise_registration_batch([ref_full[i] for i, _ in pairs], [res_full[j] for _, j in pairs])
+            if optim:
+                Rt = [self._solve_pairwise_registration(ref_full[i][None], res_full[j][None], optim=True) for i, j in pairs]
+                R, t = torch.cat([r for r, _ in Rt], 0), torch.cat([tt for _, tt in Rt], 0)
+            else:
+                R, t = self._solve_pairwise_registration_batch([ref_full[i] for i, _ in pairs], [res_full[j] for _, j in pairs])
             T = Rt_to_SE3(R, t)
             for k, (i, j) in enumerate(pairs):
                 out["registration"][i] = T[k:k + 1]
                 cur = {key: res_codes[key][j][None] for key in ("z_so3", "z_inv", "s", "t")}
                 out["codes"][i] = self._transform_latent(cur, inverse(T[k:k + 1]))
+                if mesh:
+                    out["mesh_lst"][i] = self._mesh_from_latent(out["codes"][i])
         return out
 
 

@@ -142,6 +142,14 @@ def test_more_solver_matching_registration_end2end(small_prior):
     for i, j in enumerate(out["matches"].tolist()):
         if j >= 0:
             assert out["registration"][i].shape == (1, 4, 4) and abs(float(torch.det(out["registration"][i][0, :3, :3])) - 1) < 1e-3
+    assert out["mesh_lst"] == [None] * 4          # no mesh_extractor configured
+    # with a mesh extractor every matched instance also gets the mesh of its transformed code (more_solver.py:284-296)
+    solver_m = More_Solver(dict(solver.cfg, mesh_extractor=dict(threshold=0.5, resolution0=8, upsampling_steps=1, padding=0.1)), model=sp)
+    out_m = solver_m._solve_end2end(scene(ref_x), scene(res_x))
+    assert torch.equal(out_m["matches"], out["matches"])
+    for i, j in enumerate(out_m["matches"].tolist()):
+        if j >= 0:
+            assert hasattr(out_m["mesh_lst"][i], "vertices") and hasattr(out_m["mesh_lst"][i], "faces")
 
 
 def test_flyingshape_style_harness_vs_oracle(small_prior):
