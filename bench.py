@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--cpu-instances", type=int, default=8, help="bounded sample for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads for the CPU baseline: the reference's op sequence peaks at ~16 threads on the GPU box's "
-                         "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; scripts/cpu_threads_probe.py)")
+                         "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; tests/tools/cpu_threads_probe.py)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fma-variant", action="store_true", help="skip the secondary fused-multiply-add k-NN timing")
     ap.add_argument("--inflight", type=int, default=3,

@@ -56,7 +56,3 @@ for _ in range(5): v, f = marching_cubes(vol, level)
 torch.cuda.synchronize(); dk = (time.perf_counter() - t0) / 5
 print(f"marching cubes 131^3: {dk*1e3:.2f} ms on the device (two passes incl. the count read-back), extract_mesh incl. host copies "
       f"{dm*1e3:.1f} ms; mesh {len(mesh.vertices)} vertices / {len(mesh.faces)} faces")
-t0 = time.perf_counter()
-from oracle import mcubes as om   # CPU restatement (numpy) for scale only
-vo, fo = om.marching_cubes(vol.cpu().numpy(), level)
-print(f"numpy oracle on the host: {(time.perf_counter()-t0)*1e3:.0f} ms; identical: {np.array_equal(vo, v.cpu().numpy()) and np.array_equal(fo, f.cpu().numpy())}")
