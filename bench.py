@@ -324,7 +324,8 @@ def main():
                        "instances_per_step_per_gpu": B, "points": N, "parallelism": f"instance-sharded x{world}",
                        "steps_in_flight": nfl,
                        "knn_arithmetic": "canonical (separately rounded mul/add)"},
-            "check": {"matches_identity": f"{n_correct}/{n_obj}", "rotations_proper": det_ok},
+            "check": {"matches_identity": f"{n_correct}/{n_obj}", "rotations_proper": det_ok,
+                      "note": "sanity of the timed work only: weights are untrained (deterministic random init), so the matcher is not expected to recover the identity permutation"},
             "variants": None if dt_fma is None else {
                 "knn_fused_multiply_add": {"value": total_objects / dt_fma, "ms_per_step": dt_fma / args.steps * 1e3,
                                            "note": "same steps with LS_FLAG_CONTRACT_FMA (nvcc-style rounding of dist += diff*diff); "
