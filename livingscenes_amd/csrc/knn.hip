@@ -237,7 +237,10 @@ static int knn_choose_splits(int B, int Nd, int Ns) {
     const int qtiles = cdiv(Nd, KNN_TQ), ctiles = cdiv(Ns, KNN_TS);
     const int blocks = B * qtiles;
     if (blocks >= 512 || ctiles < 2) return 1;  // >= 2 workgroups per CU: splitting would only add merge work (and un-seeded splits)
-    int sp = cdiv(1024, blocks);
+    // one workgroup per CU is the target: every split re-stages the 64 x 3C query tile and only split 0 is seeded, so at the
+    // layer-4 shape (128 x 512, D = 192) 2 splits run in 0.14 ms where 8 splits (1024 workgroups) took 0.23 ms and 1 split 0.19 ms
+    static const int target = getenv("LS_KNN_SPLIT_TARGET") ? atoi(getenv("LS_KNN_SPLIT_TARGET")) : 256;
+    int sp = cdiv(target, blocks);
     if (sp > ctiles) sp = ctiles;
     if (sp > 16) sp = 16;
     return sp < 1 ? 1 : sp;
