@@ -24,7 +24,13 @@ import os
 import sys
 import time
 
-import torch
+# Each in-flight step drives one caller stream plus two library side streams; ROCm maps HIP streams round-robin onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels that share a hardware queue serialise.  Measured on MI355X
+# (DESIGN.md 6): 4 queues / 3 steps in flight 25.9k obj/s, 16 queues / 8 steps 28.8k, 32 queues worse.  Must be set before the
+# HIP runtime initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -117,7 +123,7 @@ def main():
                          "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; tests/tools/cpu_threads_probe.py)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fma-variant", action="store_true", help="skip the secondary fused-multiply-add k-NN timing")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent steps kept in flight on separate HIP streams (each with its own model handle and "
                          "workspace): one step's low-occupancy kernels (FPS, heads, matcher) overlap another's big ones")
     args = ap.parse_args()
@@ -324,7 +330,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]+[2]: batch={B} instances x N={N} pts per GPU = {n_obj}-object scene + rescan; "
                                    f"VN-DGCNN encode, {n_obj}x{n_obj} sequential matching, {n_obj} Kabsch poses",
                        "instances_per_step_per_gpu": B, "points": N, "parallelism": f"instance-sharded x{world}",
-                       "steps_in_flight": nfl,
+                       "steps_in_flight": nfl, "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "knn_arithmetic": "canonical (separately rounded mul/add)"},
             "check": {"matches_identity": f"{n_correct}/{n_obj}", "rotations_proper": det_ok,
                       "note": "sanity of the timed work only: weights are untrained (deterministic random init), so the matcher is not expected to recover the identity permutation"},
