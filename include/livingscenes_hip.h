@@ -184,6 +184,14 @@ size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M);
 int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s,
                   const float* t, int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Ragged form of ls_sdf_decode: R query rows of B instances packed back to back (rows of one instance contiguous), row_inst [R]
+ * int32 = instance of each row.  Used by the batched MISE rounds, where every instance asks for a different number of points
+ * (the reference evaluates one instance at a time, occnet_utils/mesh_extractor2.py:116-131).  sdf [R]. */
+size_t ls_sdf_rows_workspace_bytes(const ls_model_t* m, int B, long long R);
+int ls_sdf_decode_rows(ls_model_t* m, const float* query, const int32_t* row_inst, const float* z_so3, const float* z_inv,
+                       const float* s, const float* t, int B, long long R, float* sdf, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* SURVEY.md 8 (f-1), the autograd half: what `loss.backward()` computes in More_Solver._optimize_code
  * (lib_more/more_solver.py:191-228) through FieldWrapper.forward (model_utils.py:230-263) and DeepSDF_Decoder.forward
  * (deepsdf_decoder.py:78-123).  ls_sdf_decode_train = ls_sdf_decode keeping every layer's activations in `workspace`

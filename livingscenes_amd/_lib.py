@@ -88,6 +88,8 @@ SIGNATURES = {
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ls_sdf_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_sdf_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "ls_sdf_rows_workspace_bytes": (_SZ, [_P, _I, ctypes.c_longlong]),
+    "ls_sdf_decode_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, ctypes.c_longlong, _P, _P, _SZ, _P]),
     "ls_sdf_train_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_sdf_decode_train": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
     "ls_sdf_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P]),

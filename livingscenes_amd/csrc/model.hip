@@ -42,6 +42,8 @@ int sdf_prep_launch(const float*, const float*, const float*, const float*, cons
 int sdf_affine_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
                       hipStream_t);
 int sdf_out_launch(const float*, int, int, const float*, const float*, long long, float*, hipStream_t);
+int sdf_affine_rows_launch(const float*, const int32_t*, const float*, const float*, const float*, const float*, long long, int, int, int,
+                           float*, hipStream_t);
 int sdf_out_bwd_launch(const float*, const float*, const float*, const float*, int, int, long long, float*, hipStream_t);
 int relu_mask_launch(float*, const float*, long long, int, int, hipStream_t);
 int sdf_affine_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*, float*,
@@ -479,7 +481,6 @@ size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M) {
     b += 2 * align_up((size_t)B * w * 4 * 4, 256);   // A0, A4
     b += 2 * align_up((size_t)B * w * 4, 256);       // beff0, beff4
     b += 2 * align_up((size_t)B * M * w * 4, 256);   // ping-pong activations
-    b += align_up(sdf_gemm_scratch(m->d, (long long)B * M) * 4, 256) + 256;   // split-K slabs (small M only)
     return b;
 }
 // training form: every layer's activations are kept for the backward pass, plus its scratch
@@ -517,7 +518,9 @@ static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, in
         float* hA = take((size_t)B * M * w * 4);
         float* hB = take((size_t)B * M * w * 4);
         for (int l = 0; l < nl - 1; ++l) sb.h[l] = (l & 1) ? hB : hA;
-        sb.gws = sdf_gemm_scratch(d, (long long)B * M) ? take(sdf_gemm_scratch(d, (long long)B * M) * 4) : nullptr;
+        // inference never splits K: a query's SDF must not depend on how many other queries share the call (MISE evaluates
+        // the same lattice point in calls of very different sizes; split-K changes the fp32 summation order)
+        sb.gws = nullptr;
         return sb;
     }
     for (int l = 0; l < nl - 1; ++l) sb.h[l] = take((size_t)B * M * w * 4);
@@ -532,8 +535,10 @@ static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, in
     return sb;
 }
 
+// row_inst == nullptr: B instances x M rows each; else `M` = total rows R, row r belongs to instance row_inst[r]
 static int sdf_forward(ls_model_t* m, const SdfBuffers& sb, const float* query, const float* z_so3, const float* z_inv, const float* s,
-                       const float* t, int B, int M, float* sdf, hipStream_t st) {
+                       const float* t, int B, int M, float* sdf, hipStream_t st, const int32_t* row_inst = nullptr) {
+    const long long rows = row_inst ? (long long)M : (long long)B * M;
     const ls_model_desc& d = m->d;
     const int w = d.dec_width, L = d.c_dim, nl = d.dec_num_linear, li = d.dec_latent_in;
     const float* W = m->blob;
@@ -548,7 +553,9 @@ static int sdf_forward(ls_model_t* m, const SdfBuffers& sb, const float* query, 
     }
     if (rc != LS_OK) return rc;
     // layer 0: pure affine in (q, |q|)
-    { PROF(LS_K_SDF_AFFINE, 0, st); rc = sdf_affine_launch(query, s, t, sb.A0, sb.b0, B, M, w, w, 0, sb.h[0], st); }
+    { PROF(LS_K_SDF_AFFINE, 0, st);
+      rc = row_inst ? sdf_affine_rows_launch(query, row_inst, s, t, sb.A0, sb.b0, rows, w, w, 0, sb.h[0], st)
+                    : sdf_affine_launch(query, s, t, sb.A0, sb.b0, B, M, w, w, 0, sb.h[0], st); }
     if (rc != LS_OK) return rc;
     int kin = w;
     for (int l = 1; l < nl - 1; ++l) {
@@ -556,19 +563,20 @@ static int sdf_forward(ls_model_t* m, const SdfBuffers& sb, const float* query, 
         const float* cur = sb.h[l - 1];
         float* nxt = sb.h[l];
         if (l == li) {
-            { PROF(LS_K_GEMM_SDF, l, st); rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, B * M, outw, kin, 0, sb.gws, st); }
+            { PROF(LS_K_GEMM_SDF, l, st); rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, (int)rows, outw, kin, 0, sb.gws, st); }
             if (rc != LS_OK) return rc;
             PROF(LS_K_SDF_AFFINE, l, st);
-            rc = sdf_affine_launch(query, s, t, sb.A4, sb.b4, B, M, w, w, 1, nxt, st);
+            rc = row_inst ? sdf_affine_rows_launch(query, row_inst, s, t, sb.A4, sb.b4, rows, w, w, 1, nxt, st)
+                          : sdf_affine_launch(query, s, t, sb.A4, sb.b4, B, M, w, w, 1, nxt, st);
         } else {
             PROF(LS_K_GEMM_SDF, l, st);
-            rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, B * M, outw, kin, 1, sb.gws, st);
+            rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, (int)rows, outw, kin, 1, sb.gws, st);
         }
         if (rc != LS_OK) return rc;
         kin = outw;
     }
     PROF(LS_K_SDF_OUT, nl - 1, st);
-    return sdf_out_launch(sb.h[nl - 2], w, kin, W + d.off_dec_w[nl - 1], W + d.off_dec_b[nl - 1], (long long)B * M, sdf, st);
+    return sdf_out_launch(sb.h[nl - 2], w, kin, W + d.off_dec_w[nl - 1], W + d.off_dec_b[nl - 1], rows, sdf, st);
 }
 
 int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s, const float* t,
@@ -580,6 +588,38 @@ int ls_sdf_decode(ls_model_t* m, const float* query, const float* z_so3, const f
     const size_t need = ls_sdf_workspace_bytes(m, B, M);
     if (workspace_bytes < need) { set_error("sdf_decode: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
     return sdf_forward(m, sdf_buffers(d, workspace, B, M, false), query, z_so3, z_inv, s, t, B, M, sdf, (hipStream_t)stream);
+}
+
+// Ragged batch: R query rows of B instances packed back to back (rows of one instance contiguous), row_inst[r] = instance of row r.
+// Workspace: ls_sdf_rows_workspace_bytes(m, B, R).
+size_t ls_sdf_rows_workspace_bytes(const ls_model_t* m, int B, long long R) {
+    if (!m || m->d.dec_num_linear <= 0) return 0;
+    const size_t w = (size_t)m->d.dec_width;
+    size_t b = 2 * align_up((size_t)B * w * 4 * 4, 256) + 2 * align_up((size_t)B * w * 4, 256);
+    b += 2 * align_up((size_t)R * w * 4, 256);
+    return b;
+}
+int ls_sdf_decode_rows(ls_model_t* m, const float* query, const int32_t* row_inst, const float* z_so3, const float* z_inv, const float* s,
+                       const float* t, int B, long long R, float* sdf, void* workspace, size_t workspace_bytes, void* stream) {
+    LS_REQUIRE(m && query && row_inst && z_so3 && z_inv && s && t && sdf && workspace, "sdf_decode_rows: null argument");
+    const ls_model_desc& d = m->d;
+    LS_REQUIRE(d.dec_num_linear >= 3, "sdf_decode_rows: model has no decoder packed");
+    LS_REQUIRE(B > 0 && R > 0 && R < (1ll << 31), "sdf_decode_rows: empty or oversized problem");
+    const size_t need = ls_sdf_rows_workspace_bytes(m, B, R);
+    if (workspace_bytes < need) { set_error("sdf_decode_rows: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
+    // same buffer layout as the dense form with "M" = R rows shared by all instances
+    SdfBuffers sb{};
+    const int w = d.dec_width, nl = d.dec_num_linear;
+    char* ws = (char*)workspace;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { float* p = (float*)(ws + off); off = align_up(off + bytes, 256); return p; };
+    sb.A0 = take((size_t)B * w * 16); sb.A4 = take((size_t)B * w * 16);
+    sb.b0 = take((size_t)B * w * 4); sb.b4 = take((size_t)B * w * 4);
+    float* hA = take((size_t)R * w * 4);
+    float* hB = take((size_t)R * w * 4);
+    for (int l = 0; l < nl - 1; ++l) sb.h[l] = (l & 1) ? hB : hA;
+    sb.gws = nullptr;   // batch-invariant: no split-K (see sdf_buffers)
+    return sdf_forward(m, sb, query, z_so3, z_inv, s, t, B, (int)R, sdf, (hipStream_t)stream, row_inst);
 }
 
 // forward that keeps every layer's activations in `workspace` for ls_sdf_backward

@@ -62,6 +62,41 @@ __global__ __launch_bounds__(256) void sdf_affine_kernel(const float* __restrict
     }
 }
 
+// Ragged form: rows of SEVERAL instances packed back to back, row r belongs to instance row_inst[r] (batched MISE rounds, where
+// every instance contributes a different number of query points).  Same arithmetic as sdf_affine_kernel.
+__global__ __launch_bounds__(256) void sdf_affine_rows_kernel(const float* __restrict__ query, const int32_t* __restrict__ row_inst,
+                                                              const float* __restrict__ s, const float* __restrict__ t,
+                                                              const float* __restrict__ A, const float* __restrict__ beff, long long R,
+                                                              int out_dim, int ldh, int accumulate, int rows_per_block,
+                                                              float* __restrict__ h) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const bool on = o < out_dim;
+    const int ow = on ? o : 0;
+    const long long r1 = min(R, r0 + rows_per_block);
+    int bprev = -1;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bb = 0.f, sc = 1.f, tx = 0.f, ty = 0.f, tz = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        const int b = row_inst[r];
+        if (b != bprev) {   // rows of an instance are contiguous: reloaded a handful of times per block
+            a = *reinterpret_cast<const float4*>(A + ((size_t)b * out_dim + ow) * 4);
+            bb = beff[(size_t)b * out_dim + ow];
+            sc = s[b]; tx = t[b * 3]; ty = t[b * 3 + 1]; tz = t[b * 3 + 2];
+            bprev = b;
+        }
+        const float* qp = query + (size_t)r * 3;
+        const float qx = (qp[0] - tx) / sc, qy = (qp[1] - ty) / sc, qz = (qp[2] - tz) / sc;
+        const float len = sqrtf(qx * qx + qy * qy + qz * qz);
+        float v = a.x * qx + a.y * qy + a.z * qz + a.w * len + bb;
+        if (on) {
+            float* hp = h + (size_t)r * ldh + o;
+            if (accumulate) v += *hp;
+            *hp = fmaxf(v, 0.f);
+        }
+    }
+}
+
 // last layer + tanh (deepsdf_decoder.py:104-121): sdf[row] = tanh(<h[row], w> + bias); one wave per row
 __global__ __launch_bounds__(256) void sdf_out_kernel(const float* __restrict__ h, int ldh, int width, const float* __restrict__ w,
                                                       const float* __restrict__ bias, long long rows, float* __restrict__ sdf) {
@@ -293,6 +328,14 @@ int sdf_affine_launch(const float* query, const float* s, const float* t, const 
     const int rpb = 64;
     hipLaunchKernelGGL(sdf_affine_kernel, dim3(cdiv(out_dim, 256), B, cdiv(M, rpb)), dim3(256), 0, st, query, s, t, A, beff, M,
                        out_dim, ldh, accumulate, rpb, h);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int sdf_affine_rows_launch(const float* query, const int32_t* row_inst, const float* s, const float* t, const float* A, const float* beff,
+                           long long R, int out_dim, int ldh, int accumulate, float* h, hipStream_t st) {
+    const int rpb = 64;
+    hipLaunchKernelGGL(sdf_affine_rows_kernel, dim3(cdiv(out_dim, 256), (unsigned)cdiv(R, rpb)), dim3(256), 0, st, query, row_inst, s, t, A,
+                       beff, R, out_dim, ldh, accumulate, rpb, h);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

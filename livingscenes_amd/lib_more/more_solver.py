@@ -225,6 +225,77 @@ class More_Solver:
         return out
 
 
+def _scene_clouds(scene):
+    return [pc.T[mask.reshape(-1).bool()] for pc, mask in zip(scene["pc"], scene["pc_mask"])]
+
+
+def solve_end2end_batch(solver, pairs, mesh=False):
+    """Batched form of More_Solver._solve_end2end over MANY (reference scan, rescan) pairs -- an extension the reference lacks
+    (eval_3rscan.py walks the scenes one pair at a time): every scan of every pair goes through ONE ragged FPS launch and ONE
+    encoder batch, every matched pair of every scene through ONE registration batch (ragged FPS, encode, Kabsch, ICP).  The
+    ragged FPS runs one workgroup per raw cloud (18 ms for a 60 000-point cloud), so a single scene pair leaves the GPU idle;
+    hundreds of clouds per launch fill it.  Returns one dict per pair, as _solve_end2end (optim=False)."""
+    scans, where = [], []
+    for ref, res in pairs:
+        where.append((len(scans), len(scans) + 1))
+        scans += [ref, res]
+    clouds = [_scene_clouds(s) for s in scans]
+    flat = [c for cl in clouds for c in cl]
+    dev = flat[0].device
+    lens = torch.tensor([c.shape[0] for c in flat], device=dev)
+    buf = torch.zeros(len(flat), 3, int(lens.max()), device=dev)
+    mask = torch.zeros(len(flat), 1, int(lens.max()), dtype=torch.bool, device=dev)
+    for i, c in enumerate(flat):
+        buf[i, :, : c.shape[0]] = c.T
+        mask[i, :, : c.shape[0]] = True
+    codes = solver.model.encode_fps(buf, mask)
+    starts = [0]
+    for cl in clouds:
+        starts.append(starts[-1] + len(cl))
+    outs, reg1, reg2, slots = [], [], [], []
+    for p, (a, b) in enumerate(where):
+        cr = {k: v[starts[a]:starts[a + 1]] for k, v in codes.items()}
+        cs = {k: v[starts[b]:starts[b + 1]] for k, v in codes.items()}
+        m0 = solver._solve_object_matching(cr, cs, "sequential")["matches0"]
+        n = len(clouds[a])
+        out = {"ref_pc_lst": clouds[a], "rescan_pc_lst": clouds[b], "matches": m0, "registration": [None] * n, "codes": [None] * n,
+               "mesh_lst": [None] * n, "_res_codes": cs}
+        for i, j in enumerate(m0.tolist()):
+            if j >= 0:
+                reg1.append(clouds[a][i]); reg2.append(clouds[b][j]); slots.append((p, i, j))
+        outs.append(out)
+    if slots:
+        R, t = solver._solve_pairwise_registration_batch(reg1, reg2)
+        T = Rt_to_SE3(R, t)
+        for k, (p, i, j) in enumerate(slots):
+            out = outs[p]
+            out["registration"][i] = T[k:k + 1]
+            cur = {key: out["_res_codes"][key][j][None] for key in ("z_so3", "z_inv", "s", "t")}
+            out["codes"][i] = solver._transform_latent(cur, inverse(T[k:k + 1]))
+        if mesh:
+            import numpy as np
+            group = 16                                     # instances whose MISE rounds advance in lock-step
+            for g0 in range(0, len(slots), group):
+                part = slots[g0:g0 + group]
+                cl = [outs[p]["codes"][i] for p, i, _ in part]
+                canon = {k: torch.cat([c[k] for c in cl], 0) for k in ("z_so3", "z_inv")}
+                canon["t"] = torch.zeros_like(torch.cat([c["t"] for c in cl], 0))   # canonical pose, as model_utils.py:296-298
+                canon["s"] = torch.ones_like(torch.cat([c["s"] for c in cl], 0))
+                meshes = solver.mesh_extractor.generate_from_latent_batch(canon, solver.model.decoder)
+                for (p, i, _), c, msh in zip(part, cl, meshes):
+                    tsfm = np.eye(4) * c["s"].squeeze().item()
+                    tsfm[-1, -1] = 1
+                    tsfm[:3, 3] = c["t"].squeeze().view(-1).detach().cpu().numpy()
+                    if hasattr(msh, "apply_transform"):
+                        msh.apply_transform(tsfm)
+                    else:
+                        msh.vertices = msh.vertices @ tsfm[:3, :3].T + tsfm[:3, 3]
+                    outs[p]["mesh_lst"][i] = msh
+    for out in outs:
+        del out["_res_codes"]
+    return outs
+
+
 def _se3_exp(xi):
     """exp of the twist (v, omega) in R^6 -> [4,4] (Rodrigues + the left Jacobian for the translation)."""
     v, w = xi[:3], xi[3:]

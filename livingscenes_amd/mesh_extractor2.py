@@ -31,7 +31,13 @@ class MISE:
         self._cap = int(load().ls_mise_lattice_points(self.resolution_0, self.depth))
         self._idx = torch.empty(self._cap, dtype=torch.int32, device=self.device)
         self._pts = torch.empty(self._cap, 3, dtype=torch.float32, device=self.device)
-        check(load().ls_mise_init(ptr(self._state), nbytes, self.resolution_0, self.depth, stream_ptr(self.device)), "ls_mise_init")
+        self.reset()
+
+    def reset(self, threshold=None):
+        """Back to the initial lattice (the buffers are kept: a pool of MISE objects serves many instances)."""
+        if threshold is not None:
+            self.threshold = float(threshold)
+        check(load().ls_mise_init(ptr(self._state), self._state.numel(), self.resolution_0, self.depth, stream_ptr(self.device)), "ls_mise_init")
 
     def query_device(self, box_size=1.0):
         """-> (idx [n] int32 lattice indices, pts [n,3] float32 = box_size * (p / resolution - 0.5)), device tensors (views)."""
@@ -117,6 +123,50 @@ class Generator3D:
         if stats_dict is not None:
             stats_dict["mise rounds"] = rounds
         return mise.to_dense()
+
+    def eval_grid_batch(self, codes, F):
+        """Value grids of SEVERAL instances at once (an extension: the reference extracts one mesh at a time).  codes: dict of
+        [B,...] tensors.  All MISE octrees advance in lock-step; each round the unknown points of every instance are packed into
+        ONE ragged decoder call (ls_sdf_decode_rows), so the small late rounds and the per-round host round trip are shared.
+        Returns a list of B float64 grids, each bit-identical to ``eval_grid`` on that instance."""
+        assert self.upsampling_steps > 0, "eval_grid_batch: MISE path only"
+        B = codes["z_inv"].shape[0]
+        threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
+        box_size = 1 + self.padding
+        hip = F._owner().hip_model()
+        pool = self.__dict__.setdefault("_mise_pool", [])
+        while len(pool) < B:
+            pool.append(MISE(self.resolution0, self.upsampling_steps, threshold, device=self.device))
+        mises = pool[:B]
+        for m in mises:
+            if (m.resolution_0, m.depth) != (self.resolution0, self.upsampling_steps):
+                raise ValueError("eval_grid_batch: resolution changed after the MISE pool was created")
+            m.reset(threshold)
+        active = list(range(B))
+        while active:
+            # launch every query first, read all counts back in one copy
+            for b in active:
+                m = mises[b]
+                check(load().ls_mise_query(ptr(m._state), m.resolution_0, m.depth, float(box_size), ptr(m._idx), ptr(m._pts), m._cap,
+                                           ptr(m._count), stream_ptr(m.device)), "ls_mise_query")
+            counts = torch.cat([mises[b]._count for b in active]).cpu().tolist()
+            live = [(b, n) for b, n in zip(active, counts) if n > 0]
+            if not live:
+                break
+            pts = torch.cat([mises[b]._pts[:n] for b, n in live], 0)
+            inst = torch.cat([torch.full((n,), b, dtype=torch.int32, device=pts.device) for b, n in live])
+            sdf = hip.sdf_decode_rows(pts, inst, codes["z_so3"], codes["z_inv"], codes["s"], codes["t"])
+            logits = F.sdf2occ_factor * sdf
+            o = 0
+            for b, n in live:
+                mises[b].update_device(mises[b]._idx[:n], logits[o:o + n])
+                o += n
+            active = [b for b, _ in live]
+        return [m.to_dense() for m in mises]
+
+    def generate_from_latent_batch(self, codes, F):
+        """Meshes of B codes (batched MISE rounds, then marching cubes per instance)."""
+        return [self.extract_mesh(g, None, None) for g in self.eval_grid_batch(codes, F)]
 
     def generate_from_latent(self, c, F, **kwargs):
         """mesh_extractor2.py:60-74."""

@@ -231,6 +231,24 @@ class HipModel:
                 sdf[:, m0:m0 + mc] = out
         return sdf
 
+    def sdf_decode_rows(self, query, row_inst, z_so3, z_inv, s, t, max_rows=1 << 20):
+        """Ragged batch: query [R,3], row_inst [R] int32 (instance of each row; rows of an instance contiguous) -> sdf [R]."""
+        query = _f32(query)
+        R = query.shape[0]
+        B = z_inv.shape[0]
+        row_inst = row_inst.to(torch.int32).contiguous()
+        z_so3, z_inv, s, t = _f32(z_so3), _f32(z_inv), _f32(s), _f32(t.reshape(B, 3))
+        sdf = torch.empty(R, dtype=torch.float32, device=query.device)
+        for r0 in range(0, R, max_rows):
+            rc = min(max_rows, R - r0)
+            q, ri, out = query[r0:r0 + rc], row_inst[r0:r0 + rc], sdf[r0:r0 + rc]
+            need = load().ls_sdf_rows_workspace_bytes(self._h, B, rc)
+            ws = self._workspace(need)
+            with torch.cuda.device(query.device):
+                check(load().ls_sdf_decode_rows(self._h, ptr(q), ptr(ri), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, rc, ptr(out), ptr(ws),
+                                                ws.numel(), stream_ptr(query.device)), "ls_sdf_decode_rows")
+        return sdf
+
     def sdf_decode_train(self, query, z_so3, z_inv, s, t):
         """Forward that keeps the activations: -> (sdf [B,M], saved) where ``saved`` feeds sdf_backward (its workspace is
         private to the call, so several graphs can be alive at once)."""

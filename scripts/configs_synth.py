@@ -88,6 +88,22 @@ print(f"configs[3] synthetic, 1 GPU: {args.scenes} scenes x 3 scans, {n_inst} in
 print(f"  encode+match+register {t['encode+match+register']:.2f} s ({enc_inst / t['encode+match+register']:.0f} instance-encodes/s), "
       f"SDF reconstruction {t['mesh']:.2f} s ({t['mesh'] / max(n_mesh, 1) * 1e3:.1f} ms per mesh), total {tot:.2f} s = "
       f"{n_pairs / tot:.1f} matched objects/s end to end")
+# the same work with every scan / matched pair of all scenes batched (lib_more.more_solver.solve_end2end_batch)
+from livingscenes_amd.lib_more.more_solver import solve_end2end_batch
+all_pairs = [(sc[0][0], sc[k][0]) for sc in scenes for k in (1, 2)]
+solve_end2end_batch(solver, all_pairs[:2])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+outs = solve_end2end_batch(solver, all_pairs)
+torch.cuda.synchronize(); tb = time.perf_counter() - t0
+nb = sum(r is not None for o in outs for r in o["registration"])
+print(f"  batched over all {len(all_pairs)} scene pairs: encode+match+register {tb:.2f} s ({enc_inst / tb:.0f} instance-encodes/s, {nb} registrations)")
+solve_end2end_batch(solver, all_pairs[:1], mesh=True)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+outs = solve_end2end_batch(solver, all_pairs, mesh=True)
+torch.cuda.synchronize(); tm = time.perf_counter() - t0
+nm = sum(m is not None for o in outs for m in o["mesh_lst"])
+print(f"  batched incl. SDF reconstruction (16 MISE octrees in lock-step, ragged decoder calls): {tm:.2f} s total, "
+      f"{(tm - tb) / max(nm, 1) * 1e3:.1f} ms per mesh, {nm / tm:.1f} matched-and-meshed objects/s")
 pairs = [(scenes[0][0][0], scenes[0][1][0])]
 ref, res = pairs[0]
 full = lambda scn, i: scn["pc"][i].T[scn["pc_mask"][i].reshape(-1)][None]

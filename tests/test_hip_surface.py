@@ -352,3 +352,65 @@ def test_optim_registration_refines_the_pose(small_prior):
     e0, e1 = float(rotation_error(R0, gt[:, :, :3])), float(rotation_error(R1, gt[:, :, :3]))
     assert e1 < e0 + 1.0 and e1 < 5.0, (e0, e1)
     assert float(translation_error(t1, gt[:, :, 3:4])) < 0.05
+
+
+@pytest.mark.gpu
+def test_solve_end2end_batch_equals_per_pair(small_prior):
+    """lib_more.more_solver.solve_end2end_batch (all scans / pairs of several scenes in single launches) returns what
+    _solve_end2end returns pair by pair: same matches, same registrations, same transformed codes."""
+    from livingscenes_amd.lib_more.more_solver import More_Solver, solve_end2end_batch
+    sp, _ = small_prior
+    d = _dev()
+    cfg = {"shape_priors": {"n_input_point": 128, "prior_name": "chair", "ckpt_dir": ""}, "fps": {"n_init": 1}}
+    solver = More_Solver(cfg, model=sp)
+
+    def scene(x, pad):
+        n, N, _ = x.shape
+        pc = torch.zeros(n, 3, N + pad)
+        pc[:, :, :N] = x.transpose(1, 2)
+        mask = torch.zeros(n, 1, N + pad, dtype=torch.bool)
+        mask[:, :, :N] = True
+        return {"pc": pc.to(d), "pc_mask": mask.to(d)}
+    pairs = []
+    for s, (n, N) in enumerate(((3, 200), (5, 150), (2, 333))):
+        sc = synth.make_scene_pair(n, N, seed=60 + s, noise=0.002)
+        pairs.append((scene(sc["ref"], 7 * s), scene(sc["rescan"], 11)))
+    got = solve_end2end_batch(solver, pairs)
+    for (ref, res), g in zip(pairs, got):
+        w = solver._solve_end2end(ref, res)
+        assert torch.equal(g["matches"], w["matches"])
+        for i in range(len(w["registration"])):
+            if w["registration"][i] is None:
+                assert g["registration"][i] is None
+                continue
+            assert relerr(g["registration"][i], w["registration"][i]) < 1e-5
+            for k in ("z_so3", "z_inv", "s", "t"):
+                assert relerr(g["codes"][i][k], w["codes"][i][k]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_ragged_decode_and_batched_mise_equal_per_instance(small_prior):
+    """ls_sdf_decode_rows on rows of several instances == ls_sdf_decode per instance (bit for bit: every query is independent),
+    and Generator3D.eval_grid_batch == eval_grid instance by instance."""
+    from livingscenes_amd.mesh_extractor2 import Generator3D
+    sp, _ = small_prior
+    d = _dev()
+    codes = sp.encode(synth.make_instances(3, 128, seed=41).to(d))
+    hip = sp.hip_model()
+    g = torch.Generator().manual_seed(3)
+    counts = [700, 1, 333]
+    qs = [(torch.rand(n, 3, generator=g) - 0.5).to(d) for n in counts]
+    inst = torch.cat([torch.full((n,), b, dtype=torch.int32) for b, n in enumerate(counts)]).to(d)
+    got = hip.sdf_decode_rows(torch.cat(qs, 0), inst, codes["z_so3"], codes["z_inv"], codes["s"], codes["t"])
+    o = 0
+    for b, n in enumerate(counts):
+        one = hip.sdf_decode(qs[b][None], codes["z_so3"][b:b + 1], codes["z_inv"][b:b + 1], codes["s"][b:b + 1], codes["t"][b:b + 1])
+        assert torch.equal(got[o:o + n], one[0]), b
+        o += n
+    gen = Generator3D(threshold=0.5, resolution0=8, upsampling_steps=2, padding=0.1)
+    canon = {k: v.clone() for k, v in codes.items()}
+    level = float(np.median(gen.eval_grid({k: v[:1] for k, v in canon.items()}, sp.decoder)))
+    gen.threshold = 1.0 / (1.0 + np.exp(-level))
+    grids = gen.eval_grid_batch(canon, sp.decoder)
+    for b in range(3):
+        assert np.array_equal(grids[b], gen.eval_grid({k: v[b:b + 1] for k, v in canon.items()}, sp.decoder)), b
