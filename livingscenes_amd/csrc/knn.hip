@@ -257,6 +257,7 @@ static bool knn_uses_sweep(int C, bool seeded, int Ns, unsigned flags) {
 size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns);
 int knn_sweep_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, bool, int32_t*, float*, const int32_t*, int,
                      int, void*, hipStream_t);
+int knn_xyz_launch(const float*, const float*, const int32_t*, int, int, int, int, int, bool, int32_t*, float*, hipStream_t);
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags) {
     if (knn_uses_sweep(C, seeded, Ns, flags)) return knn_sweep_scratch_bytes(B, Nd, dst_n, Ns);
     return knn_partial_bytes(B, Nd, Ns);
@@ -293,6 +294,9 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
     if (scratch && knn_uses_sweep(C, seed_idx != nullptr, Ns, flags))   // seeded C == 32 layer: seed / MFMA sweep / finish (knn_mfma.hip)
         return knn_sweep_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
     if (C == 1) {
+        // raw clouds: wave-per-query kernel (knn_xyz.hip); LS_KNN_XYZ_TILED=1 keeps the tiled kernel for A/B timing
+        static const bool tiled = getenv("LS_KNN_XYZ_TILED") && atoi(getenv("LS_KNN_XYZ_TILED")) != 0;
+        if (!tiled) return knn_xyz_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, st);
         return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st)
                    : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st);
     }

@@ -49,6 +49,48 @@ def test_knn_bit_exact(shape, contract):
     assert np.array_equal(dist.cpu().numpy()[valid], refd[valid])  # distances bit-exact too
 
 
+@pytest.mark.parametrize("contract", [0, 1])
+@pytest.mark.parametrize("case", ["tiny", "one_chunk", "multi_chunk", "ties", "rows", "tiled"])
+def test_knn_xyz_wave_kernel_bit_exact(case, contract, monkeypatch):
+    """Raw-cloud (C == 1) k-NN: wave-per-query kernel incl. fewer candidates than K, several 1024-candidate chunks, more exact
+    ties than one sorting round holds, query rows, and the tiled kernel kept for A/B."""
+    from livingscenes_amd import ops
+    from oracle import canon
+    rng = np.random.default_rng(11)
+    B, Nd, Ns = {"tiny": (3, 7, 9), "one_chunk": (2, 300, 1024), "multi_chunk": (2, 130, 2500), "ties": (1, 40, 700),
+                 "rows": (2, 50, 1024), "tiled": (2, 100, 150)}[case]
+    src = rng.standard_normal((B, Ns, 3, 1)).astype(np.float32)
+    dst = rng.standard_normal((B, Nd, 3, 1)).astype(np.float32)
+    dst_rows = None
+    if case == "ties":        # 200 copies of 3 distinct points: hundreds of candidates tie at the K-th distance
+        src[0, :600] = src[0, :3].repeat(200, axis=0)
+        dst[0, 0] = src[0, 1]
+    if case == "rows":
+        dst_rows = np.stack([rng.permutation(Ns)[:Nd] for _ in range(B)]).astype(np.int32)
+        ref, refd = canon.knn_c(np.stack([src[b][dst_rows[b]] for b in range(B)]), src, 16, contract=contract, return_dist=True)
+        dst_t = torch.from_numpy(src).to(_dev())
+    else:
+        ref, refd = canon.knn_c(dst, src, 16, contract=contract, return_dist=True)
+        dst_t = torch.from_numpy(dst).to(_dev())
+    if case == "tiled":
+        import subprocess, sys
+        code = ("import numpy as np, torch; from livingscenes_amd import ops; d = np.load(r'%s');"
+                "i = ops.knn(torch.from_numpy(d['dst']).cuda(), torch.from_numpy(d['src']).cuda(), 16, flags=int(d['c']));"
+                "assert np.array_equal(i.cpu().numpy(), d['ref'])")
+        import tempfile, os
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "c.npz")
+            np.savez(f, dst=dst, src=src, ref=ref, c=contract)
+            env = dict(os.environ, LS_KNN_XYZ_TILED="1")
+            subprocess.run([sys.executable, "-c", code % f], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        return
+    idx, dist = ops.knn(dst_t, torch.from_numpy(src).to(_dev()), 16, flags=contract, return_dist=True,
+                        dst_rows=None if dst_rows is None else torch.from_numpy(dst_rows).to(_dev()))
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    valid = ref >= 0
+    assert np.array_equal(dist.cpu().numpy()[valid], refd[valid])
+
+
 def test_knn_large_batch_unsplit_path():
     """B*qtiles >= 768 workgroups -> the single-pass (no candidate split) path, at the encoder's layer-1 shape."""
     from livingscenes_amd import ops
