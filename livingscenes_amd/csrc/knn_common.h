@@ -216,4 +216,46 @@ __device__ __forceinline__ void write_lists(const u64 (&lk)[4], int b, int q0, i
     }
 }
 
+// ---- 64-lane sorting network (one value per lane)
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// value of lane (lane ^ M)
+template <int M>
+__device__ __forceinline__ unsigned lane_xor(unsigned v, int lane) {
+    if constexpr (M == 1) return dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return dpp_mov<0x1B>(v);     // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return dpp_mov<0x141>(v);    // row_half_mirror
+    else if constexpr (M == 15) return dpp_mov<0x140>(v);   // row_mirror
+    else if constexpr (M < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);   // bit mode: lane ^ M
+    else return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ M) << 2, (int)v);
+}
+template <int M>
+__device__ __forceinline__ constexpr int pair_bit() { return (M & (M + 1)) == 0 ? (M + 1) / 2 : M; }   // the lower lane of a pair has this bit clear
+
+template <int M>
+__device__ __forceinline__ void cx32(unsigned& v, int lane) {
+    const unsigned o = lane_xor<M>(v, lane);
+    v = (lane & pair_bit<M>()) == 0 ? min(v, o) : max(v, o);
+}
+template <int M>
+__device__ __forceinline__ void cx64(u64& v, int lane) {
+    const u64 o = ((u64)lane_xor<M>((unsigned)(v >> 32), lane) << 32) | lane_xor<M>((unsigned)v, lane);
+    const bool lt = o < v, takemin = (lane & pair_bit<M>()) == 0;
+    v = (takemin == lt) ? o : v;
+}
+// ascending sort of one value per lane over the 64 lanes: bitonic network in the "flip" form (first step of every merge
+// pairs lane i with lane i ^ (k-1), the rest are plain half-cleaners), so that every exchange is a lane-xor and 13 of the 21
+// stages are DPP moves
+#define LS_SORT64(CX, v, lane)                                                                                         \
+    CX<1>(v, lane);                                                                                                    \
+    CX<3>(v, lane); CX<1>(v, lane);                                                                                    \
+    CX<7>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                                                    \
+    CX<15>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                                   \
+    CX<31>(v, lane); CX<8>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                   \
+    CX<63>(v, lane); CX<16>(v, lane); CX<8>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);
+
+
 }  // namespace ls

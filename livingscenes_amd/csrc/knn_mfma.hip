@@ -21,8 +21,6 @@ namespace ls {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KM_CC = 32;
-constexpr int KM_ROW = 3 * KM_CC + 4;
 
 // squared norms of feature rows: one wave per point
 __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ f, int row_f, long long npts,
@@ -67,18 +65,22 @@ constexpr int KS_LD = 36;     // chunk row stride (floats): 32 dims + 4, 9 x 16 
 // the value one lane up (DPP quad_perm); after stage s lane s holds the exact prefix over runs 0..s.  96 dependent adds per
 // 16 pairs instead of 96 per 64 pairs -- 2x the VALU work of the lane-per-pair form, 8x fewer L1 line accesses.
 // Result valid in lanes with (lane & 3) == 3.
-struct QuadRow {   // one lane's share of a feature row: channels 8i..8i+7 of the x, y, z segments (i = lane & 3)
+// Rows wider than 32 channels (CC = 64) take CC/32 rounds of the same four stages; between rounds the running value rotates
+// from lane 3 back to lane 0 of the quad (quad_perm [3,0,1,2]).
+template <int CC>
+struct QuadRow {   // one lane's share of one 32-channel round of a feature row: channels 8i..8i+7 of the x, y, z segments (i = lane & 3)
     float4 v[6];
-    __device__ __forceinline__ void load(const float* __restrict__ row, int lane) {
-        const int off = (lane & 3) * 8;
+    __device__ __forceinline__ void load(const float* __restrict__ row, int lane, int round = 0) {
+        const int off = round * 32 + (lane & 3) * 8;
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) v[x * 2 + h] = *reinterpret_cast<const float4*>(row + x * KM_CC + off + 4 * h);
+            for (int h = 0; h < 2; ++h) v[x * 2 + h] = *reinterpret_cast<const float4*>(row + x * CC + off + 4 * h);
     }
 };
-template <bool FMA>
-__device__ __forceinline__ float quad_pair_distance(const QuadRow& q, const QuadRow& c) {
+// one round: d := d + (the round's 96 terms in canonical order); LAST: no rotation after the fourth stage (result in lane 3)
+template <int CC, bool FMA, bool LAST>
+__device__ __forceinline__ float quad_round(float d, const QuadRow<CC>& q, const QuadRow<CC>& c) {
 #pragma clang fp contract(off)
     float t[24];
 #pragma unroll
@@ -92,26 +94,47 @@ __device__ __forceinline__ float quad_pair_distance(const QuadRow& q, const Quad
             t[(h * 4 + 2) * 3 + x] = FMA ? d2 : d2 * d2;
             t[(h * 4 + 3) * 3 + x] = FMA ? d3 : d3 * d3;
         }
-    float d = 0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int j = 0; j < 24; ++j) d = FMA ? __builtin_fmaf(t[j], t[j], d) : d + t[j];
-        if (s < 3)   // lane i <- lane i-1 within the quad (quad_perm [0,0,1,2])
+        if (s < 3)        // lane i <- lane i-1 within the quad (quad_perm [0,0,1,2])
             d = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x90, 0xF, 0xF, false));
+        else if (!LAST)   // next round starts in lane 0 with lane 3's prefix (quad_perm [3,0,1,2])
+            d = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x93, 0xF, 0xF, false));
     }
     return d;
+}
+// canonical distance of the quad's (query row, candidate row) pair; q0 = the query's round-0 share (held by the caller)
+template <int CC, bool FMA>
+__device__ __forceinline__ float quad_pair_distance(const QuadRow<CC>& q0, const float* __restrict__ qrow, const float* __restrict__ crow,
+                                                    int lane) {
+    QuadRow<CC> c;
+    c.load(crow, lane, 0);
+    if constexpr (CC == 32) {
+        return quad_round<CC, FMA, true>(0.0f, q0, c);
+    } else {
+        float d = quad_round<CC, FMA, false>(0.0f, q0, c);
+#pragma unroll
+        for (int r = 1; r < CC / 32; ++r) {
+            QuadRow<CC> q;
+            q.load(qrow, lane, r);
+            c.load(crow, lane, r);
+            d = (r == CC / 32 - 1) ? quad_round<CC, FMA, true>(d, q, c) : quad_round<CC, FMA, false>(d, q, c);
+        }
+        return d;
+    }
 }
 
 int row_norms_launch(const float* f, int row_f, long long npts, float* norms, hipStream_t st);
 
 // ---- 1. seeds.  One wave per four queries (row r of the wave = query 4*wave_id + r), four quad-steps of four hints.
-template <bool FMA>
+template <int CC, bool FMA>
 __global__ __launch_bounds__(256, 4) void knn_seed_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                           const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
                                                           const int32_t* __restrict__ seed_idx, int seed_n, int seed_by_row,
                                                           u64* __restrict__ seedkeys, int groups_per_inst, int total_groups) {
-    constexpr int RF = 3 * KM_CC;
+    constexpr int RF = 3 * CC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware order: consecutive logical workgroups (= the queries of one instance) share an XCD, so the instance's
     // 393 KB candidate table is gathered out of that XCD's L2 instead of the fabric (round-robin placement: every XCD
@@ -132,15 +155,13 @@ __global__ __launch_bounds__(256, 4) void knn_seed_kernel(const float* __restric
         const int si = hp[u * 4 + quad];
         sidx[u] = (r >= 0 && si >= 0 && si < Ns) ? si : -1;
     }
-    QuadRow qv;
-    qv.load(dbase + (size_t)max(r, 0) * RF, lane);
+    const float* qrow = dbase + (size_t)max(r, 0) * RF;
+    QuadRow<CC> qv;
+    qv.load(qrow, lane);
     u64 ks[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        QuadRow cv;
-        cv.load(sbase + (size_t)max(sidx[u], 0) * RF, lane);
-        ks[u] = make_key(quad_pair_distance<FMA>(qv, cv), sidx[u], (sidx[u] >= 0) & qlast);
-    }
+    for (int u = 0; u < 4; ++u)
+        ks[u] = make_key(quad_pair_distance<CC, FMA>(qv, qrow, sbase + (size_t)max(sidx[u], 0) * RF, lane), sidx[u], (sidx[u] >= 0) & qlast);
     key_cx(ks[0], ks[1]); key_cx(ks[2], ks[3]); key_cx(ks[0], ks[2]); key_cx(ks[1], ks[3]); key_cx(ks[1], ks[2]);
     u64 lk = ~0ull, rkey = ~0ull;
     merge_keys<true>(ks[0], ks[1], ks[2], ks[3], lk, rkey, 16, lane);   // all distinct valid hints, sorted (K applies later)
@@ -150,12 +171,13 @@ __global__ __launch_bounds__(256, 4) void knn_seed_kernel(const float* __restric
 // ---- 2. sweep.  64 queries x all candidates per workgroup; wave (wm, wn) owns the 32x32 block of S for queries wm*32..,
 // candidates wn*32.. of each 64-candidate tile; the query fragments stay in registers, candidates stream through LDS in
 // 64-row x 32-dim chunks (double buffered, one barrier per chunk, three chunks = one tile).
-__global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+template <int CC>
+__global__ __launch_bounds__(256, CC == 32 ? 4 : 2) void knn_sweep_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                            const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
                                                            const float* __restrict__ nrm_src, int Nd, int dst_n, int Ns, int K,
                                                            int qtiles, float epsE, const u64* __restrict__ seedkeys,
                                                            int32_t* __restrict__ surv_cnt, unsigned short* __restrict__ surv) {
-    constexpr int C = KM_CC, RF = 3 * KM_CC;
+    constexpr int RF = 3 * CC, NCH = RF / 32;   // a tile = NCH chunks of 32 consecutive floats of every candidate row
     __shared__ __attribute__((aligned(16))) float lc[2][KNN_TS * KS_LD];              // 18 KB: two candidate chunks
     __shared__ __attribute__((aligned(16))) unsigned short lseedidx[KNN_TQ * 16];     // 2 KB: the hints (0xFFFF = none)
     __shared__ float lnq[KNN_TQ], lkth[KNN_TQ];
@@ -198,15 +220,15 @@ __global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restri
     const int l31 = lane & 31, lh = lane >> 5;
 
     // loop-invariant A fragments: query row wm*32 + l31, dims k*32 + j*8 + lh*4 .. +3 (padding queries: row 0, kth = -inf)
-    float4 a[12];
+    float4 a[NCH * 4];
     {
         const int r = lqrow[wm * 32 + l31];
         const float* qp = dbase + (size_t)(r >= 0 ? r : 0) * RF + lh * 4;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) a[i] = *reinterpret_cast<const float4*>(qp + i * 8);
+        for (int i = 0; i < NCH * 4; ++i) a[i] = *reinterpret_cast<const float4*>(qp + i * 8);
     }
 
-    // chunk staging: chunk g = (tile g/3, xyz component g%3); thread -> rows sr and sr+32, float4 column sc4
+    // chunk staging: chunk g = (tile g/NCH, 32-float slice g%NCH of the row); thread -> rows sr and sr+32, float4 column sc4
     const int sr = tid >> 3, sc4 = (tid & 7) * 4;
     const int ntiles = (Ns + KNN_TS - 1) / KNN_TS;
     float4 st0, st1;
@@ -214,8 +236,8 @@ __global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restri
         const int r0 = t * KNN_TS + sr, r1 = r0 + 32;
         // rows past Ns are clamped, not zeroed: their S column is garbage but `cvalid` keeps it out of the filter, and a
         // select on the loaded value would make the wave wait for the load right here instead of one chunk later
-        st0 = *reinterpret_cast<const float4*>(sbase + (size_t)min(r0, Ns - 1) * RF + k * C + sc4);
-        st1 = *reinterpret_cast<const float4*>(sbase + (size_t)min(r1, Ns - 1) * RF + k * C + sc4);
+        st0 = *reinterpret_cast<const float4*>(sbase + (size_t)min(r0, Ns - 1) * RF + k * 32 + sc4);
+        st1 = *reinterpret_cast<const float4*>(sbase + (size_t)min(r1, Ns - 1) * RF + k * 32 + sc4);
     };
     auto lstore = [&](int buf) {
         *reinterpret_cast<float4*>(&lc[buf][sr * KS_LD + sc4]) = st0;
@@ -239,8 +261,8 @@ __global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int buf = (t + k) & 1;
+        for (int k = 0; k < NCH; ++k) {
+            const int buf = (t * NCH + k) & 1;
             const float* bp = &lc[buf][(wn * 32 + l31) * KS_LD + lh * 4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -251,7 +273,7 @@ __global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restri
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bb.z, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bb.w, S, 0, 0, 0);
             }
-            if (k == 2) {
+            if (k == NCH - 1) {
                 // filter epilogue: candidate t*64 + cc against the 16 queries of this lane's accumulator rows
                 const int cglob = t * KNN_TS + cc;
                 const bool cvalid = cglob < Ns;
@@ -285,8 +307,8 @@ __global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restri
             // flight and falls back to s_waitcnt vmcnt(0) in front of the MFMA block
             lstore(buf ^ 1);
             {
-                const int t2 = k == 0 ? t : t + 1;          // chunk g + 2
-                gload(min(t2, ntiles - 1), (k + 2) % 3);
+                const int t2 = k + 2 < NCH ? t : t + 1;     // chunk g + 2
+                gload(min(t2, ntiles - 1), (k + 2) % NCH);
             }
             __syncthreads();
         }
@@ -296,13 +318,13 @@ __global__ __launch_bounds__(256, 4) void knn_sweep_kernel(const float* __restri
 
 // ---- 3. finish.  Same wave layout as the seed kernel; the seeded list is reloaded, survivors get canonical keys in rounds of
 // 16 per query (four quad-steps), a query flagged as overflowed scans every candidate the same way.
-template <bool FMA>
+template <int CC, bool FMA>
 __global__ __launch_bounds__(256, 4) void knn_finish_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                             const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
                                                             const u64* __restrict__ seedkeys, const int32_t* __restrict__ surv_cnt,
                                                             const unsigned short* __restrict__ surv, int32_t* __restrict__ idx_out,
                                                             float* __restrict__ dist_out, int groups_per_inst, int total_groups) {
-    constexpr int RF = 3 * KM_CC;
+    constexpr int RF = 3 * CC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // XCD-aware order, as in the seed kernel
     if (wg >= total_groups) return;
@@ -321,8 +343,9 @@ __global__ __launch_bounds__(256, 4) void knn_finish_kernel(const float* __restr
     const bool brute = cnt > KS_CAP;
     if (brute) cnt = Ns;
     const unsigned short* sp = surv + qg * KS_CAP;
-    QuadRow qv;
-    qv.load(dbase + (size_t)max(r, 0) * RF, lane);
+    const float* qrow = dbase + (size_t)max(r, 0) * RF;
+    QuadRow<CC> qv;
+    qv.load(qrow, lane);
     for (int base = 0; __any(base < cnt); base += 16) {
         u64 ks[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 #pragma unroll
@@ -331,9 +354,7 @@ __global__ __launch_bounds__(256, 4) void knn_finish_kernel(const float* __restr
             const bool v = j < cnt;
             if (__any(v)) {   // wave-uniform: skip the steps no row of the wave needs
                 const int c = v ? (brute ? j : (int)sp[j]) : 0;
-                QuadRow cv;
-                cv.load(sbase + (size_t)c * RF, lane);
-                ks[u] = make_key(quad_pair_distance<FMA>(qv, cv), c, v & qlast);
+                ks[u] = make_key(quad_pair_distance<CC, FMA>(qv, qrow, sbase + (size_t)c * RF, lane), c, v & qlast);
             }
         }
         key_cx(ks[0], ks[1]); key_cx(ks[2], ks[3]); key_cx(ks[0], ks[2]); key_cx(ks[1], ks[3]); key_cx(ks[1], ks[2]);
@@ -347,18 +368,71 @@ __global__ __launch_bounds__(256, 4) void knn_finish_kernel(const float* __restr
     }
 }
 
+// ---- 3'. finish, one WAVE per query (rows wider than 32 channels).  The row-per-query form above serialises a query's
+// survivors four at a time and a wave waits for its slowest row (layer 4, D = 192, ~38 survivors: 104 us for 8 k queries).
+// Here the 16 quads of a wave take 16 survivors per step, three steps are independent instruction streams, and the 48 new keys
+// are sorted together with the seeded list by one 64-lane network (knn_common.h).
+template <int CC, bool FMA>
+__global__ __launch_bounds__(256, 3) void knn_finish_wave_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+                                                                 const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
+                                                                 const u64* __restrict__ seedkeys, const int32_t* __restrict__ surv_cnt,
+                                                                 const unsigned short* __restrict__ surv, int32_t* __restrict__ idx_out,
+                                                                 float* __restrict__ dist_out, int total_q) {
+    constexpr int RF = 3 * CC;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // consecutive queries (one instance) share an XCD
+    if (qg >= total_q) return;
+    const int b = qg / Nd, q = qg % Nd;
+    const float* sbase = srcf + (size_t)b * Ns * RF;
+    const int r = dst_rows ? dst_rows[qg] : q;
+    const float* qrow = dstf + ((size_t)b * dst_n + r) * RF;
+    const int quad = lane >> 2;
+    const bool qlast = (lane & 3) == 3;
+    int cnt = surv_cnt[qg];
+    const bool brute = cnt > KS_CAP;    // overflowed survivor list: scan every candidate, starting from an empty list
+    if (brute) cnt = Ns;
+    u64 best = (!brute && lane < K) ? seedkeys[(size_t)qg * 16 + lane] : ~0ull;   // lanes 0..15: the list so far
+    const unsigned short* sp = surv + (size_t)qg * KS_CAP;
+    QuadRow<CC> qv;
+    qv.load(qrow, lane);
+    for (int base = 0; base < cnt; base += 48) {
+        u64 ks[3] = {~0ull, ~0ull, ~0ull};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (base + u * 16 < cnt) {   // wave-uniform
+                const int j = base + u * 16 + quad;
+                const bool v = j < cnt;
+                const int c = v ? (brute ? j : (int)sp[j]) : 0;
+                ks[u] = make_key(quad_pair_distance<CC, FMA>(qv, qrow, sbase + (size_t)c * RF, lane), c, v & qlast);
+            }
+        }
+        // lane 16 + 16 u + g <- the key of quad g in step u (held by lane 4 g + 3)
+        const int src = ((lane & 15) << 2) + 3;
+        const u64 n0 = bperm64(src, ks[0]), n1 = bperm64(src, ks[1]), n2 = bperm64(src, ks[2]);
+        u64 k = lane < 16 ? best : (lane < 32 ? n0 : (lane < 48 ? n1 : n2));
+        LS_SORT64(cx64, k, lane)
+        best = k;
+    }
+    if (lane < K) {
+        const size_t o = (size_t)qg * K + lane;
+        const unsigned hi = (unsigned)(best >> 32), lo = (unsigned)best;
+        idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lo;
+        if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
+    }
+}
+
 size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns) {
     const size_t nq = (size_t)B * Nd;
     return ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256      // row norms
            + nq * 16 * sizeof(u64) + nq * sizeof(int32_t) + nq * KS_CAP * sizeof(unsigned short) + 256;
 }
 
-int knn_sweep_launch(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K,
-                     bool fma, int32_t* idx_out, float* dist_out, const int32_t* seed_idx, int seed_n, int seed_by_row, void* scratch,
-                     hipStream_t st) {
-    LS_REQUIRE(C == KM_CC, "knn_sweep: only C == 32 layers are supported (C=%d)", C);
-    LS_REQUIRE(seed_idx != nullptr, "knn_sweep: needs seed lists");
-    LS_REQUIRE(Ns <= 65535, "knn_sweep: Ns=%d exceeds the 16-bit survivor index", Ns);
+template <int CC>
+static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int K, bool fma,
+                              int32_t* idx_out, float* dist_out, const int32_t* seed_idx, int seed_n, int seed_by_row, void* scratch,
+                              hipStream_t st) {
+    const int C = CC;
     const size_t nq = (size_t)B * Nd;
     char* sc = (char*)scratch;
     float* nsrc = (float*)sc;
@@ -384,23 +458,44 @@ int knn_sweep_launch(const float* dst, const float* src, const int32_t* dst_rows
     const int qtiles = cdiv(Nd, KNN_TQ);
     const float epsE = 6.0f * (float)(3 * C + 4) * 5.9604645e-8f;
     if (fma)
-        hipLaunchKernelGGL(knn_seed_kernel<true>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
+        hipLaunchKernelGGL((knn_seed_kernel<CC, true>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
                            seed_by_row, seedkeys, groups, B * groups);
     else
-        hipLaunchKernelGGL(knn_seed_kernel<false>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
+        hipLaunchKernelGGL((knn_seed_kernel<CC, false>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
                            seed_by_row, seedkeys, groups, B * groups);
     LS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_sweep_kernel, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles, epsE,
+    hipLaunchKernelGGL(knn_sweep_kernel<CC>, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles, epsE,
                        seedkeys, surv_cnt, surv);
     LS_LAUNCH_CHECK();
-    if (fma)
-        hipLaunchKernelGGL(knn_finish_kernel<true>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seedkeys, surv_cnt,
-                           surv, idx_out, dist_out, groups, B * groups);
-    else
-        hipLaunchKernelGGL(knn_finish_kernel<false>, dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seedkeys, surv_cnt,
-                           surv, idx_out, dist_out, groups, B * groups);
+    if constexpr (CC == 32) {
+        if (fma)
+            hipLaunchKernelGGL((knn_finish_kernel<CC, true>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seedkeys,
+                               surv_cnt, surv, idx_out, dist_out, groups, B * groups);
+        else
+            hipLaunchKernelGGL((knn_finish_kernel<CC, false>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seedkeys,
+                               surv_cnt, surv, idx_out, dist_out, groups, B * groups);
+    } else {
+        const int wblocks = cdiv((long long)nq, 4);
+        if (fma)
+            hipLaunchKernelGGL((knn_finish_wave_kernel<CC, true>), dim3(wblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K,
+                               seedkeys, surv_cnt, surv, idx_out, dist_out, (int)nq);
+        else
+            hipLaunchKernelGGL((knn_finish_wave_kernel<CC, false>), dim3(wblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K,
+                               seedkeys, surv_cnt, surv, idx_out, dist_out, (int)nq);
+    }
     LS_LAUNCH_CHECK();
     return LS_OK;
+}
+
+int knn_sweep_launch(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K,
+                     bool fma, int32_t* idx_out, float* dist_out, const int32_t* seed_idx, int seed_n, int seed_by_row, void* scratch,
+                     hipStream_t st) {
+    LS_REQUIRE(C == 32 || C == 64, "knn_sweep: only C == 32 / 64 layers are supported (C=%d)", C);
+    LS_REQUIRE(seed_idx != nullptr, "knn_sweep: needs seed lists");
+    LS_REQUIRE(Ns <= 65535, "knn_sweep: Ns=%d exceeds the 16-bit survivor index", Ns);
+    if (C == 32)
+        return knn_sweep_launch_t<32>(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
+    return knn_sweep_launch_t<64>(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
 }
 
 int row_norms_launch(const float* f, int row_f, long long npts, float* norms, hipStream_t st) {

@@ -20,46 +20,6 @@
 
 namespace ls {
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-// value of lane (lane ^ M)
-template <int M>
-__device__ __forceinline__ unsigned lane_xor(unsigned v, int lane) {
-    if constexpr (M == 1) return dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) return dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
-    else if constexpr (M == 3) return dpp_mov<0x1B>(v);     // quad_perm [3,2,1,0]
-    else if constexpr (M == 7) return dpp_mov<0x141>(v);    // row_half_mirror
-    else if constexpr (M == 15) return dpp_mov<0x140>(v);   // row_mirror
-    else if constexpr (M < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);   // bit mode: lane ^ M
-    else return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ M) << 2, (int)v);
-}
-template <int M>
-__device__ __forceinline__ constexpr int pair_bit() { return (M & (M + 1)) == 0 ? (M + 1) / 2 : M; }   // the lower lane of a pair has this bit clear
-
-template <int M>
-__device__ __forceinline__ void cx32(unsigned& v, int lane) {
-    const unsigned o = lane_xor<M>(v, lane);
-    v = (lane & pair_bit<M>()) == 0 ? min(v, o) : max(v, o);
-}
-template <int M>
-__device__ __forceinline__ void cx64(u64& v, int lane) {
-    const u64 o = ((u64)lane_xor<M>((unsigned)(v >> 32), lane) << 32) | lane_xor<M>((unsigned)v, lane);
-    const bool lt = o < v, takemin = (lane & pair_bit<M>()) == 0;
-    v = (takemin == lt) ? o : v;
-}
-// ascending sort of one value per lane over the 64 lanes: bitonic network in the "flip" form (first step of every merge
-// pairs lane i with lane i ^ (k-1), the rest are plain half-cleaners), so that every exchange is a lane-xor and 13 of the 21
-// stages are DPP moves
-#define LS_SORT64(CX, v, lane)                                                                                         \
-    CX<1>(v, lane);                                                                                                    \
-    CX<3>(v, lane); CX<1>(v, lane);                                                                                    \
-    CX<7>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                                                    \
-    CX<15>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                                   \
-    CX<31>(v, lane); CX<8>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                   \
-    CX<63>(v, lane); CX<16>(v, lane); CX<8>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);
-
 constexpr int KX_CH = 1024;   // candidates per chunk (16 per lane)
 
 template <bool FMA, bool SINGLE>
@@ -156,6 +116,129 @@ int knn_xyz_launch(const float* dst, const float* src, const int32_t* dst_rows, 
     if (fma) { if (single) LS_KX(true, true); else LS_KX(true, false); }
     else { if (single) LS_KX(false, true); else LS_KX(false, false); }
 #undef LS_KX
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small feature-space problems (encoder layers 5 and 6: 32 queries x 128 / 32 candidates per instance, D = 384 / 768).
+// The 64 x 64-tile kernel of knn.hip leaves 3/4 (layer 5) or 15/16 (layer 6) of its register micro-tiles on padding and walks
+// the channels in 32-wide chunks with two workgroup barriers each: 65 + 77 us of mostly latency.  Here a workgroup owns 8
+// queries of one instance and 32 candidates at a time, one (query, candidate) pair per thread, whole rows (up to 128
+// channels per pass) staged x-major through LDS with 16-byte copies; a thread reads the x, y and z float4 of four channels
+// and adds the twelve terms in canonical order (j = c*3 + x), so no LDS transpose is needed.  Selection: the 8 x 32 distance
+// tile goes through LDS to two waves whose 16-lane rows merge it (knn_common.h).  Same arithmetic chain, same keys.
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+constexpr int KSM_Q = 8, KSM_S = 32, KSM_CCH = 128;
+constexpr int KSM_ROW = 3 * KSM_CCH + 4;     // floats; (ROW / 4) odd -> the 16 lanes of a ds_read_b128 group hit distinct banks
+
+template <bool FMA>
+__global__ __launch_bounds__(256, 2) void knn_small_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+                                                           const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int C, int K,
+                                                           int32_t* __restrict__ idx_out, float* __restrict__ dist_out, int qblocks) {
+    __shared__ __attribute__((aligned(16))) float lq[KSM_Q * KSM_ROW];
+    __shared__ __attribute__((aligned(16))) float lc[KSM_S * KSM_ROW];
+    __shared__ float ldist[KSM_Q][KSM_S + 1];
+    __shared__ int lqrow[KSM_Q];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = logical / qblocks, q0 = (logical % qblocks) * KSM_Q;
+    const size_t row_f = (size_t)3 * C;
+    const float* dbase = dstf + (size_t)b * dst_n * row_f;
+    const float* sbase = srcf + (size_t)b * Ns * row_f;
+    if (tid < KSM_Q) {
+        const int q = q0 + tid;
+        lqrow[tid] = q < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + q] : q) : -1;
+    }
+    __syncthreads();
+    const int qi = tid >> 5, ci = tid & 31;
+    // rows of this wave's merge: waves 0 and 1, row r = lane >> 4 -> query wave * 4 + r
+    u64 lk = ~0ull, rkey = ~0ull;
+    const int nch = cdiv_dev(C, KSM_CCH);
+    // candidate staging: thread -> row sr = tid >> 3, float4 columns (tid & 7) + 8 m of each x segment; the next pass's rows are
+    // in flight (registers) under the current pass's arithmetic
+    const int sr = tid >> 3, sc = (tid & 7) * 4;
+    // (named scalars: hipcc keeps a prefetch ARRAY that is written in one iteration and read in the next in scratch memory)
+#define KSM_PF_LIST(F) F(0, 0) F(0, 1) F(0, 2) F(0, 3) F(1, 0) F(1, 1) F(1, 2) F(1, 3) F(2, 0) F(2, 1) F(2, 2) F(2, 3)
+#define KSM_PF_DECL(x, m) float4 pf_##x##_##m;
+#define KSM_PF_LOAD(x, m) pf_##x##_##m = *reinterpret_cast<const float4*>(rp + (size_t)x * C + min(m * 32, cwp - 32));
+#define KSM_PF_STORE(x, m) \
+    if (sc + m * 32 < cw) *reinterpret_cast<float4*>(&lc[sr * KSM_ROW + x * KSM_CCH + sc + m * 32]) = pf_##x##_##m;
+    KSM_PF_LIST(KSM_PF_DECL)
+#define KSM_PREFETCH(S0, CH)                                                                                  \
+    {                                                                                                         \
+        const int c0p = (CH) * KSM_CCH, cwp = min(C - c0p, KSM_CCH);                                          \
+        const float* rp = sbase + (size_t)min((S0) + sr, Ns - 1) * row_f + c0p + sc;                          \
+        KSM_PF_LIST(KSM_PF_LOAD)   /* columns past this pass's width: a clamped re-read inside the row */     \
+    }
+    KSM_PREFETCH(0, 0)
+    for (int s0 = 0; s0 < Ns; s0 += KSM_S) {
+        float d = 0.0f;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int c0 = ch * KSM_CCH, cw = min(C - c0, KSM_CCH);   // channels of this pass
+            __syncthreads();   // previous pass / previous merge done with lq, lc, ldist
+            if (nch > 1 || s0 == 0) {   // query rows: 32 threads per row
+                const int gr = lqrow[qi];
+                for (int x = 0; x < 3; ++x)
+                    for (int c4 = ci * 4; c4 < cw; c4 += 128)
+                        *reinterpret_cast<float4*>(&lq[qi * KSM_ROW + x * KSM_CCH + c4]) =
+                            gr >= 0 ? *reinterpret_cast<const float4*>(dbase + (size_t)gr * row_f + (size_t)x * C + c0 + c4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            KSM_PF_LIST(KSM_PF_STORE)
+            __syncthreads();
+            {
+                int nch2 = ch + 1, ns0 = s0;
+                if (nch2 == nch) { nch2 = 0; ns0 = s0 + KSM_S; }
+                KSM_PREFETCH(min(ns0, Ns - 1), nch2)   // past the end: a harmless re-read of the last row
+            }
+            const float* qp = &lq[qi * KSM_ROW];
+            const float* cp = &lc[ci * KSM_ROW];
+#pragma unroll 2
+            for (int c4 = 0; c4 < cw; c4 += 4) {
+                const float4 ax = *reinterpret_cast<const float4*>(qp + c4), ay = *reinterpret_cast<const float4*>(qp + KSM_CCH + c4),
+                             az = *reinterpret_cast<const float4*>(qp + 2 * KSM_CCH + c4);
+                const float4 bx = *reinterpret_cast<const float4*>(cp + c4), by = *reinterpret_cast<const float4*>(cp + KSM_CCH + c4),
+                             bz = *reinterpret_cast<const float4*>(cp + 2 * KSM_CCH + c4);
+                d = accq<FMA>(d, ax.x, bx.x); d = accq<FMA>(d, ay.x, by.x); d = accq<FMA>(d, az.x, bz.x);
+                d = accq<FMA>(d, ax.y, bx.y); d = accq<FMA>(d, ay.y, by.y); d = accq<FMA>(d, az.y, bz.y);
+                d = accq<FMA>(d, ax.z, bx.z); d = accq<FMA>(d, ay.z, by.z); d = accq<FMA>(d, az.z, bz.z);
+                d = accq<FMA>(d, ax.w, bx.w); d = accq<FMA>(d, ay.w, by.w); d = accq<FMA>(d, az.w, bz.w);
+            }
+        }
+        ldist[qi][ci] = d;
+        __syncthreads();
+        if (wave < 2) {
+            const int qr = wave * 4 + (lane >> 4), e = lane & 15;
+            const int ca = s0 + e, cb = s0 + e + 16;
+            const bool live = lqrow[qr] >= 0;
+            u64 k0 = make_key(ldist[qr][e], ca, live && ca < Ns), k1 = make_key(ldist[qr][e + 16], cb, live && cb < Ns);
+            key_cx(k0, k1);
+            merge_keys<false>(k0, k1, ~0ull, ~0ull, lk, rkey, K, lane);
+        }
+    }
+    if (wave < 2) {
+        const int qr = wave * 4 + (lane >> 4), e = lane & 15, q = q0 + qr;
+        if (q < Nd && e < K) {
+            const size_t o = ((size_t)b * Nd + q) * K + e;
+            const unsigned hi = (unsigned)(lk >> 32), lo = (unsigned)lk;
+            idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lo;
+            if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
+        }
+    }
+}
+
+int knn_small_launch(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int C, int K, bool fma,
+                     int32_t* idx_out, float* dist_out, hipStream_t st) {
+    LS_REQUIRE(C % 4 == 0, "knn_small: C=%d must be a multiple of 4", C);
+    const int qblocks = cdiv(Nd, KSM_Q);
+    if (fma)
+        hipLaunchKernelGGL(knn_small_kernel<true>, dim3(B * qblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, C, K, idx_out,
+                           dist_out, qblocks);
+    else
+        hipLaunchKernelGGL(knn_small_kernel<false>, dim3(B * qblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, C, K, idx_out,
+                           dist_out, qblocks);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

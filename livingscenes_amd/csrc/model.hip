@@ -22,6 +22,8 @@ void set_error(const char* fmt, ...) {
 int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, void*, const int32_t*, int, int,
                  hipStream_t);
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags);
+int knn_compose_hints_launch(const int32_t* prev_knn, const int32_t* prev_rows, int B, int Nd, int Ns, int32_t* inv, int32_t* hints, hipStream_t st);
+bool knn_would_sweep(int C, int Ns, unsigned flags);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
@@ -114,7 +116,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_hint, o_inv, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -173,6 +175,8 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_knn = take((size_t)B * maxKnn * 4);
     p.o_knn2 = take((size_t)B * maxKnn * 4);
     p.o_knns = take(maxKs + 256);
+    p.o_hint = take((size_t)B * maxKnn * 4);   // composed hints of a layer that follows a down-sampling layer
+    p.o_inv = take((size_t)B * N * 4);         // inverse of that layer's FPS selection
     p.o_fA = take((size_t)B * maxF * 4);
     p.o_fB = take((size_t)B * maxF * 4);
     p.o_msg = take((size_t)B * maxF * 4);
@@ -362,6 +366,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     bool joined = false;
     size_t knn_off = 0, fps_off = 0;
     const int32_t* prev_knn = nullptr;
+    const int32_t* prev_rows = nullptr;   // the previous layer's FPS selection (rows of its source set), if it down-sampled
     for (int i = 0; i < p.L; ++i) {
         const int Ns = p.Ns[i], Nd = p.Nd[i], Co = p.Co[i];
         const int32_t* dst_rows = nullptr;
@@ -413,6 +418,12 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
                 // == this layer's source set, so its indices address this layer's candidates directly)
                 const int32_t* seeds = (m->seed_knn && prev_knn && p.level[i - 1] < 0) ? prev_knn : nullptr;
                 const unsigned kflags = flags | (m->knn_filter ? 0u : LS_FLAG_KNN_VALU_ONLY);
+                if (m->seed_knn && prev_knn && prev_rows && knn_would_sweep(Cin, Ns, kflags)) {
+                    // the previous layer down-sampled: map its lists into this layer's (smaller) source set, two hops deep
+                    rc = knn_compose_hints_launch(prev_knn, prev_rows, B, Ns, p.Ns[i - 1], I(p.o_inv), I(p.o_hint), st);
+                    if (rc != LS_OK) return rc;
+                    seeds = I(p.o_hint);
+                }
                 rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
@@ -438,6 +449,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
         }
         std::swap(cur, nxt);
         prev_knn = knn;
+        prev_rows = dst_rows;
     }
     if (p.nlevels > 0 && !joined) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
 

@@ -32,7 +32,8 @@ def rows(f):
 
 # ------------------------------------------------------------------------------------------------ k-NN
 @pytest.mark.parametrize("contract", [0, 1])
-@pytest.mark.parametrize("shape", [(2, 100, 150, 1), (2, 70, 130, 32), (1, 64, 64, 64), (3, 33, 257, 96), (1, 5, 9, 32)])
+@pytest.mark.parametrize("shape", [(2, 100, 150, 1), (2, 70, 130, 32), (1, 64, 64, 64), (3, 33, 257, 96), (1, 5, 9, 32),
+                                   (2, 32, 128, 128), (2, 32, 32, 256), (1, 20, 45, 160), (2, 9, 70, 64)])
 def test_knn_bit_exact(shape, contract):
     from livingscenes_amd import ops
     from oracle import canon
@@ -108,15 +109,16 @@ def test_knn_large_batch_unsplit_path():
     assert np.array_equal(ops.knn(ft, ft, 16, seeds=hints, flags=_lib.FLAG_KNN_VALU_ONLY).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("C", [32, 64])
 @pytest.mark.parametrize("case", ["offset", "near_duplicates", "clustered", "scale_mix"])
-def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
+def test_knn_mfma_filter_is_exact_on_adversarial_features(case, C):
     """The MFMA sweep kernel may only drop pairs that provably cannot enter a list.  Stress the cancellation in
     |q|^2+|s|^2-2q.s: a huge common offset, near-duplicate points, tight clusters, wildly different norms.  The result
     must be bit-identical to the oracle for the all-VALU kernel (un-seeded) AND the seeded MFMA sweep kernel."""
     from livingscenes_amd import _lib, ops
     from oracle import canon
     rng = np.random.default_rng({"offset": 1, "near_duplicates": 2, "clustered": 3, "scale_mix": 4}[case])
-    B, N, C = 3, 640, 32
+    B, N = 3, 640
     f = rng.standard_normal((B, N, 3, C)).astype(np.float32)
     if case == "offset":
         f = (f * 1e-3 + 50.0).astype(np.float32)            # norms ~ 7e5, spreads ~ 1e-3: d^ is pure cancellation noise
@@ -142,7 +144,8 @@ def test_knn_mfma_filter_is_exact_on_adversarial_features(case):
             assert np.array_equal(i3.cpu().numpy(), r2) and np.array_equal(d3.cpu().numpy(), d2), (name, fl)
 
 
-@pytest.mark.parametrize("shape", [(2, 200, 200, 32), (3, 70, 330, 64), (40, 256, 1024, 32), (3, 70, 330, 32), (1, 33, 100, 32)])
+@pytest.mark.parametrize("shape", [(2, 200, 200, 32), (3, 70, 330, 64), (40, 256, 1024, 32), (3, 70, 330, 32), (1, 33, 100, 32),
+                                   (8, 128, 512, 64)])
 def test_knn_hints_do_not_change_the_result(shape):
     """seed_idx are HINTS: exact neighbours, random indices, duplicates of each other's ranges, -1 and out-of-range values
     must all yield the oracle's answer bit for bit (also through the candidate-split + merge path)."""
@@ -164,7 +167,7 @@ def test_knn_hints_do_not_change_the_result(shape):
     hints["random"][:, :, 1] = hints["random"][:, :, 0]  # duplicate hints inside a row
     from livingscenes_amd import _lib
     for name, h in hints.items():
-        for fl in (0, _lib.FLAG_KNN_VALU_ONLY):   # MFMA sweep kernel (C == 32) / all-VALU kernel
+        for fl in (0, _lib.FLAG_KNN_VALU_ONLY):   # MFMA sweep kernel (C == 32, 64) / all-VALU kernel
             idx, dist = ops.knn(dt, st, 16, seeds=torch.from_numpy(h).to(_dev()), return_dist=True, flags=fl)
             assert np.array_equal(idx.cpu().numpy(), ref), (name, fl)
             assert np.array_equal(dist.cpu().numpy(), refd), (name, fl)
