@@ -254,13 +254,13 @@ static size_t knn_partial_bytes(int B, int Nd, int Ns) {
 static bool knn_uses_sweep(int C, bool seeded, int Ns, unsigned flags) {
     return (C == 32 || C == 64) && seeded && Ns <= 65535 && !(flags & LS_FLAG_KNN_VALU_ONLY);
 }
-size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns);
+size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C);
 int knn_sweep_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, bool, int32_t*, float*, const int32_t*, int,
                      int, void*, hipStream_t);
 int knn_xyz_launch(const float*, const float*, const int32_t*, int, int, int, int, int, bool, int32_t*, float*, hipStream_t);
 int knn_small_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, bool, int32_t*, float*, hipStream_t);
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags) {
-    if (knn_uses_sweep(C, seeded, Ns, flags)) return knn_sweep_scratch_bytes(B, Nd, dst_n, Ns);
+    if (knn_uses_sweep(C, seeded, Ns, flags)) return knn_sweep_scratch_bytes(B, Nd, dst_n, Ns, C);
     return knn_partial_bytes(B, Nd, Ns);
 }
 

@@ -422,10 +422,211 @@ __global__ __launch_bounds__(256, 3) void knn_finish_wave_kernel(const float* __
     }
 }
 
-size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns) {
+// ---------------------------------------------------------------------------------------------------------------------
+// 2'. bf16 sweep.  The filter only has to be SAFE, not accurate, so S = q . s does not need fp32 operands: with the rows
+// centred on the instance mean (distances are translation invariant) and rounded to bf16 (unit roundoff 2^-8),
+//     |S~ - S| <= (2^-8 + 2^-17) (|q'|^2 + |s'|^2)       (Cauchy-Schwarz; fp32 accumulation adds D 2^-23 of the same scale)
+// so  d^ = |q'|^2 + |s'|^2 - 2 S~  is within  eps_b (|q'|^2 + |s'|^2),  eps_b = 1.02 * 2^-7 + 6 (D+4) 2^-24,  of the canonical
+// distance (the second term: fp32 norms, the canonical chain's own rounding, the centring subtraction).  A pair is dropped
+// only if  d^ - eps_b (..) > kth;  on the encoder's features kth / (|q'|^2+|s'|^2) is 0.04 .. 0.3, so the wider margin
+// admits 5 .. 20 % more survivors than the fp32 sweep (tests/tools/knn_seed_quality.py) while the matrix cores run
+// v_mfma_f32_32x32x16_bf16 at 16x the fp32 rate.  Without centring a common offset would drown the distances in eps_b.
+//
+// Layout: knn_prep_bf16_kernel writes the centred rows "fragment-major": [instance][32-row tile][k-step of 16 dims][lane
+// (k-half h, row j)][8 bf16], i.e. exactly the 1 KB a wave's B operand load wants -> one fully coalesced 16-byte-per-lane load
+// per MFMA, no LDS staging, no workgroup barriers; the waves are independent (32 queries x a candidate range each) and any
+// (queries x splits) grid fills the chip.  Per-query hints live in a wave-private LDS bitmap (a pass that is a hint is not
+// recorded), survivors are appended through global counters.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int KB_MAXNS = 2048;   // bitmap words per query = Ns / 32 <= 64
+constexpr int KB_CAPW = 64;      // survivor slots per (wave, query) in LDS
+
+__device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u);   // inf / nan
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// centre of an instance: the mean of its first min(N, 64) rows (any centre is valid -- distances are translation invariant
+// and the error bound is relative to the centred norms; the encoder's rows are in FPS order, so a prefix is a spread-out
+// sample).  grid (B, ceil(D/64)), 1024 threads = 64 dims x 16 row groups
+__global__ __launch_bounds__(1024) void knn_mean_rows_kernel(const float* __restrict__ f, int N, int D, float* __restrict__ mu) {
+    __shared__ float part[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int b = blockIdx.x, d = blockIdx.y * 64 + tx;
+    const int n = min(N, 64);
+    float s = 0.f;
+    if (d < D)
+        for (int r = ty; r < n; r += 16) s += f[((size_t)b * N + r) * D + d];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && d < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][tx];
+        mu[(size_t)b * D + d] = t / (float)n;
+    }
+}
+
+// one wave per 32-row tile: lane (h, j) walks row j in 16-dim steps (dims kk*16 + h*8 .. +7: two float4 in, one 16-byte store
+// into the step's 1 KB fragment block), accumulating the centred row's squared norm on the way
+__global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restrict__ f, const float* __restrict__ mu, int N, int Npad, int D,
+                                                            int tiles_total, unsigned short* __restrict__ out, float* __restrict__ norms) {
+    const int tg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tg >= tiles_total) return;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int tpi = Npad >> 5, b = tg / tpi, tile = tg % tpi, r = tile * 32 + j;
+    const int KK = D >> 4;
+    const bool live = r < N;
+    const float* rp = f + ((size_t)b * N + (live ? r : 0)) * D + h * 8;
+    const float* mp = mu + (size_t)b * D + h * 8;
+    unsigned short* op = out + (((size_t)b * tpi + tile) * KK * 64 + lane) * 8;
+    float s = 0.f;
+#pragma unroll 3
+    for (int kk = 0; kk < KK; ++kk) {
+        const float4 x0 = *reinterpret_cast<const float4*>(rp + kk * 16), x1 = *reinterpret_cast<const float4*>(rp + kk * 16 + 4);
+        const float4 m0 = *reinterpret_cast<const float4*>(mp + kk * 16), m1 = *reinterpret_cast<const float4*>(mp + kk * 16 + 4);
+        float c[8] = {x0.x - m0.x, x0.y - m0.y, x0.z - m0.z, x0.w - m0.w, x1.x - m1.x, x1.y - m1.y, x1.z - m1.z, x1.w - m1.w};
+        uint4 w;
+        unsigned pk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float c0 = live ? c[2 * i] : 0.f, c1 = live ? c[2 * i + 1] : 0.f;
+            s += c0 * c0 + c1 * c1;
+            pk[i] = f32_to_bf16_rne(c0) | (f32_to_bf16_rne(c1) << 16);
+        }
+        w.x = pk[0]; w.y = pk[1]; w.z = pk[2]; w.w = pk[3];
+        *reinterpret_cast<uint4*>(op + (size_t)kk * 512) = w;
+    }
+    s += __shfl_xor(s, 32, 64);
+    if (h == 0 && live) norms[(size_t)b * N + r] = s;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
+                                                             const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
+                                                             const float* __restrict__ nrm_src, int Nd, int dst_n, int dst_npad, int Ns,
+                                                             int ns_pad, int K, int qgroups, int nsplit, int total_waves, float epsB,
+                                                             const u64* __restrict__ seedkeys, int32_t* __restrict__ surv_cnt,
+                                                             unsigned short* __restrict__ surv) {
+    constexpr int KK = D / 16;
+    // dynamic LDS, per wave: hint bitmap 32 x (ns_pad / 32) words | survivor counters [32] | survivor lists [32][KB_CAPW] u16
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // consecutive waves (one instance) share an XCD's L2
+    if (wg >= total_waves) return;                                // (no workgroup barrier in this kernel)
+    const int sp = wg % nsplit, g = (wg / nsplit) % qgroups, b = wg / (nsplit * qgroups);
+    const int q0 = g * 32, l31 = lane & 31, lh = lane >> 5;
+    const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
+    const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
+    const float* nsb = nrm_src + (size_t)b * Ns;
+    const float om = 1.0f - epsB;
+    const int words = ns_pad >> 5;
+    const int per_wave = 32 * words + 32 + 32 * KB_CAPW / 2;   // 32-bit words
+    unsigned* bits = lds_dyn + (size_t)wave * per_wave;
+    int* lcnt = reinterpret_cast<int*>(bits + 32 * words);
+    unsigned short* llist = reinterpret_cast<unsigned short*>(lcnt + 32);
+
+    // A fragments: query row q0 + l31 (padding queries: row 0; their threshold drops everything)
+    bf16x8 a[KK];
+    {
+        const int qi = q0 + l31;
+        const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
+        const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+    }
+    // drop  <=>  d^ - eps nn > kth  <=>  S~ < ((1-eps)(nq + ns) - kth) / 2 = A[row] + Bc[candidate]
+    float A[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int q = q0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+        float v = INFINITY;                                        // padding query: S < inf, always dropped
+        if (q < Nd) {
+            const int row = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
+            const unsigned hi = (unsigned)(seedkeys[((size_t)b * Nd + q) * 16 + (K - 1)] >> 32);
+            const float kth = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);   // fewer than K distinct hints: nothing is dropped
+            v = 0.5f * (om * nrm_dst[(size_t)b * dst_n + row] - kth);
+        }
+        A[rr] = v;
+    }
+    // hint bitmap of the wave's 32 queries
+    for (int i = lane; i < 32 * words + 32; i += 64) bits[i] = 0u;   // bitmap and counters
+    __builtin_amdgcn_wave_barrier();
+    if (q0 + l31 < Nd) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const u64 k = seedkeys[((size_t)b * Nd + q0 + l31) * 16 + lh * 8 + e];
+            if ((unsigned)(k >> 32) != 0xFFFFFFFFu) {
+                const unsigned c = (unsigned)k;
+                atomicOr(&bits[l31 * words + (c >> 5)], 1u << (c & 31));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
+    const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
+#pragma unroll 2
+    for (int t = t0; t < t1; ++t) {
+        const unsigned short* bp = sqb + ((size_t)t * KK * 64 + lane) * 8;
+        bf16x8 bf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        const int cg = t * 32 + l31;
+        const float Bc = 0.5f * om * nsb[min(cg, Ns - 1)];
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bf[kk], S, 0, 0, 0);
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask |= (S[r] < A[r] + Bc) ? 0u : (1u << r);
+        if (cg >= Ns) mask = 0;
+        while (mask) {
+            const int r = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh, q = q0 + qr;
+            if (q < Nd && !((bits[qr * words + (cg >> 5)] >> (cg & 31)) & 1u)) {   // a hint's key is in the seeded list already
+                // wave-private list first (an LDS atomic returns in ~100 cycles; a returning global atomic per survivor inside
+                // this per-lane serial loop costs a memory round trip each); a full list spills to the global path directly
+                const int lp = atomicAdd(&lcnt[qr], 1);
+                if (lp < KB_CAPW) {
+                    llist[qr * KB_CAPW + lp] = (unsigned short)cg;
+                } else {
+                    const size_t qg = (size_t)b * Nd + q;
+                    const int pos = atomicAdd(&surv_cnt[qg], 1);
+                    if (pos < KS_CAP) surv[qg * KS_CAP + pos] = (unsigned short)cg;
+                }
+            }
+        }
+    }
+    // flush: one global atomic per query reserves the wave's slots
+    __builtin_amdgcn_wave_barrier();
+    if (lh == 0 && q0 + l31 < Nd) {
+        const int n = min(lcnt[l31], KB_CAPW);
+        if (n > 0) {
+            const size_t qg = (size_t)b * Nd + q0 + l31;
+            const int base = atomicAdd(&surv_cnt[qg], n);
+            for (int i = 0; i < n && base + i < KS_CAP; ++i) surv[qg * KS_CAP + base + i] = llist[l31 * KB_CAPW + i];
+        }
+    }
+}
+
+static inline size_t pad32(size_t n) { return (n + 31) & ~(size_t)31; }
+static bool knn_sweep_bf16_enabled() {
+    static const bool off = getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0;   // A/B: fp32 sweep kernel
+    return !off;
+}
+size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C) {
     const size_t nq = (size_t)B * Nd;
+    const size_t D = (size_t)3 * C;
     return ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256      // row norms
-           + nq * 16 * sizeof(u64) + nq * sizeof(int32_t) + nq * KS_CAP * sizeof(unsigned short) + 256;
+           + nq * 16 * sizeof(u64) + nq * sizeof(int32_t) + nq * KS_CAP * sizeof(unsigned short) + 256
+           + (size_t)B * D * sizeof(float) + 256                            // instance means
+           + ((size_t)B * pad32(Ns) + (size_t)B * pad32(dst_n)) * D * sizeof(unsigned short) + 512;   // bf16 images (src, dst)
 }
 
 template <int CC>
@@ -433,18 +634,14 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
                               int32_t* idx_out, float* dist_out, const int32_t* seed_idx, int seed_n, int seed_by_row, void* scratch,
                               hipStream_t st) {
     const int C = CC;
+    constexpr int D = 3 * CC;
     const size_t nq = (size_t)B * Nd;
+    const bool bf16 = knn_sweep_bf16_enabled() && Ns <= KB_MAXNS;
     char* sc = (char*)scratch;
     float* nsrc = (float*)sc;
     float* ndst = nsrc;
     size_t off = (size_t)B * Ns * sizeof(float);
-    int rc = row_norms_launch(src, 3 * C, (long long)B * Ns, nsrc, st);
-    if (rc != LS_OK) return rc;
-    if (dst != src) {
-        ndst = (float*)(sc + off);
-        rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
-        if (rc != LS_OK) return rc;
-    }
+    if (dst != src) ndst = (float*)(sc + off);
     off += (size_t)B * dst_n * sizeof(float);
     off = (off + 255) & ~(size_t)255;
     u64* seedkeys = (u64*)(sc + off);
@@ -452,6 +649,36 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     int32_t* surv_cnt = (int32_t*)(sc + off);
     off += nq * sizeof(int32_t);
     unsigned short* surv = (unsigned short*)(sc + off);
+    off += nq * KS_CAP * sizeof(unsigned short);
+    off = (off + 255) & ~(size_t)255;
+    float* mu = (float*)(sc + off);
+    off += (size_t)B * D * sizeof(float);
+    off = (off + 255) & ~(size_t)255;
+    unsigned short* sq = (unsigned short*)(sc + off);
+    const int ns_pad = (int)pad32(Ns), dst_npad = (int)pad32(dst_n);
+    unsigned short* dq = sq;
+    if (dst != src) dq = sq + (size_t)B * ns_pad * D;
+    int rc;
+    if (bf16) {
+        hipLaunchKernelGGL(knn_mean_rows_kernel, dim3(B, cdiv(D, 64)), dim3(1024), 0, st, src, Ns, D, mu);
+        LS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, mu, Ns, ns_pad, D,
+                           B * (ns_pad / 32), sq, nsrc);
+        LS_LAUNCH_CHECK();
+        if (dst != src) {   // same centre for both sets
+            hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, mu, dst_n, dst_npad, D,
+                               B * (dst_npad / 32), dq, ndst);
+            LS_LAUNCH_CHECK();
+        }
+        LS_HIP_CHECK(hipMemsetAsync(surv_cnt, 0, nq * sizeof(int32_t), st));
+    } else {
+        rc = row_norms_launch(src, 3 * C, (long long)B * Ns, nsrc, st);
+        if (rc != LS_OK) return rc;
+        if (dst != src) {
+            rc = row_norms_launch(dst, 3 * C, (long long)B * dst_n, ndst, st);
+            if (rc != LS_OK) return rc;
+        }
+    }
 
     const int groups = cdiv(Nd, 4);                 // one wave per four queries
     const int gblocks = cdiv((long long)B * groups, 4);
@@ -464,8 +691,19 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         hipLaunchKernelGGL((knn_seed_kernel<CC, false>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
                            seed_by_row, seedkeys, groups, B * groups);
     LS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_sweep_kernel<CC>, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles, epsE,
-                       seedkeys, surv_cnt, surv);
+    if (bf16) {
+        const int qgroups = cdiv(Nd, 32);
+        int nsplit = 1;   // >= ~4 waves per SIMD over the chip (4096 waves) when the query grid alone is smaller
+        while ((long long)B * qgroups * nsplit < 4096 && nsplit * 8 <= ns_pad / 32 && nsplit < 16) nsplit *= 2;   // >= 4 tiles per wave
+        const int total_waves = B * qgroups * nsplit;
+        const float epsB = 1.02f * 0.0078125f + epsE;
+        const size_t lds = (size_t)4 * (32 * (ns_pad / 32) + 32 + 32 * KB_CAPW / 2) * sizeof(unsigned);   // <= 52 KB
+        hipLaunchKernelGGL(knn_sweep_bf16_kernel<D>, dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, Nd, dst_n,
+                           dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
+    } else {
+        hipLaunchKernelGGL(knn_sweep_kernel<CC>, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles,
+                           epsE, seedkeys, surv_cnt, surv);
+    }
     LS_LAUNCH_CHECK();
     if constexpr (CC == 32) {
         if (fma)

@@ -37,7 +37,19 @@ def survivors(src, dst, hints):
             v = torch.sort(d[b, q, u.long()])[0]
             kth.append(v[15] if len(v) >= 16 else torch.tensor(float("inf"), dtype=torch.float64))
     kth = torch.stack(kth).reshape(d.shape[0], d.shape[1], 1)
-    return (d <= kth).sum(-1).flatten().numpy()
+    exact = (d <= kth).sum(-1).flatten().numpy()
+    # bf16 filter on centred features: d^ = |q|^2 + |s|^2 - 2 q~.s~, dropped iff d^ - eps (|q|^2+|s|^2) > kth, eps = 2.05 * 2^-8
+    mu = src.mean(1, keepdim=True)
+    sc, dc = (src - mu).float(), (dst - mu).float()
+    S = torch.matmul(dc.bfloat16().float(), sc.bfloat16().float().transpose(1, 2)).double()
+    nn = (dc.double() ** 2).sum(-1, keepdim=True) + (sc.double() ** 2).sum(-1).unsqueeze(1)
+    dh = nn - 2 * S
+    res = {"exact": exact}
+    for name, eps in (("fp32", 6 * (src.shape[2] + 4) * 2.0 ** -24), ("bf16", 2.05 * 2.0 ** -8), ("bf16x2", 4.0 * 2.0 ** -16)):
+        dd = dh if name == "bf16" else (nn - 2 * torch.matmul(dc.double(), sc.double().transpose(1, 2)))
+        res[name] = ((dd - eps * nn) <= kth).sum(-1).flatten().numpy()
+    res["d_over_nn"] = float((kth.squeeze(-1)[torch.isfinite(kth.squeeze(-1))] / nn.mean(-1)[torch.isfinite(kth.squeeze(-1))]).median())
+    return res
 
 
 prev = None
@@ -57,15 +69,20 @@ for i in range(1, L):
             pkb = pk[b].numpy()
             for q in range(Ns):
                 h = [v for v in inv[pkb[q]] if v >= 0]
-                one = list(h)
-                for nb in one:
-                    if len(h) >= 16: break
-                    for v in inv[pkb[nb]]:
+                t = 0
+                while t < len(h) and len(h) < 16:      # breadth first
+                    for v in inv[pkb[h[t]]]:
                         if v >= 0 and v not in h and len(h) < 16: h.append(v)
+                    t += 1
+                e = 0
+                while len(h) < 16:                      # isolated point: arbitrary distinct rows
+                    v = (q + 1 + e * 37) % Ns; e += 1
+                    if v not in h: h.append(v)
                 hints[b, q, :len(h)] = torch.tensor(h[:16])
         if fidx is not None:
             hints = torch.gather(hints, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 16))
         kind = "composed"
-    s = survivors(src, dst, hints)
-    print(f"layer {i}: Nd={Nd} Ns={Ns} D={src.shape[2]} hints={kind}: survivors/query mean {s.mean():.1f} median {np.median(s):.0f} "
-          f"p90 {np.percentile(s, 90):.0f} max {s.max()}  (of {Ns})")
+    res = survivors(src, dst, hints)
+    print(f"layer {i}: Nd={Nd} Ns={Ns} D={src.shape[2]} hints={kind}  kth/(|q|^2+|s|^2) median {res.pop('d_over_nn'):.3f}")
+    for name, s in res.items():
+        print(f"    {name:7s} survivors/query mean {s.mean():6.1f} median {np.median(s):4.0f} p90 {np.percentile(s, 90):4.0f} max {s.max():4d}  (of {Ns})")
