@@ -259,8 +259,12 @@ def main():
         avg_s = dom["total_ms"] / dom["launches"] * 1e-3
         t_hbm, t_fl = abytes / (HBM_PEAK_GBS * 1e9), aflops / (FP32_PEAK_TFLOPS * 1e12)
         if t_fl >= t_hbm:
-            roof = dict(bound="mfma", pipe="valu-f32" if dom["kind"] != "gemm_edge" else "mfma-f32", achieved=aflops / avg_s / 1e12,
-                        peak=FP32_PEAK_TFLOPS, unit="TFLOP/s")
+            pipe = {"gemm_edge": "mfma-f32", "gemm_glob": "mfma-f32",
+                    "knn": "valu-f32 exact distances (+ bf16-mfma safe filter on the seeded layers)"}.get(dom["kind"], "valu-f32")
+            roof = dict(bound="mfma", pipe=pipe, achieved=aflops / avg_s / 1e12, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s")
+            if dom["kind"] == "knn":
+                roof["note"] = ("one k-NN graph build = the launch sequence of that layer (hints / centre / bf16 image / seed / sweep / "
+                                "finish where seeded); achieved = algorithmic 3*Nd*Ns*3C flops of the direct-difference form / its duration")
         else:
             roof = dict(bound="hbm", achieved=abytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
