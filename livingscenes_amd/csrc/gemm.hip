@@ -18,6 +18,29 @@
 namespace ls {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// ---- fp32 GEMM on the bf16 matrix cores ("3 x bf16 split", SPLIT = true).  An fp32 value is the exact sum of three bf16 pieces
+// up to 2^-24 relative: a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2) (round to nearest; the
+// residuals are exact in fp32).  The product a b is then a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1) + O(2^-24 |a b|): six
+// v_mfma_f32_32x32x16_bf16 (exact bf16 x bf16 products, fp32 accumulate) per 16 k instead of eight v_mfma_f32_32x32x2_f32 at
+// 1/16 of the rate -> 2.7x less matrix-pipe time for a result that is as accurate as the fp32 FMA chain (measured against
+// fp64: scripts/gemm_microbench.py --check).  The split runs on the VALU while the tile is staged (v_cvt_pk_bf16_f32: ~5.5
+// instructions per value), each piece goes to its own LDS plane ([row][16 k] bf16 = 32 B rows: a lane's 16-byte operand
+// read is contiguous over the wave, conflict-free).
+__device__ __forceinline__ unsigned cvt2_bf16(f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
+__device__ __forceinline__ f32x2_t expand2_bf16(unsigned u) { return f32x2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)}; }
+// four consecutive-k values -> their three bf16 pieces, packed as 4 x bf16 = 8 bytes per piece
+__device__ __forceinline__ void split3_bf16(const float4& v, uint2& p1, uint2& p2, uint2& p3) {
+    const f32x2_t lo = {v.x, v.y}, hi = {v.z, v.w};
+    p1.x = cvt2_bf16(lo); p1.y = cvt2_bf16(hi);
+    const f32x2_t r1l = lo - expand2_bf16(p1.x), r1h = hi - expand2_bf16(p1.y);
+    p2.x = cvt2_bf16(r1l); p2.y = cvt2_bf16(r1h);
+    const f32x2_t r2l = r1l - expand2_bf16(p2.x), r2h = r1h - expand2_bf16(p2.y);
+    p3.x = cvt2_bf16(r2l); p3.y = cvt2_bf16(r2h);
+}
 
 constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 
@@ -57,6 +80,7 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
 
 // Optional row gather (down-sampled encoder layers): output row m = (b*gNd + n)*3 + x reads A row
 // (b*gNs + a_rows[b*gNd + n])*3 + x, i.e. the GEMM runs only on the FPS-selected points of each instance.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
                                                        int ldc, int M, int N, int K, int relu, int ntiles_n,
@@ -108,12 +132,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             rb[h] = (gn < N && gk < kend) ? *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // SPLIT: three bf16 planes per operand, plane = 128 rows x 32 bytes
+    char* Ap = reinterpret_cast<char*>(smem);
+    char* Bp = Ap + 3 * 4096;
     auto lstore = [&]() {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = sr0 + h * 64;
-            *reinterpret_cast<float4*>(&As[r * GLD + sk]) = ra[h];
-            *reinterpret_cast<float4*>(&Bs[r * GLD + sk]) = rb[h];
+            if constexpr (SPLIT) {
+                uint2 p1, p2, p3;
+                split3_bf16(ra[h], p1, p2, p3);
+                *reinterpret_cast<uint2*>(Ap + r * 32 + sk * 2) = p1;
+                *reinterpret_cast<uint2*>(Ap + 4096 + r * 32 + sk * 2) = p2;
+                *reinterpret_cast<uint2*>(Ap + 8192 + r * 32 + sk * 2) = p3;
+                split3_bf16(rb[h], p1, p2, p3);
+                *reinterpret_cast<uint2*>(Bp + r * 32 + sk * 2) = p1;
+                *reinterpret_cast<uint2*>(Bp + 4096 + r * 32 + sk * 2) = p2;
+                *reinterpret_cast<uint2*>(Bp + 8192 + r * 32 + sk * 2) = p3;
+            } else {
+                *reinterpret_cast<float4*>(&As[r * GLD + sk]) = ra[h];
+                *reinterpret_cast<float4*>(&Bs[r * GLD + sk]) = rb[h];
+            }
         }
     };
 
@@ -124,6 +163,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         __syncthreads();
         if (k0 + GK < kend) gload(k0 + GK);  // in flight under the MFMA block
         const int lr = lane & 31, lk = (lane >> 5) * 4;
+        if constexpr (SPLIT) {
+            bf16x8_t a[2][3], b[2][3];   // lane (row lr, half lane>>5): k = 8 (lane>>5) .. +7 of the slab, the same for A and B
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p3 = 0; p3 < 3; ++p3) {
+                    a[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ap + p3 * 4096 + (wm * 64 + i * 32 + lr) * 32 + (lane >> 5) * 16));
+                    b[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bp + p3 * 4096 + (wn * 64 + i * 32 + lr) * 32 + (lane >> 5) * 16));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {   // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        } else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4 a[2], b[2];
@@ -353,21 +413,31 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         LS_LAUNCH_CHECK();
         return LS_OK;
     }
+    // LS_GEMM_BF16X3=0: exact fp32 FMA chains on v_mfma_f32_32x32x2_f32 (A/B timing, bit-for-bit comparison with earlier builds)
+    static const bool split = !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
     const int nsplit = scratch ? gemm_choose_splits(M, N, K) : 1;
     if (nsplit > 1) {
         int kchunk = cdiv(cdiv(K, nsplit), GK) * GK;
         const int ns = cdiv(K, kchunk);
         const size_t slab = (size_t)M * N;
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn, a_rows,
-                           gNd, gNs, kchunk, slab);
+        if (split)
+            hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
+                               a_rows, gNd, gNs, kchunk, slab);
+        else
+            hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
+                               a_rows, gNd, gNs, kchunk, slab);
         LS_LAUNCH_CHECK();
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv((long long)M * (N / 4), 256)), dim3(256), 0, st, scratch, slab, ns, bias, out,
                            ldc, M, N, relu);
         LS_LAUNCH_CHECK();
         return LS_OK;
     }
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                       gNd, gNs, K, (size_t)0);
+    if (split)
+        hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
+                           gNd, gNs, K, (size_t)0);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
+                           gNd, gNs, K, (size_t)0);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

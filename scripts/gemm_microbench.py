@@ -7,6 +7,17 @@ dev = torch.device("cuda:0")
 shapes = [("L1 table", 196608, 128, 32), ("L2 P", 196608, 256, 32), ("L2 Q", 98304, 384, 32), ("L3 table", 98304, 640, 64),
           ("L4 P", 98304, 512, 64), ("L4 Q", 24576, 768, 64), ("L5 P", 24576, 1024, 128), ("L5 Q", 6144, 1536, 128),
           ("L6 table", 6144, 5120, 256), ("glob6", 6144, 1024, 512), ("mean-part 6", 192, 1024, 512), ("decoder", 262144, 768, 768)]
+if "--check" in sys.argv:
+    # accuracy against fp64: max |out - ref| in units of 2^-24 * (|A| |W|^T) (the fp32 FMA-chain bound is ~K/2 of these units)
+    sys.argv.remove("--check")
+    for K in (32, 64, 256, 768):
+        g = torch.Generator(device="cpu").manual_seed(K)
+        A = (torch.randn(4096, K, generator=g) * torch.exp(torch.randn(4096, K, generator=g))).to(dev)
+        W = (torch.randn(512, K, generator=g) * torch.exp(torch.randn(512, K, generator=g))).to(dev)
+        out = ops.gemm(A, W).double()
+        ref = A.double() @ W.double().T
+        bound = (A.double().abs() @ W.double().abs().T) * 2.0 ** -24
+        print(f"K={K:4d}: max err / (2^-24 sum|a||w|) = {((out - ref).abs() / bound).max().item():.3f}   rel-to-max {((out - ref).abs().max() / ref.abs().max()).item():.2e}")
 if len(sys.argv) > 1: shapes = [s for s in shapes if sys.argv[1] in s[0]]
 for name, M, N, K in shapes:
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
