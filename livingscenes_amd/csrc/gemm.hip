@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk,
                                                        size_t slab_stride) {
     constexpr int STG = 32 * 68;  // epilogue staging: 32 rows x (64 + 4) floats per wave
-    __shared__ __attribute__((aligned(16))) float smem[(4 * STG > (GM + GN) * GLD) ? 4 * STG : (GM + GN) * GLD];
+    constexpr int BK = SPLIT ? 32 : GK;          // k depth of one staged slab
+    constexpr int NST = SPLIT ? 4 : 2;           // float4 per thread per operand slab
+    constexpr int PLANE = GM * 64;               // SPLIT: bytes of one bf16 plane (128 rows x 32 k)
+    constexpr int OPER_FLOATS = SPLIT ? 6 * PLANE / 4 : (GM + GN) * GLD;
+    __shared__ __attribute__((aligned(16))) float smem[(4 * STG > OPER_FLOATS) ? 4 * STG : OPER_FLOATS];
     float* As = smem;
     float* Bs = smem + GM * GLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,13 +112,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // staging map: 128 rows x 4 float4 per operand tile = 512 float4, two per thread
-    const int sr0 = tid >> 2, sk = (tid & 3) * 4;  // rows sr0 and sr0+64
-    float4 ra[2], rb[2];
-    long long arow[2];  // source row of A for this thread's two staged rows (-1 = out of range)
+    // staging map.  fp32 path: 128 rows x 4 float4 per operand slab, two per thread (rows sr0, sr0 + 64).  SPLIT: 128 rows x 8
+    // float4 (32 k), four per thread (rows sr0 + 32 u)
+    const int sr0 = SPLIT ? (tid >> 3) : (tid >> 2), sk = SPLIT ? (tid & 7) * 4 : (tid & 3) * 4;
+    constexpr int RSTEP = SPLIT ? 32 : 64;
+    float4 ra[NST], rb[NST];
+    long long arow[NST];  // source row of A for this thread's staged rows (-1 = out of range)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int gm = m0 + sr0 + h * 64;
+    for (int h = 0; h < NST; ++h) {
+        const int gm = m0 + sr0 + h * RSTEP;
         long long r = gm < M ? gm : -1;
         if (a_rows && gm < M) {
             const int pt = gm / 3, x = gm - pt * 3;
@@ -125,30 +131,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = sr0 + h * 64;
+        for (int h = 0; h < NST; ++h) {
+            const int r = sr0 + h * RSTEP;
             const int gn = n0 + r, gk = k0 + sk;
             ra[h] = (arow[h] >= 0 && gk < kend) ? *reinterpret_cast<const float4*>(A + (size_t)arow[h] * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[h] = (gn < N && gk < kend) ? *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    // SPLIT: three bf16 planes per operand, plane = 128 rows x 32 bytes
+    // SPLIT: three bf16 planes per operand, plane = 128 rows x 64 bytes (32 k); the 16-byte slot index (k / 8) is XOR-ed with
+    // bits 2-3 of the row, so that 16 consecutive rows reading the same logical slot hit 16 distinct bank slots
     char* Ap = reinterpret_cast<char*>(smem);
-    char* Bp = Ap + 3 * 4096;
+    char* Bp = Ap + 3 * PLANE;
     auto lstore = [&]() {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = sr0 + h * 64;
+        for (int h = 0; h < NST; ++h) {
+            const int r = sr0 + h * RSTEP;
             if constexpr (SPLIT) {
+                const int swz = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
                 uint2 p1, p2, p3;
                 split3_bf16(ra[h], p1, p2, p3);
-                *reinterpret_cast<uint2*>(Ap + r * 32 + sk * 2) = p1;
-                *reinterpret_cast<uint2*>(Ap + 4096 + r * 32 + sk * 2) = p2;
-                *reinterpret_cast<uint2*>(Ap + 8192 + r * 32 + sk * 2) = p3;
+                *reinterpret_cast<uint2*>(Ap + swz) = p1;
+                *reinterpret_cast<uint2*>(Ap + PLANE + swz) = p2;
+                *reinterpret_cast<uint2*>(Ap + 2 * PLANE + swz) = p3;
                 split3_bf16(rb[h], p1, p2, p3);
-                *reinterpret_cast<uint2*>(Bp + r * 32 + sk * 2) = p1;
-                *reinterpret_cast<uint2*>(Bp + 4096 + r * 32 + sk * 2) = p2;
-                *reinterpret_cast<uint2*>(Bp + 8192 + r * 32 + sk * 2) = p3;
+                *reinterpret_cast<uint2*>(Bp + swz) = p1;
+                *reinterpret_cast<uint2*>(Bp + PLANE + swz) = p2;
+                *reinterpret_cast<uint2*>(Bp + 2 * PLANE + swz) = p3;
             } else {
                 *reinterpret_cast<float4*>(&As[r * GLD + sk]) = ra[h];
                 *reinterpret_cast<float4*>(&Bs[r * GLD + sk]) = rb[h];
@@ -157,32 +165,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     };
 
     gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
         lstore();
         __syncthreads();
-        if (k0 + GK < kend) gload(k0 + GK);  // in flight under the MFMA block
+        if (k0 + BK < kend) gload(k0 + BK);  // in flight under the MFMA block
         const int lr = lane & 31, lk = (lane >> 5) * 4;
         if constexpr (SPLIT) {
-            bf16x8_t a[2][3], b[2][3];   // lane (row lr, half lane>>5): k = 8 (lane>>5) .. +7 of the slab, the same for A and B
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int s2 = 0; s2 < 2; ++s2) {   // the slab's two 16-k halves; lane (row lr, lane>>5) holds k = 16 s2 + 8 (lane>>5) .. +7
+                bf16x8_t a[2][3], b[2][3];
+                const int q = s2 * 2 + (lane >> 5);
 #pragma unroll
-                for (int p3 = 0; p3 < 3; ++p3) {
-                    a[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ap + p3 * 4096 + (wm * 64 + i * 32 + lr) * 32 + (lane >> 5) * 16));
-                    b[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bp + p3 * 4096 + (wn * 64 + i * 32 + lr) * 32 + (lane >> 5) * 16));
+                for (int i = 0; i < 2; ++i) {
+                    const int rowa = wm * 64 + i * 32 + lr, rowb = wn * 64 + i * 32 + lr;
+#pragma unroll
+                    for (int p3 = 0; p3 < 3; ++p3) {
+                        a[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ap + p3 * PLANE + rowa * 64 + ((q ^ ((rowa >> 2) & 3)) << 4)));
+                        b[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bp + p3 * PLANE + rowb * 64 + ((q ^ ((rowb >> 2) & 3)) << 4)));
+                    }
                 }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {   // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                }
+                // term-major order: consecutive MFMAs go to the four independent accumulators (a dependent back-to-back chain on
+                // one accumulator does not issue at the 32-cycle rate); smallest terms first
+#define LS_TERM(PA, PB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0);
+                LS_TERM(2, 0) LS_TERM(0, 2) LS_TERM(1, 1) LS_TERM(1, 0) LS_TERM(0, 1) LS_TERM(0, 0)
+#undef LS_TERM
+            }
         } else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -395,7 +405,7 @@ size_t gemm_scratch_floats(int M, int N, int K) {
 }
 
 int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
-                       int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st) {
+                       int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st, bool latency_path = false) {
     LS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem (M=%d N=%d K=%d)", M, N, K);
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
@@ -414,10 +424,16 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         return LS_OK;
     }
     // LS_GEMM_BF16X3=0: exact fp32 FMA chains on v_mfma_f32_32x32x2_f32 (A/B timing, bit-for-bit comparison with earlier builds)
-    static const bool split = !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
+    static const bool split_on = !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
+    // The arithmetic must not depend on M (a decode of one instance's points has to equal the same rows inside a batched decode),
+    // so the choice is the CALLER's: latency_path = a handful of tiles by construction (the per-instance mean rows of the global
+    // conv, M = 3B), where the fp32 kernel's shorter slab (16 k, no split arithmetic before the first MFMA) wins: 44 vs 112 us
+    // at M = 192, N = 1024, K = 512
+    const bool split = split_on && !latency_path;
     const int nsplit = scratch ? gemm_choose_splits(M, N, K) : 1;
     if (nsplit > 1) {
-        int kchunk = cdiv(cdiv(K, nsplit), GK) * GK;
+        const int kq = split ? 32 : GK;
+        int kchunk = cdiv(cdiv(K, nsplit), kq) * kq;
         const int ns = cdiv(K, kchunk);
         const size_t slab = (size_t)M * N;
         if (split)
@@ -452,6 +468,10 @@ int gemm_dispatch(const float* A, int lda, const float* W, int ldw, const float*
 int gemm_dispatch_ws(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
                      int K, int relu, float* scratch, hipStream_t st) {
     return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, scratch, st);
+}
+int gemm_dispatch_small(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
+                        int K, int relu, float* scratch, hipStream_t st) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, scratch, st, true);
 }
 
 }  // namespace ls

@@ -31,6 +31,7 @@ int edge_pool_launch(const float*, int, const float*, int, int, int, const int32
 int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
 int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t);
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
+int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 size_t gemm_scratch_floats(int M, int N, int K);
 int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipStream_t);
 size_t prologue_scratch_floats(int B);
@@ -441,7 +442,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             {
                 PROF(LS_K_GEMM_GLOB, i, st);
                 rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, F(p.o_gws), st);
-                if (rc == LS_OK) rc = gemm_dispatch_ws(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, F(p.o_gws), st);
+                if (rc == LS_OK) rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, F(p.o_gws), st);
             }
             if (rc != LS_OK) return rc;
             { PROF(LS_K_VN_ACT, i, st); rc = vn_act_rows_launch(TG, 2 * Co, G, 4 * Co, B, Nd, Co, d.neg_slope, nxt, st); }
