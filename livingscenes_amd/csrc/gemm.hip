@@ -429,7 +429,8 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     // so the choice is the CALLER's: latency_path = a handful of tiles by construction (the per-instance mean rows of the global
     // conv, M = 3B), where the fp32 kernel's shorter slab (16 k, no split arithmetic before the first MFMA) wins: 44 vs 112 us
     // at M = 192, N = 1024, K = 512
-    const bool split = split_on && !latency_path;
+    // (K = 32 stays on the fp32 chain for every M: the persistent small-K kernel below is table-write bound anyway)
+    const bool split = split_on && !latency_path && K != 32;
     const int nsplit = scratch ? gemm_choose_splits(M, N, K) : 1;
     if (nsplit > 1) {
         const int kq = split ? 32 : GK;

@@ -231,6 +231,37 @@ def test_gemm(M, N, K):
     assert torch.equal(ops.gemm(Ai.to(_dev()), Wi.to(_dev())).cpu(), Ai @ Wi.T)
 
 
+def test_gemm_bf16x3_is_as_accurate_as_the_fp32_chain_and_row_invariant():
+    """The default GEMM forms every fp32 product from three bf16 pieces on the bf16 matrix cores.  Componentwise error against
+    fp64 must stay within the fp32 FMA chain's own bound (in units of 2^-24 sum|a||w|: measured 6-9 vs 11-13 for the chain) on
+    badly scaled operands, and the kernel's arithmetic must not depend on M: a row's result is the same whatever other rows the call
+    carries (checked here where ls_gemm_f32 does not split K, K < 128; the decoder path, which never splits K, is covered by
+    test_ragged_decode_and_batched_mise_equal_per_instance)."""
+    from livingscenes_amd import ops
+    for K in (32, 64, 256, 768):
+        g = torch.Generator().manual_seed(K)
+        A = torch.randn(3000, K, generator=g) * torch.exp(2 * torch.randn(3000, K, generator=g))
+        W = torch.randn(260, K, generator=g) * torch.exp(2 * torch.randn(260, K, generator=g))
+        out = ops.gemm(A.to(_dev()), W.to(_dev())).cpu().double()
+        ref = A.double() @ W.double().T
+        unit = (A.double().abs() @ W.double().abs().T) * 2.0 ** -24
+        assert ((out - ref).abs() / unit).max() < 16.0, K
+        if K < 128:
+            part = ops.gemm(A[100:137].contiguous().to(_dev()), W.to(_dev())).cpu()
+            assert torch.equal(part.double(), out[100:137]), K
+
+
+def test_gemm_fp32_chain_switch():
+    """LS_GEMM_BF16X3=0 keeps the v_mfma_f32_32x32x2_f32 kernel (A/B timing): same tolerance."""
+    import os, subprocess, sys
+    code = ("import torch; from livingscenes_amd import ops; g = torch.Generator().manual_seed(1);"
+            "A = torch.randn(700, 96, generator=g); W = torch.randn(200, 96, generator=g);"
+            "o = ops.gemm(A.cuda(), W.cuda()).cpu().double(); r = A.double() @ W.double().T;"
+            "assert ((o - r).abs().max() / r.abs().max()) < 2e-6")
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_GEMM_BF16X3="0"),
+                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
 # ------------------------------------------------------------------------------------------------ prologue
 def test_prologue():
     from livingscenes_amd import ops
