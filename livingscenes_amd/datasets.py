@@ -6,7 +6,7 @@
 /root/reference/eval_flyingshape.py:33-60 (the dataset class: directory walk, sorted listing, np.load per scan) and :76,
 :119-129 (which fields the loops use: data[0] = reference scan, data[1:] = rescans).  The real files are not in the container
 (.MISSING_LARGE_BLOBS); ``write_scene`` produces the same layout from synthetic scenes so that the harness can be driven from
-disk exactly as the reference drives it.  The 3RScan formats (PLY + json) are not implemented.
+disk exactly as the reference drives it.  The 3RScan formats (PLY + json + npz) are in rscan.py.
 """
 import glob
 import os

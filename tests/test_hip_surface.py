@@ -68,6 +68,34 @@ def test_encode_fps_ragged_matches_reference_loop(small_prior):
     assert emb2["z_inv"].shape == emb["z_inv"].shape and torch.isfinite(emb2["z_so3"]).all()
 
 
+def test_3rscan_tree_to_codes(small_prior, tmp_path):
+    """Disk -> Dataset_3RScan (PLY + labels + semseg json, device tensors) -> Shape_Prior.encode_fps, as eval_3rscan.py:260-261
+    drives it; each instance's code equals the oracle's on that instance's vertices in file order."""
+    from livingscenes_amd import rscan
+    from oracle import net
+    sp, (ecfg, dcfg, ew, dw) = small_prior
+    rng = np.random.default_rng(8)
+    root = tmp_path / "data"
+    sizes = {7: ("chair", 1300), 9: ("table", 1024), 11: ("lamp", 600)}
+    pts = np.concatenate([rng.standard_normal((n, 3)).astype(np.float32) * 0.4 + oid for oid, (_, n) in sizes.items()])
+    ids = np.concatenate([np.full(n, oid) for oid, (_, n) in sizes.items()])
+    perm = rng.permutation(len(pts))
+    pts, ids = pts[perm], ids[perm]
+    rscan.write_scan(str(root / "val_set"), "s0", pts, ids, [{"objectId": o, "label": l} for o, (l, _) in sizes.items()])
+    rscan.write_index(str(root), "val", [{"reference": "s0", "scans": []}])
+    ds = rscan.Dataset_3RScan({"root_path": str(root), "split": "val", "category_list": ["chair", "table"], "n_point_per_instance": 1024,
+                               "use_gt_mask": True}, device=_dev())
+    ref, rescans = ds[0]
+    assert rescans == [] and ref["pc"].is_cuda and ref["objectId"].tolist() == [7, 9]
+    emb = sp.encode_fps(ref["pc"], ref["pc_mask"])
+    for b, oid in enumerate((7, 9)):
+        valid = torch.from_numpy(pts[ids == oid]).unsqueeze(0)
+        sub, _ = net.sample_farthest_points(valid, 128)
+        want = net.shape_prior_encode(ew, ecfg, sub.transpose(1, 2).contiguous())
+        for k in ("z_so3", "z_inv", "s", "t"):
+            assert relerr(emb[k][b:b + 1], want[k]) < TOL, (oid, k)
+
+
 def test_all_matchers_vs_golden(golden):
     from livingscenes_amd.lib_more import matcher_new as mn
     g = golden("matchers")

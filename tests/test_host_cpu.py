@@ -259,3 +259,73 @@ def test_se3_exp_matches_matrix_exponential():
         A[:3, :3] = torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=torch.float64)
         A[:3, 3] = xi[:3]
         assert torch.allclose(_se3_exp(xi), torch.matrix_exp(A), atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ 3RScan on-disk formats
+def _rot_z(deg):
+    a = np.deg2rad(deg)
+    T = np.eye(4)
+    T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+    return T
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_3rscan_reader_on_a_synthetic_tree(tmp_path, binary):
+    """Dataset_3RScan reads the scan directories / index the way eval_3rscan.py does: category filter, < 1024-point instances
+    dropped (but listed in full_objectId), zero padding + mask, background decimation, column-major transforms, moving / static
+    split at 1 degree / 0.05."""
+    from livingscenes_amd import rscan
+    rng = np.random.default_rng(3)
+    root = tmp_path / "3RScan" / "data"
+    data = root / "val_set"
+    sizes = {1: ("chair", 1500), 2: ("sofa", 1100), 3: ("bed", 900), 4: ("wall", 2000), 5: ("floor", 1000), 6: ("desk", 0)}
+
+    def make_scan(scan_id, shift):
+        pts, ids, groups = [], [], []
+        for oid, (label, n) in sizes.items():
+            groups.append({"objectId": oid, "label": label, "id": oid})
+            if n:
+                p = rng.standard_normal((n, 3)).astype(np.float32) * 0.3 + np.array([oid, 0, 0.5 * oid], np.float32) + shift
+                pts.append(p); ids.append(np.full(n, oid))
+        pts, ids = np.concatenate(pts), np.concatenate(ids)
+        perm = rng.permutation(len(pts))
+        rscan.write_scan(str(data), scan_id, pts[perm], ids[perm], groups, binary=binary, extra_uchar=binary)
+        return pts[perm], ids[perm]
+
+    ref_pts, ref_ids = make_scan("ref0", 0.0)
+    make_scan("rescan0", 0.1)
+    rscan.write_scan(str(data), "empty", rng.standard_normal((50, 3)), np.full(50, 4), [{"objectId": 4, "label": "wall"}], binary=binary)
+    T_scene = _rot_z(30.0); T_scene[:3, 3] = [0.5, -0.2, 0.1]
+    T_static = np.linalg.inv(T_scene)                       # object transform ref -> rescan whose inverse equals the scene transform
+    Tt = T_scene.copy(); Tt[:3, 3] += [0.1, 0, 0]           # same rotation, 0.1 translation difference
+    cm = lambda M: [float(v) for v in np.asarray(M).T.reshape(-1)]   # column-major
+    scenes = [{"reference": "ref0", "scans": [
+        {"reference": "rescan0", "transform": cm(T_scene), "rigid": [
+            {"instance_reference": 1, "transform": cm(T_static)}, {"instance_reference": 2, "transform": cm(np.linalg.inv(_rot_z(33.0)))},
+            {"instance_reference": 3, "transform": cm(np.linalg.inv(Tt))}]},
+        {"reference": "empty", "transform": cm(np.eye(4)), "rigid": []}]},
+        {"reference": "not_in_split", "scans": []}]
+    rscan.write_index(str(root), "val", scenes[:1])
+    import json
+    with open(root / "3RScan.json", "w") as f:
+        json.dump(scenes, f)
+    cats = tmp_path / "cate.txt"
+    cats.write_text("chair\nsofa\nbed\ndesk\n")
+    ds = rscan.Dataset_3RScan({"root_path": str(root), "split": "val", "category_list": str(cats), "n_point_per_instance": 1024,
+                               "use_gt_mask": True}, device="cpu")
+    assert len(ds) == 1 and sorted(ds.scan_list) == ["empty", "ref0", "rescan0"]
+    ref, rescans = ds[0]
+    assert ref["pc"].shape == (2, 3, 1500) and ref["pc_mask"].shape == (2, 1, 1500)
+    assert ref["objectId"].tolist() == [1, 2] and ref["full_objectId"].tolist() == [1, 2, 3, 6]
+    assert ref["pc_mask"].sum(-1).flatten().tolist() == [1500, 1100]
+    assert ref["id_label"] == [(1, "chair", "chair"), (2, "sofa", "sofa"), (3, "bed", "bed"), (6, "desk", "table")]
+    assert torch.equal(ref["pc"][1, :, 1100:], torch.zeros(3, 400))
+    assert np.allclose(ref["pc"][0, :, :1500].T.numpy(), ref_pts[ref_ids == 1])      # file order of the instance's vertices
+    z_max = max(ref_pts[ref_ids == i][:, 2].max() for i in (1, 2, 3))
+    bg = np.concatenate([ref_pts[ref_ids == i][ref_pts[ref_ids == i][:, 2] < z_max] for i in (4, 5)])[::5]
+    assert np.allclose(ref["bg_pc"], bg)
+    assert len(rescans) == 1                                                           # the scan without a kept instance is ruled out
+    r = rescans[0]
+    assert np.allclose(r["rescan2ref_tsfm"][0].numpy(), T_scene, atol=1e-6)
+    assert r["static_ids"].tolist() == [1.0] and r["moving_ids"].tolist() == [2.0, 3.0]
+    assert rscan.get_shapenet_category("trash can") == "trash_bin" and rscan.get_shapenet_category("wall") == "others"
