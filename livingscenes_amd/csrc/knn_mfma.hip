@@ -551,17 +551,22 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
         }
         A[rr] = v;
     }
-    // hint bitmap of the wave's 32 queries
+    // hint bitmap of the wave's 32 queries.  The keys are loaded BEFORE the LDS clear (the wave barriers are scheduling fences: the
+    // loads would otherwise be issued only after the clear, one more exposed memory round trip per wave)
+    uint4 hk[4];
+    {
+        const int qh = min(q0 + l31, Nd - 1);
+        const uint4* kp = reinterpret_cast<const uint4*>(seedkeys + ((size_t)b * Nd + qh) * 16 + lh * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hk[e] = kp[e];
+    }
     for (int i = lane; i < 32 * words + 32; i += 64) bits[i] = 0u;   // bitmap and counters
     __builtin_amdgcn_wave_barrier();
     if (q0 + l31 < Nd) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const u64 k = seedkeys[((size_t)b * Nd + q0 + l31) * 16 + lh * 8 + e];
-            if ((unsigned)(k >> 32) != 0xFFFFFFFFu) {
-                const unsigned c = (unsigned)k;
-                atomicOr(&bits[l31 * words + (c >> 5)], 1u << (c & 31));
-            }
+        for (int e = 0; e < 4; ++e) {
+            if (hk[e].y != 0xFFFFFFFFu) atomicOr(&bits[l31 * words + (hk[e].x >> 5)], 1u << (hk[e].x & 31));
+            if (hk[e].w != 0xFFFFFFFFu) atomicOr(&bits[l31 * words + (hk[e].z >> 5)], 1u << (hk[e].z & 31));
         }
     }
     __builtin_amdgcn_wave_barrier();
