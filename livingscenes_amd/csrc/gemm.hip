@@ -80,6 +80,9 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
 
 // Optional row gather (down-sampled encoder layers): output row m = (b*gNd + n)*3 + x reads A row
 // (b*gNs + a_rows[b*gNd + n])*3 + x, i.e. the GEMM runs only on the FPS-selected points of each instance.
+#ifdef LS_GEMM_PROF
+__device__ unsigned long long ls_gemm_prof[8];
+#endif
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
@@ -164,11 +167,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
     };
 
+#ifdef LS_GEMM_PROF   // dev instrumentation (scripts/ubench/gemm_phases.hip): s_memtime per phase, every wave, summed
+#define LS_PH(i) if ((blockIdx.x & 127) == 5) { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&ls_gemm_prof[i], (unsigned long long)(t_ - tph)); tph = t_; }   /* one workgroup in 128 */
+    long long tph = __builtin_readcyclecounter();
+#else
+#define LS_PH(i)
+#endif
     gload(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
+        LS_PH(0)
         lstore();
+        LS_PH(1)
         __syncthreads();
+        LS_PH(2)
         if (k0 + BK < kend) gload(k0 + BK);  // in flight under the MFMA block
         const int lr = lane & 31, lk = (lane >> 5) * 4;
         if constexpr (SPLIT) {
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 LS_TERM(2, 0) LS_TERM(0, 2) LS_TERM(1, 1) LS_TERM(1, 0) LS_TERM(0, 1) LS_TERM(0, 0)
 #undef LS_TERM
             }
+            LS_PH(3)
         } else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
