@@ -1,18 +1,20 @@
-// knn_mfma.hip -- the same bit-exact 16-NN as knn.hip for the SEEDED C == 32 encoder layers, with the distance sweep moved
-// onto the matrix cores as an EXACT-SAFE FILTER.
+// knn_mfma.hip -- the same bit-exact 16-NN as knn.hip for the SEEDED C == 32 / 64 encoder layers (1-4), with the distance sweep
+// moved onto the matrix cores as an EXACT-SAFE FILTER.
 //
 // Replaces pytorch3d.ops.knn_points as called at
-//   /root/reference/lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:139-141        (layers whose input has 32 channels)
+//   /root/reference/lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:139-141        (layers whose input has 32 or 64 channels)
 //
 // knn.hip spends ~250 M VALU instructions per layer-1 launch on the canonical (sub, mul, add) distance of EVERY pair, although
 // once a query's list holds its previous-layer neighbours only ~25 of 1024 candidates can still enter it.  Here:
-//   1. S = q . s on the matrix cores (v_mfma_f32_32x32x2_f32, K = 3C), giving d^ = |q|^2 + |s|^2 - 2S;
-//   2. a pair is DROPPED only if  d^ - eps > kth(q)  (kth = the query's current exact K-th distance), where
-//      eps = 6 (D+4) 2^-24 (|q|^2 + |s|^2) bounds |d^ - d_true| + |d_canonical - d_true| with 50 % slack
+//   1. S = q . s on the matrix cores, giving d^ = |q|^2 + |s|^2 - 2S.  Default: bf16 operands on centred rows
+//      (v_mfma_f32_32x32x16_bf16, knn_sweep_bf16_kernel, error bound in the comment above it); fp32 operands
+//      (v_mfma_f32_32x32x2_f32, knn_sweep_kernel) for Ns > 2048 or LS_KNN_SWEEP_FP32=1;
+//   2. a pair is DROPPED only if  d^ - eps > kth(q)  (kth = the query's current exact K-th distance), where for the fp32 sweep
+//      eps = 6 (D+4) 2^-24 (|q|^2+|s|^2) bounds |d^ - d_true| + |d_canonical - d_true| with 50 % slack
 //      (gamma_{D+3} (|q|+|s|)^2 each, (|q|+|s|)^2 <= 2 (|q|^2+|s|^2)); fp32 accumulation of non-negative terms is
 //      monotone, so a dropped pair provably has canonical distance > kth and could never have been inserted;
 //   3. the survivors get the CANONICAL distance (same fp32 chain as knn.hip / the oracle) and go through the same
-//      row-parallel key merge (knn_common.h).
+//      key merge (knn_common.h).
 // The top-K lists only ever hold canonical distances, so the result is bit-identical to knn.hip / the oracle by
 // construction; the filter only decides what is worth computing.
 #include "knn_common.h"
