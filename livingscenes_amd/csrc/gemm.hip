@@ -83,7 +83,9 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
 #ifdef LS_GEMM_PROF
 __device__ unsigned long long ls_gemm_prof[8];
 #endif
-template <bool SPLIT>
+// PIECES = 2 (opt-in, LS_SDF_BF16X2): a = a1 + a2 only, three MFMAs per 16 k (a1b1 + a1b2 + a2b1); products carry a 2^-16
+// relative error instead of 2^-24 -- a decode mode for throughput, never the default.
+template <bool SPLIT, int PIECES = 3>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
                                                        int ldc, int M, int N, int K, int relu, int ntiles_n,
@@ -155,11 +157,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 split3_bf16(ra[h], p1, p2, p3);
                 *reinterpret_cast<uint2*>(Ap + swz) = p1;
                 *reinterpret_cast<uint2*>(Ap + PLANE + swz) = p2;
-                *reinterpret_cast<uint2*>(Ap + 2 * PLANE + swz) = p3;
+                if constexpr (PIECES == 3) *reinterpret_cast<uint2*>(Ap + 2 * PLANE + swz) = p3;
                 split3_bf16(rb[h], p1, p2, p3);
                 *reinterpret_cast<uint2*>(Bp + swz) = p1;
                 *reinterpret_cast<uint2*>(Bp + PLANE + swz) = p2;
-                *reinterpret_cast<uint2*>(Bp + 2 * PLANE + swz) = p3;
+                if constexpr (PIECES == 3) *reinterpret_cast<uint2*>(Bp + 2 * PLANE + swz) = p3;
             } else {
                 *reinterpret_cast<float4*>(&As[r * GLD + sk]) = ra[h];
                 *reinterpret_cast<float4*>(&Bs[r * GLD + sk]) = rb[h];
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 for (int i = 0; i < 2; ++i) {
                     const int rowa = wm * 64 + i * 32 + lr, rowb = wn * 64 + i * 32 + lr;
 #pragma unroll
-                    for (int p3 = 0; p3 < 3; ++p3) {
+                    for (int p3 = 0; p3 < PIECES; ++p3) {
                         a[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ap + p3 * PLANE + rowa * 64 + ((q ^ ((rowa >> 2) & 3)) << 4)));
                         b[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bp + p3 * PLANE + rowb * 64 + ((q ^ ((rowb >> 2) & 3)) << 4)));
                     }
@@ -202,7 +204,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #define LS_TERM(PA, PB)                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                         \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0);
-                LS_TERM(2, 0) LS_TERM(0, 2) LS_TERM(1, 1) LS_TERM(1, 0) LS_TERM(0, 1) LS_TERM(0, 0)
+                if constexpr (PIECES == 3) { LS_TERM(2, 0) LS_TERM(0, 2) LS_TERM(1, 1) }
+                LS_TERM(1, 0) LS_TERM(0, 1) LS_TERM(0, 0)
 #undef LS_TERM
             }
             LS_PH(3)
@@ -418,7 +421,8 @@ size_t gemm_scratch_floats(int M, int N, int K) {
 }
 
 int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
-                       int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st, bool latency_path = false) {
+                       int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st, bool latency_path = false,
+                       int pieces = 3) {
     LS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem (M=%d N=%d K=%d)", M, N, K);
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
@@ -462,7 +466,10 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         LS_LAUNCH_CHECK();
         return LS_OK;
     }
-    if (split)
+    if (split && pieces == 2)
+        hipLaunchKernelGGL((gemm_f32_kernel<true, 2>), dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
+                           gNd, gNs, K, (size_t)0);
+    else if (split)
         hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
                            gNd, gNs, K, (size_t)0);
     else
@@ -482,6 +489,11 @@ int gemm_dispatch(const float* A, int lda, const float* W, int ldw, const float*
 int gemm_dispatch_ws(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
                      int K, int relu, float* scratch, hipStream_t st) {
     return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, scratch, st);
+}
+// opt-in two-piece products (decoder throughput mode); never splits K
+int gemm_dispatch_fast2(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
+                        int K, int relu, hipStream_t st) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, nullptr, st, false, 2);
 }
 int gemm_dispatch_small(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
                         int K, int relu, float* scratch, hipStream_t st) {

@@ -32,6 +32,7 @@ int edge_attn_launch(const float*, int, const float*, int, int, int, const int32
 int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t);
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
+int gemm_dispatch_fast2(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 size_t gemm_scratch_floats(int M, int N, int K);
 int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipStream_t);
 size_t prologue_scratch_floats(int B);
@@ -78,6 +79,7 @@ struct ls_model {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
     bool knn_filter = true;        // LS_KNN_FILTER=0: all-VALU k-NN kernel on the seeded C == 32 layers too (A/B timing)
+    bool sdf_bf16x2 = false;       // LS_SDF_BF16X2=1: decoder GEMMs with two-piece bf16 products (2^-16 per product, ~1.7x; opt-in)
     bool seed_knn = true;          // LS_KNN_SEEDS=0 disables seeding a layer's k-NN lists from the previous layer's graph
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     bool profiling = false;
@@ -275,6 +277,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     m->d = *desc;
     if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_SEEDS")) m->seed_knn = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_SDF_BF16X2")) m->sdf_bf16x2 = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_FILTER")) m->knn_filter = atoi(ev) != 0;
     hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
     if (e != hipSuccess) { delete m; set_error("hipMalloc(model blob): %s", hipGetErrorString(e)); return LS_ERR_HIP; }
@@ -576,14 +579,18 @@ static int sdf_forward(ls_model_t* m, const SdfBuffers& sb, const float* query, 
         const float* cur = sb.h[l - 1];
         float* nxt = sb.h[l];
         if (l == li) {
-            { PROF(LS_K_GEMM_SDF, l, st); rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, (int)rows, outw, kin, 0, sb.gws, st); }
+            { PROF(LS_K_GEMM_SDF, l, st);
+              rc = (m->sdf_bf16x2 && !sb.gws) ? gemm_dispatch_fast2(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, (int)rows, outw, kin, 0, st)
+                                              : gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, (int)rows, outw, kin, 0, sb.gws, st); }
             if (rc != LS_OK) return rc;
             PROF(LS_K_SDF_AFFINE, l, st);
             rc = row_inst ? sdf_affine_rows_launch(query, row_inst, s, t, sb.A4, sb.b4, rows, w, w, 1, nxt, st)
                           : sdf_affine_launch(query, s, t, sb.A4, sb.b4, B, M, w, w, 1, nxt, st);
         } else {
             PROF(LS_K_GEMM_SDF, l, st);
-            rc = gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, (int)rows, outw, kin, 1, sb.gws, st);
+            rc = (m->sdf_bf16x2 && !sb.gws)
+                     ? gemm_dispatch_fast2(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, (int)rows, outw, kin, 1, st)
+                     : gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, (int)rows, outw, kin, 1, sb.gws, st);
         }
         if (rc != LS_OK) return rc;
         kin = outw;

@@ -45,6 +45,28 @@ def test_shape_prior_encode_and_decoder(small_prior):
     assert torch.allclose(occ.logits, -sdf)
 
 
+def test_sdf_decode_two_piece_mode_stays_inside_the_tolerance():
+    """LS_SDF_BF16X2=1 (opt-in decoder throughput mode: two bf16 pieces per operand, three MFMAs per 16 k, ~1.7x): still within the
+    1e-4 tolerance of the oracle (measured 3e-6 against fp64 on the full-width decoder)."""
+    import os, subprocess, sys
+    code = (
+        "import torch, numpy as np\n"
+        "from livingscenes_amd import synth\n"
+        "from livingscenes_amd.model_utils import Shape_Prior\n"
+        "from oracle import net\n"
+        "ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()\n"
+        "ew, dw = synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0)\n"
+        "sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=torch.device('cuda:0'))\n"
+        "emb = sp.encode(synth.make_instances(3, 1024, seed=2).cuda())\n"
+        "q = synth.make_queries(3, 700, seed=4).cuda() * emb['s'][:, None, None] + emb['t']\n"
+        "sdf = sp.decoder(q, None, emb, return_sdf=True).cpu()\n"
+        "ref = net.field_query(net.as_params(dw), dcfg, q.cpu(), {k: v.cpu() for k, v in emb.items()})\n"
+        "err = (sdf - ref).abs().max() / ref.abs().max()\n"
+        "assert err < 1e-4, err\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_SDF_BF16X2="1"), cwd=root)
+
+
 def test_encode_fps_ragged_matches_reference_loop(small_prior):
     """encode_fps (model_utils.py:199-215): mask-select, FPS to n_pcl, encode -- vs the oracle run instance by instance."""
     from oracle import net
