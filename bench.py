@@ -199,6 +199,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = run(args.steps)
+        dt_host = time.perf_counter() - t0     # host time to enqueue the K steps (no device sync inside a step)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -334,7 +335,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]+[2]: batch={B} instances x N={N} pts per GPU = {n_obj}-object scene + rescan; "
                                    f"VN-DGCNN encode, {n_obj}x{n_obj} sequential matching, {n_obj} Kabsch poses",
                        "instances_per_step_per_gpu": B, "points": N, "parallelism": f"instance-sharded x{world}",
-                       "steps_in_flight": nfl, "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "steps_in_flight": nfl, "host_enqueue_ms_per_step": round(dt_host / args.steps * 1e3, 3), "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "knn_arithmetic": "canonical (separately rounded mul/add)"},
             "check": {"matches_identity": f"{n_correct}/{n_obj}", "rotations_proper": det_ok,
                       "note": "sanity of the timed work only: weights are untrained (deterministic random init), so the matcher is not expected to recover the identity permutation"},
