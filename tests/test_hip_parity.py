@@ -92,6 +92,25 @@ def test_knn_xyz_wave_kernel_bit_exact(case, contract, monkeypatch):
     assert np.array_equal(dist.cpu().numpy()[valid], refd[valid])
 
 
+@pytest.mark.parametrize("K", [1, 5, 16])
+@pytest.mark.parametrize("shape", [(2, 90, 300, 1), (2, 90, 300, 32), (2, 90, 300, 64), (2, 20, 300, 128)])
+def test_knn_smaller_k_on_every_kernel(shape, K):
+    """K < 16 through the raw-cloud kernel, the seeded sweep (C = 32 / 64: threshold = the K-th hint), the small-problem kernel."""
+    from livingscenes_amd import ops
+    from oracle import canon
+    B, Nd, Ns, C = shape
+    rng = np.random.default_rng(K * 100 + C)
+    src = rng.standard_normal((B, Ns, 3, C)).astype(np.float32)
+    dst = rng.standard_normal((B, Nd, 3, C)).astype(np.float32)
+    ref, refd = canon.knn_c(dst, src, K, return_dist=True)
+    seeds = None
+    if C in (32, 64):
+        full = canon.knn_c(dst, src, 16)
+        seeds = torch.from_numpy(np.where(rng.random(full.shape) < 0.7, full, rng.integers(0, Ns, full.shape)).astype(np.int32)).to(_dev())
+    idx, dist = ops.knn(torch.from_numpy(dst).to(_dev()), torch.from_numpy(src).to(_dev()), K, return_dist=True, seeds=seeds)
+    assert np.array_equal(idx.cpu().numpy(), ref) and np.array_equal(dist.cpu().numpy(), refd)
+
+
 def test_knn_large_batch_unsplit_path():
     """B*qtiles >= 768 workgroups -> the single-pass (no candidate split) path, at the encoder's layer-1 shape."""
     from livingscenes_amd import ops
