@@ -132,7 +132,7 @@ int row_norms_launch(const float* f, int row_f, long long npts, float* norms, hi
 
 // ---- 1. seeds.  One wave per four queries (row r of the wave = query 4*wave_id + r), four quad-steps of four hints.
 template <int CC, bool FMA>
-__global__ __launch_bounds__(256, 4) void knn_seed_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+__global__ __launch_bounds__(256, CC == 32 ? 6 : 4) void knn_seed_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                           const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
                                                           const int32_t* __restrict__ seed_idx, int seed_n, int seed_by_row,
                                                           u64* __restrict__ seedkeys, int groups_per_inst, int total_groups) {
