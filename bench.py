@@ -112,9 +112,9 @@ def algorithmic_cost(kind, layer, cfg, B, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240,
+    ap.add_argument("--steps", type=int, default=480,
                     help="timed steps (a step is ~2.5 ms: a 24-step region was short enough for one host hiccup to cost 25 %%)")
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--batch", type=int, default=64, help="instances per step per GPU (two scenes of batch/2 objects)")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--cpu-instances", type=int, default=8, help="bounded sample for the CPU baseline (0 = skip)")

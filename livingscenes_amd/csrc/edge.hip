@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
                                                            float oms, float inv_sqrt_dk, float* __restrict__ out, int total) {
     constexpr int PPW = 64 / LPP;
-    // lane-private LDS slots (stride 17: conflict-free): head scores per chunk and |k|^2 per neighbour.  Keeping these
-    // arrays out of VGPRs lets the neighbour loops stay rolled (bounded registers, 2 neighbours of loads in flight).
-    __shared__ float l_score[NCH][256][EK + 1];
-    __shared__ float l_ssk[256][EK + 1];
+    // lane-private LDS slots ([neighbour][thread]: conflict-free without padding -> 32 KB per chunk pair, five workgroups per CU):
+    // head scores per chunk and |k|^2 per neighbour.  Keeping these arrays out of VGPRs lets the neighbour loops stay rolled
+    // (bounded registers, 2 neighbours of loads in flight).
+    __shared__ float l_score[NCH][EK][256];
+    __shared__ float l_ssk[EK][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / LPP, ll = lane % LPP;
     int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * PPW + sub;
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
             const F43 kd = add43(ld43(Tr + 3 * Co + c4, ldt), qd);
             act43(y, kd, oms);
             const float s2 = dot43(y, y);
-            l_ssk[tid][k] = (ch == 0) ? s2 : l_ssk[tid][k] + s2;
-            l_score[ch][tid][k] = quad_sum(dot43(y, qf[ch]));
+            l_ssk[k][tid] = (ch == 0) ? s2 : l_ssk[k][tid] + s2;
+            l_score[ch][k][tid] = quad_sum(dot43(y, qf[ch]));
         }
     }
     float mx[NCH], sum[NCH];
@@ -328,11 +329,11 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     for (int ch = 0; ch < NCH; ++ch) { mx[ch] = -INFINITY; sum[ch] = 0.f; }
 #pragma unroll 4
     for (int k = 0; k < EK; ++k) {
-        const float invk = 1.0f / fmaxf(sqrtf(group_sum<LPP>(l_ssk[tid][k])), 1e-12f);
+        const float invk = 1.0f / fmaxf(sqrtf(group_sum<LPP>(l_ssk[k][tid])), 1e-12f);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            const float v = l_score[ch][tid][k] * inv_q * invk * inv_sqrt_dk;
-            l_score[ch][tid][k] = v;
+            const float v = l_score[ch][k][tid] * inv_q * invk * inv_sqrt_dk;
+            l_score[ch][k][tid] = v;
             mx[ch] = fmaxf(mx[ch], v);
         }
     }
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     for (int ch = 0; ch < NCH; ++ch) {  // soft-max numerators (the 1/sum is applied to the weighted sum below)
 #pragma unroll 4
         for (int k = 0; k < EK; ++k) {
-            const float ex = expf(l_score[ch][tid][k] - mx[ch]);
-            l_score[ch][tid][k] = ex;
+            const float ex = expf(l_score[ch][k][tid] - mx[ch]);
+            l_score[ch][k][tid] = ex;
             sum[ch] += ex;
         }
     }
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
             F43 y = add43(ld43(Tr + c4, ldt), ql);
             const F43 kd = add43(ld43(Tr + Co + c4, ldt), qd);
             act43(y, kd, oms);
-            const float w = l_score[ch][tid][k];
+            const float w = l_score[ch][k][tid];
             acc.x.x += w * y.x.x; acc.x.y += w * y.x.y; acc.x.z += w * y.x.z; acc.x.w += w * y.x.w;
             acc.y.x += w * y.y.x; acc.y.y += w * y.y.y; acc.y.z += w * y.y.z; acc.y.w += w * y.y.w;
             acc.z.x += w * y.z.x; acc.z.y += w * y.z.y; acc.z.z += w * y.z.z; acc.z.w += w * y.z.w;
