@@ -62,3 +62,80 @@ def eval_relocalization(scenes, solver, icp=True):
     return {"recall_rre5": float((rre < 5).mean() * 100), "recall_rre10": float((rre < 10).mean() * 100),
             "median_rre_5": med(rre[rre < 5]), "median_rte_5": med(rte[rre < 5]), "te_cm_5": med(te[rre < 5]) * 100,
             "median_rre_all": med(rre), "rre": rre, "rte": rte, "te": te}
+
+
+# ------------------------------------------------------------------------------------------------ 3RScan matching evaluation
+def disambiguate(pred_ids, gt_ids, ambiguity, max_hops=200):
+    """/root/reference/eval_3rscan.py:189-228: 3RScan annotates symmetric / interchangeable instances of a scene as groups of
+    {'instance_source', 'instance_target', 'transform'} links.  A prediction counts as the ground truth when the ground-truth id
+    is reachable from the predicted id by following those links (source -> target, first matching link each hop, until the walk
+    returns to its start, dead-ends, or ``max_hops``).  Returns a corrected copy of ``pred_ids``."""
+    links = [(p["instance_source"], p["instance_target"]) for group in ambiguity for p in group]
+    out = pred_ids.clone()
+    for i in range(gt_ids.shape[0]):
+        start = int(pred_ids[i])
+        chain = [t for s, t in links if s == start]
+        hops = 0
+        while chain and hops < max_hops:
+            nxt = next((t for s, t in links if s == chain[-1]), None)
+            if nxt is None or nxt == start:
+                break
+            chain.append(nxt)
+            hops += 1
+        if int(gt_ids[i]) in chain:
+            out[i] = gt_ids[i]
+    return out
+
+
+@torch.no_grad()
+def eval_3rscan_matching(dataset, solver, method_list=("sequential",)):
+    """Object matching between the reference scan and every rescan of each scene of a ``rscan.Dataset_3RScan``
+    (eval_3rscan.py:232-335): object-level recall over the instances present in both scans (all / static / dynamic, the split
+    coming from the rescan's rigid annotations), and scene-level recall = share of (scene, rescan) pairs whose hit ratio reaches
+    75 / 50 / 25 %.  Codes come from ``model.encode_fps`` on the padded clouds, matches from ``solver._solve_object_matching``."""
+    model = solver.model
+    n_methods = len(method_list)
+    n_total = 0
+    n_correct = np.zeros(n_methods)
+    scene_total = np.zeros(3)
+    scene_count = np.zeros(3)      # hits @75, @50, @25
+    tot_dyn = cor_dyn = tot_sta = cor_sta = 0
+    for i_s, scene in enumerate(dataset.scene_list):
+        ref, rescans = dataset._get_scene(i_s)
+        if ref is None or len(rescans) == 0:
+            continue
+        ref_codes = model.encode_fps(ref["pc"], ref["pc_mask"])
+        ref_ids = ref["objectId"]
+        for rescan in rescans:
+            codes = model.encode_fps(rescan["pc"], rescan["pc_mask"])
+            res_ids = rescan["objectId"]
+            moving = set(int(v) for v in rescan["moving_ids"].tolist())
+            valid = torch.tensor([int(i) in set(res_ids.tolist()) for i in ref_ids.tolist()], device=ref_ids.device)
+            moving_mask = torch.tensor([int(i) in moving for i in ref_ids.tolist()], device=ref_ids.device)
+            for mi, method in enumerate(method_list):
+                m0 = solver._solve_object_matching(ref_codes, codes, method)["matches0"].to(ref_ids.device)
+                matched = res_ids[m0.clamp(min=0)]
+                if len(scene.get("ambiguity", [])) != 0:
+                    matched = disambiguate(matched.view(-1), ref_ids, scene["ambiguity"])
+                matched = torch.where(m0 != -1, matched, torch.full_like(matched, -1))
+                hit = matched == ref_ids
+                n_match = int(valid.sum())
+                ok = int(hit[valid].sum())
+                n_correct[mi] += ok
+                n_total += n_match
+                scene_total += 1
+                ratio = ok / n_match if n_match else 0.0
+                if ratio >= 0.75:
+                    scene_count[:] += 1
+                elif ratio >= 0.5:
+                    scene_count[1:] += 1
+                elif ratio >= 0.25:
+                    scene_count[2:] += 1
+                tot_dyn += int((valid & moving_mask).sum()); cor_dyn += int(hit[valid & moving_mask].sum())
+                tot_sta += int((valid & ~moving_mask).sum()); cor_sta += int(hit[valid & ~moving_mask].sum())
+    per_method_total = n_total / max(n_methods, 1)
+    pct = lambda a, b: 100.0 * a / b if b else float("nan")
+    out = {f"object_recall[{m}]": pct(n_correct[i], per_method_total) for i, m in enumerate(method_list)}
+    out.update({"static_recall": pct(cor_sta, tot_sta), "dynamic_recall": pct(cor_dyn, tot_dyn)})
+    out.update({f"scene_recall@{t}": pct(scene_count[i], scene_total[i]) for i, t in enumerate((75, 50, 25))})
+    return out

@@ -329,3 +329,53 @@ def test_3rscan_reader_on_a_synthetic_tree(tmp_path, binary):
     assert np.allclose(r["rescan2ref_tsfm"][0].numpy(), T_scene, atol=1e-6)
     assert r["static_ids"].tolist() == [1.0] and r["moving_ids"].tolist() == [2.0, 3.0]
     assert rscan.get_shapenet_category("trash can") == "trash_bin" and rscan.get_shapenet_category("wall") == "others"
+
+
+def test_3rscan_matching_metrics_and_disambiguation(tmp_path):
+    """harness.eval_3rscan_matching on a synthetic 3RScan tree with a stub model / solver (CPU): recalls, the static / dynamic
+    split, scene-level thresholds, and the symmetry-link walk of ``disambiguate``."""
+    from livingscenes_amd import harness, rscan
+    rng = np.random.default_rng(5)
+    root = tmp_path / "data"
+    labels = {1: "chair", 2: "chair", 3: "sofa", 4: "bed"}
+
+    def make_scan(scan_id, ids):
+        pts = np.concatenate([rng.standard_normal((1030, 3)).astype(np.float32) * 0.2 + i for i in ids])
+        oid = np.concatenate([np.full(1030, i) for i in ids])
+        rscan.write_scan(str(root / "val_set"), scan_id, pts, oid, [{"objectId": i, "label": labels[i]} for i in ids])
+
+    make_scan("ref", [1, 2, 3, 4])
+    make_scan("res", [4, 3, 2, 1])             # same objects, listed in reverse order
+    cm = lambda M: [float(v) for v in np.asarray(M).T.reshape(-1)]
+    moved = np.eye(4); moved[:3, 3] = [1.0, 0, 0]
+    scenes = [{"reference": "ref", "ambiguity": [[{"instance_source": 1, "instance_target": 2, "transform": cm(np.eye(4))},
+                                                   {"instance_source": 2, "instance_target": 1, "transform": cm(np.eye(4))}]],
+               "scans": [{"reference": "res", "transform": cm(np.eye(4)),
+                          "rigid": [{"instance_reference": 3, "transform": cm(moved)}, {"instance_reference": 4, "transform": cm(np.eye(4))}]}]}]
+    rscan.write_index(str(root), "val", scenes)
+    import json
+    with open(root / "3RScan.json", "w") as f:
+        json.dump(scenes, f)
+    ds = rscan.Dataset_3RScan({"root_path": str(root), "split": "val", "category_list": ["chair", "sofa", "bed"],
+                               "n_point_per_instance": 1024, "use_gt_mask": True}, device="cpu")
+
+    class Model:
+        def encode_fps(self, pc, mask):
+            return {"n": pc.shape[0]}
+
+    class Solver:
+        model = Model()
+        def __init__(self, matches): self.matches = matches
+        def _solve_object_matching(self, a, b, method): return {"matches0": torch.tensor(self.matches)}
+
+    # ref ids [1,2,3,4], rescan ids [4,3,2,1]: the correct matches0 is [3,2,1,0].
+    perfect = harness.eval_3rscan_matching(ds, Solver([3, 2, 1, 0]))
+    assert perfect["object_recall[sequential]"] == 100.0 and perfect["scene_recall@75"] == 100.0
+    assert perfect["dynamic_recall"] == 100.0 and perfect["static_recall"] == 100.0
+    # chairs 1 and 2 swapped: forgiven by the ambiguity links; sofa (the moving object) unmatched, bed wrong
+    m = harness.eval_3rscan_matching(ds, Solver([2, 3, -1, 1]))
+    assert m["object_recall[sequential]"] == 50.0 and m["dynamic_recall"] == 0.0
+    assert abs(m["static_recall"] - 100.0 * 2 / 3) < 1e-9
+    assert (m["scene_recall@75"], m["scene_recall@50"], m["scene_recall@25"]) == (0.0, 100.0, 100.0)
+    ids = torch.tensor([2, 1, 9])
+    assert harness.disambiguate(ids, torch.tensor([1, 2, 3]), scenes[0]["ambiguity"]).tolist() == [1, 2, 9]
