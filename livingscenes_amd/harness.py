@@ -139,3 +139,56 @@ def eval_3rscan_matching(dataset, solver, method_list=("sequential",)):
     out.update({"static_recall": pct(cor_sta, tot_sta), "dynamic_recall": pct(cor_dyn, tot_dyn)})
     out.update({f"scene_recall@{t}": pct(scene_count[i], scene_total[i]) for i, t in enumerate((75, 50, 25))})
     return out
+
+
+@torch.no_grad()
+def eval_3rscan_relocalization(dataset, solver, optim=True):
+    """Instance re-localisation over a ``rscan.Dataset_3RScan`` (eval_3rscan.py:337-456): for every annotated rigid instance that
+    is present in both the reference scan and the rescan, register its reference cloud to its rescan cloud
+    (``solver._solve_pairwise_registration``; the rescan is first moved back into its own frame with the inverse scene
+    transform), then relative rotation error (folded by the annotation's symmetry class: 1 -> min(r, |180-r|), 2 -> also
+    |90-r|), relative translation error, end-point RMSE and the chamfer distance of every tenth point.  Reported as the
+    reference does: recall at RMSE < 0.1 m with the medians over RMSE < 0.2 m, recall at RRE < 10 deg with the medians over it,
+    median chamfer distance."""
+    from .evaluate import chamfer_distance_torch
+    from .lib_math import torch_se3
+    rre_l, rte_l, err_l, cd_l, shape_l = [], [], [], [], []
+    for i_s, scene in enumerate(dataset.scene_list):
+        ref, rescans = dataset._get_scene(i_s)
+        if ref is None:
+            continue
+        dev = ref["pc"].device
+        for rescan, sg in zip(rescans, [s for s in scene["scans"]]):
+            scene_tsfm = rescan["rescan2ref_tsfm"]
+            pc = torch_se3.transform(torch_se3.inverse(scene_tsfm), rescan["pc"].transpose(-1, -2)).transpose(-1, -2)
+            ref_ids, res_ids = ref["objectId"].tolist(), rescan["objectId"].tolist()
+            for rigid in sg["rigid"]:
+                if rigid["instance_reference"] not in ref_ids or rigid.get("instance_rescan", rigid["instance_reference"]) not in res_ids:
+                    continue
+                gt = torch.tensor(rigid["transform"], dtype=torch.float32, device=dev).reshape(1, 4, 4).transpose(-1, -2).contiguous()
+                a = ref_ids.index(rigid["instance_reference"])
+                b = res_ids.index(rigid.get("instance_rescan", rigid["instance_reference"]))
+                inst_ref = ref["pc"][a].T[ref["pc_mask"][a, 0]].unsqueeze(0).contiguous()
+                inst_res = pc[b].T[rescan["pc_mask"][b, 0]].unsqueeze(0).contiguous()
+                with torch.enable_grad():
+                    R, t = solver._solve_pairwise_registration(inst_ref, inst_res, optim=optim)
+                rre = float(rotation_error(R, gt[:, :3, :3]))
+                sym = rigid.get("symmetry", 0)
+                if sym == 1:
+                    rre = min(rre, abs(180 - rre))
+                elif sym == 2:
+                    rre = min(rre, abs(180 - rre), abs(90 - rre))
+                pred = torch_se3.Rt_to_SE3(R, t)
+                rre_l.append(rre)
+                rte_l.append(float(translation_error(t, gt[:, :3, 3:4])))
+                err_l.append(float(compute_transformation_error(inst_ref, inst_res, pred, gt)))
+                cd_l.append(float(chamfer_distance_torch(inst_ref[:, ::10].contiguous(), inst_res[:, ::10].contiguous(), pred, gt)))
+                shape_l.append(ref["id_label"][[l[0] for l in ref["id_label"]].index(rigid["instance_reference"])][-1])
+    rre, rte, err, cd = (np.asarray(v, dtype=np.float64) for v in (rre_l, rte_l, err_l, cd_l))
+    med = lambda v, m: float(np.median(v[m])) if m.any() else float("nan")
+    return {"n_pairs": int(len(rre)),
+            "recall[T<0.1m]": float(100 * (err < 0.1).mean()) if len(err) else float("nan"),
+            "rre_median[T<0.2m]": med(rre, err < 0.2), "rte_median[T<0.2m]": med(rte, err < 0.2),
+            "recall[RRE<10deg]": float(100 * (rre < 10).mean()) if len(rre) else float("nan"),
+            "rre_median[RRE<10deg]": med(rre, rre < 10), "rte_median[RRE<10deg]": med(rte, rre < 10),
+            "chamfer_median": float(np.median(cd)) if len(cd) else float("nan"), "shape": shape_l}

@@ -118,6 +118,55 @@ def test_3rscan_tree_to_codes(small_prior, tmp_path):
             assert relerr(emb[k][b:b + 1], want[k]) < TOL, (oid, k)
 
 
+def test_chamfer_metric_and_3rscan_relocalization_eval(small_prior, tmp_path):
+    """evaluate.chamfer_distance_torch (nearest neighbours from the library's raw-cloud k-NN) against the dense formula of
+    evaluate.py:111-123, and harness.eval_3rscan_relocalization end to end from a synthetic 3RScan tree: with untrained weights
+    the Kabsch init is meaningless, but ICP on a noise-free rigid copy of a small motion still has to recover the pose."""
+    from livingscenes_amd import evaluate, harness, rscan
+    from livingscenes_amd.lib_math import torch_se3
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    sp, _ = small_prior
+    d = _dev()
+    g = torch.Generator().manual_seed(0)
+    src, ref = torch.randn(2, 300, 3, generator=g), torch.randn(2, 257, 3, generator=g)
+    def rnd_se3():
+        q, _ = torch.linalg.qr(torch.randn(2, 3, 3, generator=g))
+        q = q * torch.sign(torch.det(q))[:, None, None]
+        return torch.cat([q, torch.randn(2, 3, 1, generator=g)], 2)
+    pred, gt = rnd_se3(), rnd_se3()
+    sq = lambda a, b: ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+    a = torch_se3.transform(pred, src)
+    b = torch_se3.transform(torch_se3.concatenate(pred, torch_se3.inverse(gt)), ref)
+    want = sq(a, ref).min(-1)[0].mean(1) + sq(ref, b).min(-1)[0].mean(1)
+    got = evaluate.chamfer_distance_torch(src.to(d), ref.to(d), pred.to(d), gt.to(d))
+    assert relerr(got, want) < 1e-5
+
+    rng = np.random.default_rng(2)
+    root = tmp_path / "data"
+    shape = {5: ("chair", np.abs(rng.standard_normal((1400, 3))).astype(np.float32) * [0.3, 0.5, 0.2]),
+             6: ("sofa", np.abs(rng.standard_normal((1200, 3))).astype(np.float32) * [0.6, 0.2, 0.3] + 2.0)}
+    ang = np.deg2rad(4.0)
+    T = np.eye(4); T[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]; T[:3, 3] = [0.03, -0.02, 0.01]
+    def write(scan_id, move):
+        pts = np.concatenate([(v @ T[:3, :3].T + T[:3, 3]).astype(np.float32) if move else v for _, v in shape.values()])
+        ids = np.concatenate([np.full(len(v), k) for k, (_, v) in shape.items()])
+        rscan.write_scan(str(root / "val_set"), scan_id, pts, ids, [{"objectId": k, "label": l} for k, (l, _) in shape.items()])
+    write("ref", False); write("res", True)
+    cm = lambda M: [float(v) for v in np.asarray(M).T.reshape(-1)]
+    scenes = [{"reference": "ref", "ambiguity": [], "scans": [{"reference": "res", "transform": cm(np.eye(4)), "rigid": [
+        {"instance_reference": 5, "instance_rescan": 5, "transform": cm(T), "symmetry": 0},
+        {"instance_reference": 6, "instance_rescan": 6, "transform": cm(T), "symmetry": 2},
+        {"instance_reference": 99, "instance_rescan": 99, "transform": cm(T), "symmetry": 0}]}]}]
+    rscan.write_index(str(root), "val", scenes)
+    ds = rscan.Dataset_3RScan({"root_path": str(root), "split": "val", "category_list": ["chair", "sofa"], "n_point_per_instance": 1024,
+                               "use_gt_mask": True}, device=d)
+    solver = More_Solver({"shape_priors": {"n_input_point": 128, "prior_name": "chair", "ckpt_dir": ""}, "fps": {"n_init": 1, "random_start": False}}, model=sp)
+    out = harness.eval_3rscan_relocalization(ds, solver, optim=False)
+    assert out["n_pairs"] == 2 and out["shape"] == ["chair", "sofa"]
+    assert out["recall[T<0.1m]"] == 100.0 and out["recall[RRE<10deg]"] == 100.0, out
+    assert out["rre_median[RRE<10deg]"] < 1.0 and out["rte_median[RRE<10deg]"] < 0.02 and out["chamfer_median"] < 1e-3, out
+
+
 def test_all_matchers_vs_golden(golden):
     from livingscenes_amd.lib_more import matcher_new as mn
     g = golden("matchers")
