@@ -23,10 +23,3 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 nq = a.B * M
 print(f"sdf decode B={a.B} grid={a.res}^3: {dt*1e3:.2f} ms  {nq/dt/1e6:.2f} Mqueries/s  {nq*6.7e6/dt/1e12:.1f} TFLOP/s (6.7 MFLOP/query as executed; reference formulation 8.26)")
-if os.environ.get("LS_SDF_CHECK"):   # error of this mode against an fp64 evaluation of the same decoder (torch, on the GPU)
-    from oracle import net  # dev check only
-    w64 = {k: v.double().to(dev) for k, v in net.as_params(synth.make_decoder_weights(dcfg, 0)).items()}
-    sub = slice(0, 20000)
-    ref = net.field_query(w64, dcfg, q[:, sub].double(), {k: v.double() for k, v in emb.items()})
-    err = (sdf[:, sub].double() - ref).abs().max().item() / ref.abs().max().item()
-    print(f"  max |sdf - fp64| / max |sdf| over {a.B}x20000 queries = {err:.2e}")
