@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_kernel(const float* __restrict
                                                       const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
                                                       int32_t* __restrict__ idx_out, float* __restrict__ dist_out, int qpw,
                                                       int qblocks) {
-    __shared__ u64 lsurv[4][KX_CH];
+    __shared__ u64 lsurv[4][KX_CH + 1];   // + one dump slot per wave for the lanes that do not pass (branch-free compaction)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);   // the query blocks of one instance share an XCD (12 KB cloud in its L2)
@@ -37,12 +37,19 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_kernel(const float* __restrict
     u64* ls = lsurv[wave];
     constexpr bool single = SINGLE;   // Ns <= KX_CH: the candidates are loaded once per wave
 
-    float cx[16], cy[16], cz[16];
+    // candidates as PAIRS (j, j + 8) -> packed fp32 math (v_pk_add / v_pk_mul: half the distance instructions; no MFMA in this
+    // kernel, so the packed ops cost nothing extra).  Columns past Ns hold +inf: their distance is +inf and never passes.
+    f32x2 cx[8], cy[8], cz[8];
     auto load_chunk = [&](int c0) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = min(c0 + lane + 64 * j, Ns - 1);   // clamped: columns past Ns are masked below
-            cx[j] = sb[(size_t)c * 3 + 0]; cy[j] = sb[(size_t)c * 3 + 1]; cz[j] = sb[(size_t)c * 3 + 2];
+        for (int j = 0; j < 8; ++j) {
+            const int ca = c0 + lane + 64 * j, cb = ca + 512;
+            const int la = min(ca, Ns - 1), lb = min(cb, Ns - 1);
+            const float ax = sb[(size_t)la * 3 + 0], ay = sb[(size_t)la * 3 + 1], az = sb[(size_t)la * 3 + 2];
+            const float bx = sb[(size_t)lb * 3 + 0], by = sb[(size_t)lb * 3 + 1], bz = sb[(size_t)lb * 3 + 2];
+            cx[j] = f32x2{ca < Ns ? ax : INFINITY, cb < Ns ? bx : INFINITY};
+            cy[j] = f32x2{ca < Ns ? ay : INFINITY, cb < Ns ? by : INFINITY};
+            cz[j] = f32x2{ca < Ns ? az : INFINITY, cb < Ns ? bz : INFINITY};
         }
     };
     if (single) load_chunk(0);
@@ -56,31 +63,32 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_kernel(const float* __restrict
         u64 best = ~0ull;                                     // lanes 0..15: the sorted list so far
         for (int c0 = 0; c0 < Ns; c0 += KX_CH) {
             if (!single) load_chunk(c0);
-            float d[16];
+            f32x2 d[8];
             unsigned mn = 0x7F800000u;                        // +inf
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                float a = accq<FMA>(0.0f, qx, cx[j]);
-                a = accq<FMA>(a, qy, cy[j]);
-                a = accq<FMA>(a, qz, cz[j]);
+            for (int j = 0; j < 8; ++j) {
+                f32x2 a = accq2<FMA>(f32x2{0.0f, 0.0f}, qx, cx[j]);
+                a = accq2<FMA>(a, qy, cy[j]);
+                a = accq2<FMA>(a, qz, cz[j]);
                 d[j] = a;
-                const bool valid = c0 + lane + 64 * j < Ns;
-                mn = min(mn, valid ? __float_as_uint(a) : 0x7F800000u);
+                mn = min(mn, min(__float_as_uint(a.x), __float_as_uint(a.y)));
             }
-            // admission threshold: K-th smallest lane minimum, tightened by the carried list's K-th key
+            // admission threshold: K-th smallest lane minimum, tightened by the carried list's K-th key; capped at the largest
+            // finite float so that the +inf padding columns never pass
             LS_SORT64(cx32, mn, lane)
             unsigned thr = (unsigned)__builtin_amdgcn_readlane((int)mn, K - 1);
             thr = min(thr, (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best >> 32), K - 1));
+            thr = min(thr, 0x7F7FFFFFu);
             int n = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int c = c0 + lane + 64 * j;
-                const bool pass = (c < Ns) & (__float_as_uint(d[j]) <= thr);
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = jj & 7;
+                const float dv = jj < 8 ? d[j].x : d[j].y;
+                const int c = c0 + lane + 64 * j + (jj < 8 ? 0 : 512);
+                const bool pass = __float_as_uint(dv) <= thr;
                 const u64 bal = __ballot(pass);
-                if (pass) {
-                    const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    ls[pos] = make_key(d[j], c, true);
-                }
+                const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                ls[pass ? pos : KX_CH] = make_key(dv, c, true);   // non-passing lanes write the dump slot
                 n += __builtin_popcountll(bal);
             }
             __builtin_amdgcn_wave_barrier();
