@@ -133,12 +133,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the hot path)")
+    # LS_BENCH_BACKEND=gloo: dry run of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices; the
+    # collectives go through the host) -- a logic check only, never a measurement
+    backend = os.environ.get("LS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from livingscenes_amd import sharding as parallel, synth
     from livingscenes_amd.lib_more.matcher_new import sequential_matcher
@@ -181,7 +189,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
 
     def run(n):
         out = None
@@ -348,7 +356,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
-        dist.barrier(device_ids=[local_rank])  # rank 0 may still be in its profiled pass / JSON print
+        dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()  # rank 0 may still be in its profiled pass / JSON print
         dist.destroy_process_group()
 
 
