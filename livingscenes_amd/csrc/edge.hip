@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
         const int ow = on ? oc : 0;
         const float a0 = w0[0 * Co + ow], a1 = w0[1 * Co + ow], a2 = w0[2 * Co + ow];
         const float d0 = w0[3 * Co + ow], d1 = w0[4 * Co + ow], d2 = w0[5 * Co + ow];
+        // the centre-point terms do not depend on the edge
+        const float yc0 = a2 * cx, yc1 = a2 * cy, yc2 = a2 * cz, kc0 = d2 * cx, kc1 = d2 * cy, kc2 = d2 * cz;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
         for (int k = 0; k < EK; ++k) {
@@ -55,8 +57,8 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
             const float nx = P[(size_t)r * 3 + 0], ny = P[(size_t)r * 3 + 1], nz = P[(size_t)r * 3 + 2];
             const float crx = ay * nz - az * ny, cry = az * nx - ax * nz, crz = ax * ny - ay * nx;
             const float dx = nx - cx, dy = ny - cy, dz = nz - cz;
-            float y0 = a0 * crx + a1 * dx + a2 * cx, y1 = a0 * cry + a1 * dy + a2 * cy, y2 = a0 * crz + a1 * dz + a2 * cz;
-            const float k0 = d0 * crx + d1 * dx + d2 * cx, k1 = d0 * cry + d1 * dy + d2 * cy, k2 = d0 * crz + d1 * dz + d2 * cz;
+            float y0 = a0 * crx + a1 * dx + yc0, y1 = a0 * cry + a1 * dy + yc1, y2 = a0 * crz + a1 * dz + yc2;
+            const float k0 = d0 * crx + d1 * dx + kc0, k1 = d0 * cry + d1 * dy + kc1, k2 = d0 * crz + d1 * dz + kc2;
             vn_act(y0, y1, y2, k0, k1, k2, oms);
             s0 += y0; s1 += y1; s2 += y2;
         }
