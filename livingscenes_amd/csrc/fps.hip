@@ -51,6 +51,15 @@ __device__ __forceinline__ void dpp_max_u64(unsigned& hi, unsigned& lo) {
     hi = take ? ohi : hi;
     lo = take ? olo : lo;
 }
+// old value = own value: lanes a row_bcast does not reach (or masks out) keep theirs, so max / min stay correct
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false);
+}
 __device__ __forceinline__ int wave_argmax_dpp(float v, int i, bool valid) {
     unsigned hi = valid ? __float_as_uint(v) + 1u : 0u;  // +1: a valid 0.0 still beats padding
     unsigned lo = valid ? ~(unsigned)i : 0u;
@@ -110,6 +119,85 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ 
         }
     }
     for (int k = max(kk, 0) + lane; k < K; k += 64) {
+        out[k] = -1;
+        if (po) { po[k * 3 + 0] = 0.f; po[k * 3 + 1] = 0.f; po[k * 3 + 2] = 0.f; }
+    }
+}
+
+// Four waves per instance (N = 256 .. 2048): cloud and running min-distance in VGPRs (<= 8 points per thread), per-wave DPP
+// arg-max, the four wave maxima exchanged through a double-buffered LDS slot with ONE workgroup barrier per step.  A step is
+// ~PPT*8 VALU ops + the DPP network + ~2 LDS round trips: 4x shorter than the one-wave kernel's 16 points per lane at N = 1024
+// (the encoder's first down-sampling: 0.52 -> 0.18 ms), same arithmetic and tie rule.
+template <int PPT, bool FMA>
+__global__ __launch_bounds__(256) void fps_quad_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
+                                                       int N, int K, int32_t* __restrict__ idx_out, float* __restrict__ pts_out) {
+    extern __shared__ __attribute__((aligned(16))) float lp[];  // [N][3]
+    __shared__ unsigned lmax[2][4][2];                          // [buffer][wave][hi, lo]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = pts + (size_t)b * N * 3;
+    const int n = lengths ? min(lengths[b], N) : N;
+    for (int t = tid; t < N * 3; t += 256) lp[t] = p[t];
+    __syncthreads();
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = i * 256 + tid;
+        const bool ok = j < n;
+        px[i] = ok ? lp[j * 3 + 0] : 0.f;
+        py[i] = ok ? lp[j * 3 + 1] : 0.f;
+        pz[i] = ok ? lp[j * 3 + 2] : 0.f;
+        md[i] = ok ? INFINITY : -INFINITY;  // padding can never win an arg-max
+    }
+    int32_t* out = idx_out + (size_t)b * K;
+    float* po = pts_out ? pts_out + (size_t)b * K * 3 : nullptr;
+    int last = 0;
+    const int kk = min(K, n);
+    if (tid == 0 && n > 0) {
+        out[0] = 0;
+        if (po) { po[0] = lp[0]; po[1] = lp[1]; po[2] = lp[2]; }
+    }
+    for (int k = 1; k < kk; ++k) {
+        const float lx = lp[last * 3 + 0], ly = lp[last * 3 + 1], lz = lp[last * 3 + 2];
+        float bv = -INFINITY;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float d = dist3<FMA>(lx, ly, lz, px[i], py[i], pz[i]);
+            const float m = fminf(md[i], d);
+            md[i] = (md[i] == -INFINITY) ? md[i] : m;
+            if (md[i] > bv) { bv = md[i]; bi = i * 256 + tid; }  // ascending index inside the thread: strict '>'
+        }
+        // wave arg-max in two single-instruction-per-stage DPP reductions (the compiler folds the DPP move into v_max_f32 /
+        // v_min_u32): the maximum value, then the smallest index among the lanes that hold it.  (The 64-bit key network of the
+        // one-wave kernel costs ~8 dependent instructions per stage.)
+        float wm = bv;
+        wm = fmaxf(wm, dpp_f<0xB1, 0xF>(wm)); wm = fmaxf(wm, dpp_f<0x4E, 0xF>(wm));
+        wm = fmaxf(wm, dpp_f<0x141, 0xF>(wm)); wm = fmaxf(wm, dpp_f<0x140, 0xF>(wm));
+        wm = fmaxf(wm, dpp_f<0x142, 0xA>(wm)); wm = fmaxf(wm, dpp_f<0x143, 0xC>(wm));
+        const float wmax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(wm), 63));
+        unsigned ci = (bv == wmax) ? (unsigned)bi : 0xFFFFFFFFu;
+        ci = min(ci, dpp_u<0xB1, 0xF>(ci)); ci = min(ci, dpp_u<0x4E, 0xF>(ci));
+        ci = min(ci, dpp_u<0x141, 0xF>(ci)); ci = min(ci, dpp_u<0x140, 0xF>(ci));
+        ci = min(ci, dpp_u<0x142, 0xA>(ci)); ci = min(ci, dpp_u<0x143, 0xC>(ci));
+        if (lane == 63) { lmax[k & 1][wave][0] = __float_as_uint(wmax); lmax[k & 1][wave][1] = ci; }
+        __syncthreads();
+        float bh = __uint_as_float(lmax[k & 1][0][0]);
+        unsigned bl = lmax[k & 1][0][1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float oh = __uint_as_float(lmax[k & 1][w][0]);
+            const unsigned ol = lmax[k & 1][w][1];
+            const bool take = oh > bh || (oh == bh && ol < bl);
+            bh = take ? oh : bh;
+            bl = take ? ol : bl;
+        }
+        last = (int)bl;
+        if (tid == 0) {
+            out[k] = last;
+            if (po) { po[k * 3 + 0] = lp[last * 3 + 0]; po[k * 3 + 1] = lp[last * 3 + 1]; po[k * 3 + 2] = lp[last * 3 + 2]; }
+        }
+    }
+    for (int k = max(kk, 0) + tid; k < K; k += 256) {
         out[k] = -1;
         if (po) { po[k * 3 + 0] = 0.f; po[k * 3 + 1] = 0.f; po[k * 3 + 2] = 0.f; }
     }
@@ -178,6 +266,12 @@ static int launch_wave(const float* pts, const int32_t* lengths, int B, int N, i
     return LS_OK;
 }
 template <int PPT, bool FMA>
+static int launch_quad(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
+    hipLaunchKernelGGL((fps_quad_kernel<PPT, FMA>), dim3(B), dim3(256), (size_t)N * 3 * sizeof(float), st, pts, lengths, N, K, idx, po);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+template <int PPT, bool FMA>
 static int launch_block(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
     hipLaunchKernelGGL((fps_block_kernel<PPT, FMA>), dim3(B), dim3(1024), 0, st, pts, lengths, N, K, idx, po);
     LS_LAUNCH_CHECK();
@@ -186,7 +280,14 @@ static int launch_block(const float* pts, const int32_t* lengths, int B, int N, 
 
 template <bool FMA>
 static int fps_mode(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
+    static const bool one_wave = getenv("LS_FPS_ONE_WAVE") && atoi(getenv("LS_FPS_ONE_WAVE")) != 0;   // A/B: the one-wave kernel
     if (N <= 128) return launch_wave<2, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (!one_wave) {
+        if (N <= 256) return launch_quad<1, FMA>(pts, lengths, B, N, K, idx, po, st);
+        if (N <= 512) return launch_quad<2, FMA>(pts, lengths, B, N, K, idx, po, st);
+        if (N <= 1024) return launch_quad<4, FMA>(pts, lengths, B, N, K, idx, po, st);
+        if (N <= 2048) return launch_quad<8, FMA>(pts, lengths, B, N, K, idx, po, st);
+    }
     if (N <= 512) return launch_wave<8, FMA>(pts, lengths, B, N, K, idx, po, st);
     if (N <= 1024) return launch_wave<16, FMA>(pts, lengths, B, N, K, idx, po, st);
     if (N <= 2048) return launch_wave<32, FMA>(pts, lengths, B, N, K, idx, po, st);

@@ -207,7 +207,7 @@ def test_knn_dst_rows_and_self():
 
 # ------------------------------------------------------------------------------------------------ FPS
 @pytest.mark.parametrize("contract", [0, 1])
-@pytest.mark.parametrize("N,K", [(128, 32), (512, 128), (1024, 512), (1500, 300), (5000, 1024), (20000, 1024)])
+@pytest.mark.parametrize("N,K", [(128, 32), (200, 70), (256, 64), (512, 128), (1024, 512), (1500, 300), (2048, 600), (5000, 1024), (20000, 1024)])
 def test_fps_bit_exact(N, K, contract):
     from livingscenes_amd import ops
     from oracle import canon
