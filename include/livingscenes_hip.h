@@ -39,7 +39,7 @@ typedef enum {
 /* flags for the integer-exact ops: how `dist += diff*diff` is rounded (oracle/ls_oracle.c header) */
 #define LS_FLAG_CONTRACT_FMA 1u /* d = fmaf(diff,diff,d); default (0) = separately rounded mul, add */
 #define LS_FLAG_KNN_MFMA_FILTER 2u /* k-NN: accepted for compatibility, no effect: the MFMA sweep kernel (knn_mfma.hip) is the
-                                     default wherever it applies (seed_idx given, C == 32); result is bit-identical */
+                                     default wherever it applies (seed_idx given, C == 32 or 64); result is bit-identical */
 #define LS_FLAG_KNN_VALU_ONLY 4u   /* k-NN: force the all-VALU kernel (knn.hip) even where the MFMA sweep applies (A/B work) */
 
 #define LS_MAX_LAYERS 8
@@ -64,7 +64,10 @@ int ls_device_count(void);
  *            neighbour list of the same point in the previous encoder layer.  Their exact distances initialise
  *            the top-K lists (tighter admission threshold, fewer insertions); the RESULT DOES NOT DEPEND on them.
  * Distance = sum_j (a_j-b_j)^2, j = c*3+x ascending, fp32, rounding per `flags`.  K <= 16.
- * C must be 1 or a multiple of 32. */
+ * C must be 1 or a multiple of 32.  Kernel choice (never visible in the result): C == 1 -> wave-per-query kernel
+ * (knn_xyz.hip); seed_idx given and C in {32, 64} -> seed / matrix-core sweep / finish (knn_mfma.hip; the sweep filters with
+ * bf16 MFMA on centred rows for Ns <= 2048, fp32 MFMA above); Nd <= 32 -> small-problem kernel; otherwise the tiled all-VALU
+ * kernel (knn.hip). */
 int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, const int32_t* seed_idx, int B, int Nd,
                int dst_n, int Ns, int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* stream);
 
