@@ -70,10 +70,15 @@ for i in range(1, L):
             for q in range(Ns):
                 h = [v for v in inv[pkb[q]] if v >= 0]
                 t = 0
-                while t < len(h) and len(h) < 16:      # breadth first
+                cap = 32 if os.environ.get("HINTS32") else 16
+                while t < len(h) and len(h) < cap:      # breadth first
                     for v in inv[pkb[h[t]]]:
-                        if v >= 0 and v not in h and len(h) < 16: h.append(v)
+                        if v >= 0 and v not in h and len(h) < cap: h.append(v)
                     t += 1
+                if cap == 32:                            # keep the 16 best of the 32 by exact distance
+                    srcb, dstb = rows(tr[f"src_f_{i}"])[b], rows(tr[f"dst_f_in_{i}"])[b]
+                    dd = ((srcb[h].double() - dstb[q].double()) ** 2).sum(-1)
+                    h = [h[j] for j in torch.argsort(dd)[:16].tolist()]
                 e = 0
                 while len(h) < 16:                      # isolated point: arbitrary distinct rows
                     v = (q + 1 + e * 37) % Ns; e += 1
