@@ -220,6 +220,16 @@ def test_fps_bit_exact(N, K, contract):
     assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(p, ref[..., None].astype(np.int64), 1))
 
 
+def test_fps_one_wave_switch():
+    """LS_FPS_ONE_WAVE=1 keeps the one-wave kernel for 256..2048-point clouds (A/B): same indices."""
+    import os, subprocess, sys
+    code = ("import numpy as np, torch; from livingscenes_amd import ops; from oracle import canon;"
+            "p = np.random.default_rng(4).standard_normal((2, 1024, 3)).astype(np.float32);"
+            "assert np.array_equal(ops.fps(torch.from_numpy(p).cuda(), 512).cpu().numpy(), canon.fps_c(p, 512))")
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_FPS_ONE_WAVE="1"),
+                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
 def test_fps_ragged_and_degenerate():
     from livingscenes_amd import ops
     from oracle import canon
