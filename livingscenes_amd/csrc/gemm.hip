@@ -427,7 +427,10 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
     const int tm = cdiv(M, GM), tn = cdiv(N, GN);
-    if (K == 32 && tm >= 16) {
+    static const bool split_on = !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
+    // (fp32 mode only: with three-piece bf16 products the tiled kernel below is faster on the K = 32 tables too -- 27.8 / 42.8 /
+    // 34.5 us vs 28.8 / 47.2 / 38.8 us for the three layer-1/2 shapes -- and the arithmetic then depends on nothing but K)
+    if (K == 32 && tm >= 16 && !split_on) {
         // persistent small-K kernel: ~3 resident workgroups per CU, spread evenly over the N-tiles.  (The K = 64 instantiation
         // needs 70 KB of LDS -> 2 workgroups per CU and measured SLOWER than the tiled kernel: 138 vs 110 us at the layer-3 shape.)
         int per_n = cdiv(768, tn);
@@ -441,13 +444,11 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         return LS_OK;
     }
     // LS_GEMM_BF16X3=0: exact fp32 FMA chains on v_mfma_f32_32x32x2_f32 (A/B timing, bit-for-bit comparison with earlier builds)
-    static const bool split_on = !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
     // The arithmetic must not depend on M (a decode of one instance's points has to equal the same rows inside a batched decode),
     // so the choice is the CALLER's: latency_path = a handful of tiles by construction (the per-instance mean rows of the global
     // conv, M = 3B), where the fp32 kernel's shorter slab (16 k, no split arithmetic before the first MFMA) wins: 44 vs 112 us
     // at M = 192, N = 1024, K = 512
-    // (K = 32 stays on the fp32 chain for every M: the persistent small-K kernel below is table-write bound anyway)
-    const bool split = split_on && !latency_path && K != 32;
+    const bool split = split_on && !latency_path;
     const int nsplit = scratch ? gemm_choose_splits(M, N, K) : 1;
     if (nsplit > 1) {
         const int kq = split ? 32 : GK;
