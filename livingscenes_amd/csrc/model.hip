@@ -142,6 +142,10 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         }
         p.Nd[i] = cur;
         LS_REQUIRE(cur >= 1, "encoder: N=%d too small for the down-sampling schedule", N);
+        // a layer with fewer source points than neighbours would hand -1 padded lists to the gather kernels (and the reference's
+        // behaviour there is pytorch3d's padding convention, unpinned): refuse instead of reading out of bounds
+        LS_REQUIRE(p.Ns[i] >= d.num_knn, "encoder: layer %d has %d source points < num_knn=%d (N=%d too small for the schedule)", i,
+                   p.Ns[i], d.num_knn, N);
         p.Cin[i] = i == 0 ? 1 : d.feat_dim[i - 1];
         p.Co[i] = d.feat_dim[i];
         const bool attn = i >= d.atten_start_layer;

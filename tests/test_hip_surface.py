@@ -67,6 +67,18 @@ def test_sdf_decode_two_piece_mode_stays_inside_the_tolerance():
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_SDF_BF16X2="1"), cwd=root)
 
 
+def test_encoder_refuses_a_cloud_too_small_for_its_schedule():
+    """The released schedule down-samples by 32: with N = 256 the last layer would have 8 source points for 16 neighbours
+    (-1 padded lists into the gather kernels).  The library refuses instead of reading out of bounds."""
+    from livingscenes_amd._lib import LsError
+    from livingscenes_amd.model_utils import Shape_Prior
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=_dev())
+    with pytest.raises(LsError, match="too small"):
+        sp.encode(synth.make_instances(2, 256, seed=1).to(_dev()))
+    assert torch.isfinite(sp.encode(synth.make_instances(2, 512, seed=1).to(_dev()))["z_inv"]).all()
+
+
 def test_encode_fps_ragged_matches_reference_loop(small_prior):
     """encode_fps (model_utils.py:199-215): mask-select, FPS to n_pcl, encode -- vs the oracle run instance by instance."""
     from oracle import net
