@@ -164,7 +164,8 @@ def test_knn_mfma_filter_is_exact_on_adversarial_features(case, C):
 
 
 @pytest.mark.parametrize("shape", [(2, 200, 200, 32), (3, 70, 330, 64), (40, 256, 1024, 32), (3, 70, 330, 32), (1, 33, 100, 32),
-                                   (8, 128, 512, 64), (1, 64, 2500, 32), (1, 40, 2100, 64)])   # Ns > 2048: fp32 sweep kernel
+                                   (8, 128, 512, 64), (1, 64, 2500, 32), (1, 40, 2100, 64),   # Ns > 2048: fp32 sweep kernel
+                                   (1, 70, 2048, 32), (1, 50, 1500, 64)])                      # largest bf16-sweep bitmaps
 def test_knn_hints_do_not_change_the_result(shape):
     """seed_idx are HINTS: exact neighbours, random indices, duplicates of each other's ranges, -1 and out-of-range values
     must all yield the oracle's answer bit for bit (also through the candidate-split + merge path)."""
