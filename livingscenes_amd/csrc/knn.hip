@@ -251,8 +251,16 @@ static size_t knn_partial_bytes(int B, int Nd, int Ns) {
     return sp > 1 ? (size_t)B * Nd * sp * 16 * sizeof(u64) : 0;
 }
 // the MFMA sweep kernel (knn_mfma.hip) takes the seeded C == 32 launches unless the caller forces the all-VALU kernel
+// ... and, with hints of its own making (knn_mfma.hip, "auto hints"), the un-seeded ones whose candidates fit the bf16 sweep's bitmap
+static bool knn_autohints_enabled() {
+    static const bool off = (getenv("LS_KNN_AUTOHINTS") && atoi(getenv("LS_KNN_AUTOHINTS")) == 0) ||
+                            (getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0);
+    return !off;
+}
 static bool knn_uses_sweep(int C, bool seeded, int Ns, unsigned flags) {
-    return (C == 32 || C == 64) && seeded && Ns <= 65535 && !(flags & LS_FLAG_KNN_VALU_ONLY);
+    if (!(C == 32 || C == 64) || (flags & LS_FLAG_KNN_VALU_ONLY)) return false;
+    if (seeded) return Ns <= 65535;
+    return knn_autohints_enabled() && Ns >= 64 && Ns <= 2048;
 }
 size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C);
 int knn_sweep_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, bool, int32_t*, float*, const int32_t*, int,
@@ -363,7 +371,8 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
-    if (scratch && knn_uses_sweep(C, seed_idx != nullptr, Ns, flags))   // seeded C == 32 layer: seed / MFMA sweep / finish (knn_mfma.hip)
+    // seeded C == 32 / 64 layers, and un-seeded calls with more than a handful of queries: (auto hints /) seed / MFMA sweep / finish
+    if (scratch && knn_uses_sweep(C, seed_idx != nullptr, Ns, flags) && (seed_idx != nullptr || Nd > 32))
         return knn_sweep_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
     if (C == 1) {
         // raw clouds: wave-per-query kernel (knn_xyz.hip); LS_KNN_XYZ_TILED=1 keeps the tiled kernel for A/B timing

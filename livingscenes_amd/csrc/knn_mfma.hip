@@ -622,6 +622,91 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 0'. hints for UN-SEEDED calls ("auto hints").  Without a previous layer's graph the thresholds come from the data itself: one
+// more bf16 sweep in which every lane keeps, for each of its 16 query rows, the best candidate it has seen -- lane l31 of a wave
+// sees the candidates of residue class l31 (mod 32) of its tile range, so a query gets 32 x nsplit class winners -- and
+// knn_autohint_select_kernel keeps the 16 best of them by approximate distance.  A true neighbour is missed only if a better
+// one shares its class (~2 of 16 with 64 classes), so the K-th exact distance among these hints is close to the final one and
+// the seeded pipeline above runs unchanged.  Hints never influence the result.
+template <int D>
+__global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
+                                                                const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_src,
+                                                                int Nd, int dst_npad, int Ns, int ns_pad, int qgroups, int nsplit,
+                                                                int total_waves, float* __restrict__ win_val, int32_t* __restrict__ win_idx) {
+    constexpr int KK = D / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wg >= total_waves) return;
+    const int sp = wg % nsplit, g = (wg / nsplit) % qgroups, b = wg / (nsplit * qgroups);
+    const int q0 = g * 32, l31 = lane & 31, lh = lane >> 5;
+    const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
+    const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
+    const float* nsb = nrm_src + (size_t)b * Ns;
+    bf16x8 a[KK];
+    {
+        const int qi = q0 + l31;
+        const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
+        const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+    }
+    float best[16];
+    int bt[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best[r] = -INFINITY; bt[r] = -1; }
+    const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
+    const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
+#pragma unroll 2
+    for (int t = t0; t < t1; ++t) {
+        const unsigned short* bp = sqb + ((size_t)t * KK * 64 + lane) * 8;
+        bf16x8 bf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        const int cg = t * 32 + l31;
+        const float hb = cg < Ns ? 0.5f * nsb[min(cg, Ns - 1)] : INFINITY;   // padding columns can never win
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = -hb;                              // S - |s|^2 / 2: largest = nearest (|q|^2 is per query)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bf[kk], S, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool better = S[r] > best[r];
+            best[r] = better ? S[r] : best[r];
+            bt[r] = better ? t : bt[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (q < Nd) {
+            const size_t o = (((size_t)b * Nd + q) * nsplit + sp) * 32 + l31;
+            win_val[o] = best[r];
+            win_idx[o] = bt[r] >= 0 ? bt[r] * 32 + l31 : -1;
+        }
+    }
+}
+// one wave per query: the 16 best of its W = 32 * nsplit <= 64 class winners -> hints[q][16]
+__global__ __launch_bounds__(256) void knn_autohint_select_kernel(const float* __restrict__ win_val, const int32_t* __restrict__ win_idx, int W,
+                                                                  int total_q, int32_t* __restrict__ hints) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= total_q) return;
+    u64 k = ~0ull;
+    if (lane < W) {
+        const int idx = win_idx[(size_t)q * W + lane];
+        if (idx >= 0) {
+            unsigned u = __float_as_uint(win_val[(size_t)q * W + lane]);
+            u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;       // monotone in the float value
+            k = ((u64)(~u) << 32) | (unsigned)idx;             // ascending key order = descending value
+        }
+    }
+    LS_SORT64(cx64, k, lane)
+    if (lane < 16) hints[(size_t)q * 16 + lane] = (k == ~0ull) ? -1 : (int)(unsigned)k;
+}
+
 static inline size_t pad32(size_t n) { return (n + 31) & ~(size_t)31; }
 static bool knn_sweep_bf16_enabled() {
     static const bool off = getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0;   // A/B: fp32 sweep kernel
@@ -633,7 +718,8 @@ size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C) {
     return ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256      // row norms
            + nq * 16 * sizeof(u64) + nq * sizeof(int32_t) + nq * KS_CAP * sizeof(unsigned short) + 256
            + (size_t)B * D * sizeof(float) + 256                            // instance means
-           + ((size_t)B * pad32(Ns) + (size_t)B * pad32(dst_n)) * D * sizeof(unsigned short) + 512;   // bf16 images (src, dst)
+           + ((size_t)B * pad32(Ns) + (size_t)B * pad32(dst_n)) * D * sizeof(unsigned short) + 512    // bf16 images (src, dst)
+           + nq * 64 * (sizeof(float) + sizeof(int32_t)) + nq * 16 * sizeof(int32_t) + 512;           // auto hints: class winners, hints
 }
 
 template <int CC>
@@ -678,7 +764,26 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
             LS_LAUNCH_CHECK();
         }
         LS_HIP_CHECK(hipMemsetAsync(surv_cnt, 0, nq * sizeof(int32_t), st));
+        if (!seed_idx) {   // un-seeded call: hints from a first sweep (class winners -> 16 best)
+            unsigned short* img_end = dq + (size_t)B * dst_npad * D;
+            float* win_val = (float*)(((uintptr_t)img_end + 255) & ~(uintptr_t)255);
+            int32_t* win_idx = (int32_t*)(win_val + nq * 64);
+            int32_t* hints = win_idx + nq * 64;
+            const int qgroups = cdiv(Nd, 32);
+            const int nsplit = ((long long)B * qgroups < 4096 && ns_pad / 32 >= 16) ? 2 : 1;   // W = 32 nsplit <= 64 winners per query
+            const int total_waves = B * qgroups * nsplit;
+            hipLaunchKernelGGL(knn_sweep_winners_kernel<D>, dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, Nd, dst_npad,
+                               Ns, ns_pad, qgroups, nsplit, total_waves, win_val, win_idx);
+            LS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(knn_autohint_select_kernel, dim3(cdiv((long long)nq, 4)), dim3(256), 0, st, win_val, win_idx, 32 * nsplit, (int)nq,
+                               hints);
+            LS_LAUNCH_CHECK();
+            seed_idx = hints;
+            seed_n = Nd;
+            seed_by_row = 0;
+        }
     } else {
+        LS_REQUIRE(seed_idx != nullptr, "knn_sweep: the fp32 sweep needs seed lists");
         rc = row_norms_launch(src, 3 * C, (long long)B * Ns, nsrc, st);
         if (rc != LS_OK) return rc;
         if (dst != src) {
@@ -736,7 +841,6 @@ int knn_sweep_launch(const float* dst, const float* src, const int32_t* dst_rows
                      bool fma, int32_t* idx_out, float* dist_out, const int32_t* seed_idx, int seed_n, int seed_by_row, void* scratch,
                      hipStream_t st) {
     LS_REQUIRE(C == 32 || C == 64, "knn_sweep: only C == 32 / 64 layers are supported (C=%d)", C);
-    LS_REQUIRE(seed_idx != nullptr, "knn_sweep: needs seed lists");
     LS_REQUIRE(Ns <= 65535, "knn_sweep: Ns=%d exceeds the 16-bit survivor index", Ns);
     if (C == 32)
         return knn_sweep_launch_t<32>(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);

@@ -81,6 +81,9 @@ struct ls_model {
     bool knn_filter = true;        // LS_KNN_FILTER=0: all-VALU k-NN kernel on the seeded C == 32 layers too (A/B timing)
     bool sdf_bf16x2 = false;       // LS_SDF_BF16X2=1: decoder GEMMs with two-piece bf16 products (2^-16 per product, ~1.7x; opt-in)
     bool seed_knn = true;          // LS_KNN_SEEDS=0 disables seeding a layer's k-NN lists from the previous layer's graph
+    int hint_policy = 0;           // LS_KNN_HINTS: 0 "mixed" (default) = previous-layer lists for the C = 32 layers, the sweep's own
+                                   // auto hints elsewhere; 1 "prev" = previous-layer lists wherever they exist (composed after a
+                                   // down-sampling layer); 2 "auto" = never use the previous layer
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     bool profiling = false;
     std::vector<ProfRec> prof;          // pending (un-collected) event pairs
@@ -281,6 +284,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     m->d = *desc;
     if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_SEEDS")) m->seed_knn = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_KNN_HINTS")) m->hint_policy = !strcmp(ev, "prev") ? 1 : (!strcmp(ev, "auto") ? 2 : 0);
     if (const char* ev = getenv("LS_SDF_BF16X2")) m->sdf_bf16x2 = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_FILTER")) m->knn_filter = atoi(ev) != 0;
     hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
@@ -424,9 +428,14 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
             { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
                 // == this layer's source set, so its indices address this layer's candidates directly)
-                const int32_t* seeds = (m->seed_knn && prev_knn && p.level[i - 1] < 0) ? prev_knn : nullptr;
+                // Measured per layer (bench, B = 64): the previous layer's lists are the better hints where features change little
+                // (C = 32 layers 1, 2: 0.136 / 0.106 ms vs 0.166 / 0.121 ms with auto hints); after a down-sampling layer (composed
+                // two-hop hints) and on the C = 64 layers the sweep's own class-winner hints are tighter (layer 3: 0.144 vs 0.207 ms,
+                // layer 4: 0.088 vs 0.100 ms).
+                const bool want_prev = m->seed_knn && prev_knn && m->hint_policy != 2 && (m->hint_policy == 1 || Cin == 32);
+                const int32_t* seeds = (want_prev && p.level[i - 1] < 0) ? prev_knn : nullptr;
                 const unsigned kflags = flags | (m->knn_filter ? 0u : LS_FLAG_KNN_VALU_ONLY);
-                if (m->seed_knn && prev_knn && prev_rows && knn_would_sweep(Cin, Ns, kflags)) {
+                if (want_prev && prev_rows && knn_would_sweep(Cin, Ns, kflags)) {
                     // the previous layer down-sampled: map its lists into this layer's (smaller) source set, two hops deep
                     rc = knn_compose_hints_launch(prev_knn, prev_rows, B, Ns, p.Ns[i - 1], I(p.o_inv), I(p.o_hint), st);
                     if (rc != LS_OK) return rc;
