@@ -15,13 +15,16 @@ LAYERS = {
     "knn[layer 2]": (["ls::knn_mean_rows_kernel @ 128 blocks", "ls::knn_prep_bf16_kernel @ 512 blocks", "ls::knn_seed_kernel<32, false> @ 2048 blocks",
                       "ls::knn_sweep_bf16_kernel<96> @ 1024 blocks", "ls::knn_finish_kernel<32, false> @ 2048 blocks"],
                      "centre + bf16 image + seed + bf16 MFMA sweep + finish"),
-    "knn[layer 3]": (["ls::knn_inverse_rows_kernel @ 128 blocks", "ls::knn_compose_hints_kernel @ 2048 blocks", "ls::knn_mean_rows_kernel @ 192 blocks",
-                      "ls::knn_prep_bf16_kernel @ 256 blocks", "ls::knn_seed_kernel<64, false> @ 2048 blocks",
-                      "ls::knn_sweep_bf16_kernel<192> @ 1024 blocks", "ls::knn_finish_wave_kernel<64, false> @ 8192 blocks"],
-                     "hint composition + centre + bf16 image + seed + bf16 MFMA sweep + wave-per-query finish"),
-    "knn[layer 4]": (["ls::knn_mean_rows_kernel @ 192 blocks", "ls::knn_prep_bf16_kernel @ 256 blocks", "ls::knn_seed_kernel<64, false> @ 512 blocks",
-                      "ls::knn_sweep_bf16_kernel<192> @ 256 blocks", "ls::knn_finish_wave_kernel<64, false> @ 2048 blocks"],
-                     "centre + bf16 image + seed + bf16 MFMA sweep + wave-per-query finish"),
+    "knn[layer 3]": (["ls::knn_mean_rows_kernel @ 192 blocks", "ls::knn_prep_bf16_kernel @ 256 blocks",
+                      "ls::knn_sweep_winners_kernel<192> @ 512 blocks", "ls::knn_autohint_select_kernel @ 8192 blocks",
+                      "ls::knn_seed_kernel<64, false> @ 2048 blocks", "ls::knn_sweep_bf16_kernel<192> @ 1024 blocks",
+                      "ls::knn_finish_wave_kernel<64, false> @ 8192 blocks"],
+                     "centre + bf16 image + class-winner sweep + hint select + seed + bf16 MFMA sweep + wave-per-query finish"),
+    "knn[layer 4]": (["ls::knn_mean_rows_kernel @ 192 blocks", "ls::knn_prep_bf16_kernel @ 256 blocks",
+                      "ls::knn_sweep_winners_kernel<192> @ 128 blocks", "ls::knn_autohint_select_kernel @ 2048 blocks",
+                      "ls::knn_seed_kernel<64, false> @ 512 blocks", "ls::knn_sweep_bf16_kernel<192> @ 256 blocks",
+                      "ls::knn_finish_wave_kernel<64, false> @ 2048 blocks"],
+                     "centre + bf16 image + class-winner sweep + hint select + seed + bf16 MFMA sweep + wave-per-query finish"),
 }
 src = sys.argv[1]
 d = json.load(open(src))
