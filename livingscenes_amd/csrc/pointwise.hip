@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const float* __restric
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < row) {
         const float* p = f + (size_t)b * N * row + col;
+#pragma unroll 8   // eight independent loads in flight; the sum keeps its order
         for (int n = rs; n < N; n += 16) {
             const float4 v = *reinterpret_cast<const float4*>(p + (size_t)n * row);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
