@@ -8,7 +8,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller (PyTorch) owns all
- *     input / output / workspace buffers; the library never frees or retains caller memory.
+ *     input / output / workspace buffers; the library never frees or retains caller memory and never
+ *     allocates device memory behind an operator call: every op that needs scratch takes
+ *     (workspace, workspace_bytes) sized by its ls_<op>_workspace_bytes() query.  The only library-owned
+ *     device allocations are the packed weights of an ls_model_t (and, on the first ls_sdf_backward of a
+ *     model, their transposed copy), freed by ls_model_destroy.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
  *     the device.  (ls_encoder_forward additionally forks onto a library-owned side stream and joins
  *     back with events; the join happens before it returns control of `stream`'s tail.)
@@ -42,6 +46,14 @@ typedef enum {
                                      default wherever it applies (seed_idx given, C == 32 or 64); result is bit-identical */
 #define LS_FLAG_KNN_VALU_ONLY 4u   /* k-NN: force the all-VALU kernel (knn.hip) even where the MFMA sweep applies (A/B work) */
 
+#define LS_FLAG_KABSCH_RAW_WEIGHTS 8u /* Kabsch: `weights` are final (the caller applied pose_estimation.py:52-66 itself); no normalisation */
+
+/* per-problem status written to ls_kabsch_batched_f32's flags_out */
+#define LS_KABSCH_OK 0         /* covariance of rank >= 2: unique rotation */
+#define LS_KABSCH_RANK1 1      /* rank 1: smallest rotation of the least-squares family (torch.svd also succeeds here) */
+#define LS_KABSCH_RANK0 2      /* zero covariance: identity rotation, t = mu2 - mu1 */
+#define LS_KABSCH_NONFINITE 3  /* NaN / Inf input: identity, zero t -- the reference's SVD-exception branch, flag = True */
+
 #define LS_MAX_LAYERS 8
 
 int ls_version(void);
@@ -67,9 +79,12 @@ int ls_device_count(void);
  * C must be 1 or a multiple of 32.  Kernel choice (never visible in the result): C == 1 -> wave-per-query kernel
  * (knn_xyz.hip); seed_idx given and C in {32, 64} -> seed / matrix-core sweep / finish (knn_mfma.hip; the sweep filters with
  * bf16 MFMA on centred rows for Ns <= 2048, fp32 MFMA above); Nd <= 32 -> small-problem kernel; otherwise the tiled all-VALU
- * kernel (knn.hip). */
+ * kernel (knn.hip).  workspace: ls_knn_workspace_bytes(..., seeded = seed_idx != NULL, flags) bytes (0 for some shapes: then
+ * workspace may be NULL). */
+size_t ls_knn_workspace_bytes(int B, int Nd, int dst_n, int Ns, int C, int seeded, unsigned flags);
 int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, const int32_t* seed_idx, int B, int Nd,
-               int dst_n, int Ns, int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* stream);
+               int dst_n, int Ns, int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* workspace,
+               size_t workspace_bytes, void* stream);
 
 /* pytorch3d.ops.sample_farthest_points(points, K=..., random_start_point=False) as called at
  * vec_dgcnn_atten.py:169, model_utils.py:205, lib_more/more_solver.py:107-108.
@@ -80,10 +95,16 @@ int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, un
 
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) -- the VecLinear channel contraction
  * (vec_layers.py:121-136, F.linear at :134) on x-major rows, and the DeepSDF linears
- * (lib_shape_prior/core/lib/implicit_func/deepsdf_decoder.py:98-121).  fp32 MFMA (exact fp32 FMA chains).
- * K % 4 == 0, lda/ldw/ldc % 4 == 0; bias may be NULL; relu in {0,1}. */
+ * (lib_shape_prior/core/lib/implicit_func/deepsdf_decoder.py:98-121).  fp32 in, fp32 out; the products run on the bf16
+ * matrix cores as THREE-PIECE splits (a = a1 + a2 + a3 exactly up to 2^-24, six v_mfma_f32_32x32x16_bf16 per 16 k, fp32
+ * accumulate): measured against fp64 this is as accurate as -- slightly better than -- an fp32 FMA chain, and exact on
+ * integer-valued operands.  LS_GEMM_BF16X3=0 in the environment selects the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact
+ * fp32 FMA chains) instead.  A row's result does not depend on the other rows of the call.
+ * K % 4 == 0, lda/ldw/ldc % 4 == 0; bias may be NULL; relu in {0,1}.  workspace: ls_gemm_workspace_bytes(M, N, K) bytes
+ * (split-K slabs of under-filled long-K problems; 0 -> may be NULL). */
+size_t ls_gemm_workspace_bytes(int M, int N, int K);
 int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M,
-                int N, int K, int relu, void* stream);
+                int N, int K, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Shape_Prior.encode prologue, model_utils.py:166-177: centroid, scale_0 = mean of the 5 largest
  * entries of the N x N distance matrix, normalised cloud.
@@ -92,8 +113,10 @@ int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* 
                            void* stream);
 
 /* sequential_matcher's score matrix, lib_more/matcher_new.py:110-120:
- * S = normalize(m0) @ normalize(m1)^T.   m0 [n,D], m1 [m,D] -> S [n,m] */
-int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* stream);
+ * S = normalize(m0) @ normalize(m1)^T.   m0 [n,D], m1 [m,D] -> S [n,m];  workspace: (n + m) floats (the inverse row norms) */
+size_t ls_cosine_scores_workspace_bytes(int n, int m);
+int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* The greedy assignment loop shared by sequential / sim3_seq / eq_seq matchers
  * (matcher_new.py:121-136, :166-181, :212-227): repeat min(n,m) times { S /= (max(S)+1e-5); take the
@@ -103,11 +126,12 @@ int ls_greedy_match_f32(float* scores, int n, int m, int64_t* matches0, int64_t*
 
 /* kabsch_transformation_estimation(x1, x2, weights, normalize_w=True, eps=1e-7),
  * lib_more/pose_estimation.py:29-102 (+ transformation_residuals :105-121).
- *   x1,x2 [b,n,3]; weights [b,n] or NULL (ones); R [b,3,3], t [b,3] (the reference's [b,3,1]),
- *   res [b,n] or NULL, flags_out [b] int32 or NULL (1 = degenerate covariance -> identity pose,
- *   mirroring the SVD-failure branch at :79-88). */
-int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, float* R, float* t,
-                          float* res, int32_t* flags_out, void* stream);
+ *   x1,x2 [b,n,3]; weights [b,n] or NULL (ones); flags: 0 = weights are normalised as :52-54 does, LS_FLAG_KABSCH_RAW_WEIGHTS =
+ *   used as given (normalize_w=False, or the caller applied best_k / w_threshold of :58-66 to the normalised weights);
+ *   R [b,3,3], t [b,3] (the reference's [b,3,1]), res [b,n] or NULL, flags_out [b] int32 or NULL = LS_KABSCH_* status
+ *   (only LS_KABSCH_NONFINITE corresponds to the reference's SVD-failure branch at :79-88). */
+int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, unsigned flags, float* R,
+                          float* t, float* res, int32_t* flags_out, void* stream);
 
 /* mean Kabsch residual of every (src i, tgt j) pair of equivariant codes: res_mat of
  * matcher_new.py:150-156 / :196-202.   src [n,P,3], tgt [m,P,3] -> res [n,m] */
@@ -123,7 +147,7 @@ int ls_icp_f32(const float* X, const float* Y, const float* R0, const float* T0,
                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Model handle (packed device-resident weights: the library's only allocation)
+ * Model handle (packed device-resident weights: the library's only device allocation)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ls_model ls_model_t;
 
@@ -179,6 +203,40 @@ size_t ls_encoder_workspace_bytes(const ls_model_t* m, int B, int N);
 int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, unsigned flags, float* z_so3,
               float* z_inv, float* s, float* t, int32_t* trace_knn, int32_t* trace_fps, void* workspace,
               size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The encoder's layer operators on their own (the same code ls_encode runs), for callers that drive the layer loop
+ * themselves and for isolated parity tests.  Features are [B, N, 3, C] rows; `layer` selects the weights.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One edge-conv layer of VecDGCNN_att.forward WITHOUT its residual global conv: get_graph_feature (vec_dgcnn_atten.py:124-161:
+ * cat(nbr - ctr, ctr); + the cross-product channel at layer 0) -> V_list[layer] VecLNA (vec_layers.py:523-534) -> mean over the
+ * 16 neighbours (:202-204, layers < atten_start_layer: ls_vn_edgeconv_pool_f32), or K / Q / V VecLNAs + channel_equi_vec_normalize
+ * (vec_layers.py:24-31) + per-head soft-max attention (:205-219, ls_vn_edgeconv_attn_f32).
+ *   src_f [B,Ns,3,C_in] (layer 0: the normalised cloud [B,Ns,3]); knn [B,Nd,16] int32 indices into the Ns source points;
+ *   dst_rows [B,Nd] int32 or NULL: the FPS selection when the layer down-samples (destination point n = source row dst_rows[n]),
+ *   NULL requires Nd == Ns;  out [B,Nd,3,C_out].  workspace holds the folded per-point tables (edge.hip header). */
+size_t ls_vn_edgeconv_workspace_bytes(const ls_model_t* m, int layer, int B, int Ns, int Nd, int has_dst_rows);
+int ls_vn_edgeconv_pool_f32(ls_model_t* m, int layer, const float* src_f, const int32_t* knn, const int32_t* dst_rows, int B,
+                            int Ns, int Nd, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int ls_vn_edgeconv_attn_f32(ls_model_t* m, int layer, const float* src_f, const int32_t* knn, const int32_t* dst_rows, int B,
+                            int Ns, int Nd, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The residual global conv of layer `layer` >= res_global_start_layer (vec_dgcnn_atten.py:222-225):
+ * out = VecLinearNormalizeActivate_G(cat(f, mean_n f))  (vec_layers.py:523-534 = VecLinear :121-136 + VecActivation :241-268).
+ *   f [B,N,3,C] -> out [B,N,3,C] */
+size_t ls_vn_lna_workspace_bytes(const ls_model_t* m, int layer, int B, int N);
+int ls_vn_lna_f32(ls_model_t* m, int layer, const float* f, int B, int N, float* out, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* The encoder's heads (vec_dgcnn_atten.py:231-250): conv_c VecLNA (shared direction) -> mean over the NP points -> z_so3 =
+ * channel_equi_vec_normalize, scale = mean_c |x_c| * scale_factor, z_inv = <cevn(fc_inv x), z_so3>, center = VecResBlock
+ * (vec_layers.py:631-651) * scale_factor; then Shape_Prior.encode's epilogue (model_utils.py:182-185) when centroid / scale0
+ * are given: t = center + centroid, s = scale0 * scale (both NULL: t = center, s = scale).
+ *   f [B,NP,3,C_last] -> z_so3 [B,c_dim,3], z_inv [B,c_dim], s [B], t [B,3] */
+size_t ls_encoder_tail_workspace_bytes(const ls_model_t* m, int B, int NP);
+int ls_encoder_tail_f32(ls_model_t* m, const float* f, const float* centroid, const float* scale0, int B, int NP, float* z_so3,
+                        float* z_inv, float* s, float* t, void* workspace, size_t workspace_bytes, void* stream);
 
 /* FieldWrapper.forward(query, None, code, return_sdf=True), decoder_type "inner_deepsdf":
  * model_utils.py:230-263 + DeepSDF_Decoder.forward, deepsdf_decoder.py:78-123.

@@ -9,12 +9,14 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblivingscenes_hip.so")
+LIB_PATH = os.environ.get("LS_LIB_PATH") or os.path.join(_HERE, "lib", "liblivingscenes_hip.so")   # LS_LIB_PATH: A/B builds
 
 LS_MAX_LAYERS = 8
 FLAG_CONTRACT_FMA = 1
 FLAG_KNN_MFMA_FILTER = 2
 FLAG_KNN_VALU_ONLY = 4
+FLAG_KABSCH_RAW_WEIGHTS = 8
+KABSCH_OK, KABSCH_RANK1, KABSCH_RANK0, KABSCH_NONFINITE = 0, 1, 2, 3
 
 
 class LsError(RuntimeError):
@@ -72,13 +74,16 @@ SIGNATURES = {
     "ls_version": (_I, []),
     "ls_last_error": (ctypes.c_char_p, []),
     "ls_device_count": (_I, []),
-    "ls_knn_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P, _P, _P]),
+    "ls_knn_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _U]),
+    "ls_knn_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P, _P, _P, _SZ, _P]),
     "ls_fps_f32": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P]),
-    "ls_gemm_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ls_gemm_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "ls_gemm_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "ls_encode_prologue_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),
-    "ls_cosine_scores_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "ls_cosine_scores_workspace_bytes": (_SZ, [_I, _I]),
+    "ls_cosine_scores_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "ls_greedy_match_f32": (_I, [_P, _I, _I, _P, _P, _P]),
-    "ls_kabsch_batched_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "ls_kabsch_batched_f32": (_I, [_P, _P, _P, _I, _I, _U, _P, _P, _P, _P, _P]),
     "ls_kabsch_residual_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "ls_icp_workspace_bytes": (_SZ, [_I, _I]),
     "ls_icp_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -86,6 +91,13 @@ SIGNATURES = {
     "ls_model_destroy": (None, [_P]),
     "ls_encoder_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ls_vn_edgeconv_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I, _I]),
+    "ls_vn_edgeconv_pool_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "ls_vn_edgeconv_attn_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "ls_vn_lna_workspace_bytes": (_SZ, [_P, _I, _I, _I]),
+    "ls_vn_lna_f32": (_I, [_P, _I, _P, _I, _I, _P, _P, _SZ, _P]),
+    "ls_encoder_tail_workspace_bytes": (_SZ, [_P, _I, _I]),
+    "ls_encoder_tail_f32": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "ls_sdf_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_sdf_decode": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
     "ls_sdf_rows_workspace_bytes": (_SZ, [_P, _I, ctypes.c_longlong]),
@@ -129,6 +141,13 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().ls_last_error().decode(errors="replace")
         raise LsError(f"{what} failed (status {rc}): {msg}")
+
+
+def call(device, name, *args):
+    """Invoke operator `name` with `device` current: the library launches on the passed stream, and a kernel launched on the NULL
+    (default) stream goes to whatever device is current -- tensors on a non-current GPU would otherwise fault or compute garbage."""
+    with torch.cuda.device(device):
+        check(getattr(load(), name)(*args), name)
 
 
 def ptr(t):

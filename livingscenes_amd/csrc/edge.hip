@@ -284,6 +284,13 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     // lane-private LDS slots ([neighbour][thread]: conflict-free without padding -> 32 KB per chunk pair, five workgroups per CU):
     // head scores per chunk and |k|^2 per neighbour.  Keeping these arrays out of VGPRs lets the neighbour loops stay rolled
     // (bounded registers, 2 neighbours of loads in flight).
+    // REPRODUCIBILITY (round 2): this file is built with -fno-slp-vectorize (build.py).  With hipcc's SLP-formed packed fp32 math
+    // (v_pk_mul_f32 / v_pk_fma_f32, 172 of them in this kernel) the outputs of a few points per launch moved by 1e-6..1e-5 whenever
+    // the kernel's waves shared CUs with the bf16-MFMA GEMM of other streams (always in the last 16 lanes of a wave; 4..19 of 48
+    // launches; never when run alone) -- found by tests/test_hip_fullbatch.py, isolated by scripts/diag/edge_determinism.py by
+    // elimination: no LDS (arrays in registers / a one-pass online soft-max), no DPP, no IEEE division, wait states after every
+    // transcendental or LDS store each still failed; the same source without packed ops never did (0 of 96) and needs fewer
+    // registers (this kernel 129 -> 104 VGPRs).  The one-pass online-soft-max form measured slower (0.57 vs 0.44 ms per step).
     __shared__ float l_score[NCH][EK][256];
     __shared__ float l_ssk[EK][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(1024) void icp_kernel(const float* __restrict__ X, 
 #pragma unroll
         for (int e = 0; e < 9; ++e) H[e] = (double)(block_sum_1024(sxy[e], red) * invn);
         float Rk[9];
-        bool ok = kabsch_rotation(H, Rk);
+        const bool ok = kabsch_rotation(H, Rk) == 0;   // rank-deficient covariance: keep the previous rotation
         float Rn[9], Tn[3];
         if (ok) {
             // pytorch3d row convention: R = U E V^T = (V E U^T)^T

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(1024) void greedy_match_kernel(float* __restrict__ 
 //   pair_mode 0: i1 = i2 = p (batched Kabsch);  pair_mode 1: p = i*m + j -> (i, j) (residual matrix)
 __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                      const float* __restrict__ weights, int nprob, int n, int pair_m,
-                                                     float eps, float* __restrict__ Rout, float* __restrict__ tout,
+                                                     int raw_weights, float eps, float* __restrict__ Rout, float* __restrict__ tout,
                                                      float* __restrict__ res, float* __restrict__ res_mean,
                                                      int32_t* __restrict__ flags) {
     const int lane = threadIdx.x & 63;
@@ -121,10 +121,11 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
     const float* a = x1 + (size_t)i1 * n * 3;
     const float* b = x2 + (size_t)i2 * n * 3;
     const float* w = weights ? weights + (size_t)p * n : nullptr;
-    // weights / (sum + eps)   (pose_estimation.py:52-54)
+    // weights / (sum + eps)   (pose_estimation.py:52-54); raw_weights: the caller already applied :52-66 (normalisation,
+    // best_k selection, w_threshold zeroing WITHOUT renormalising) and the weights are used as they are
     float sw = 0.f;
     for (int i = lane; i < n; i += 64) sw += w ? w[i] : 1.0f;
-    sw = wave_sum(sw) + eps;
+    sw = (raw_weights && w) ? 1.0f : wave_sum(sw) + eps;
     // weighted means, divided by (sum of normalised weights + eps)  (:68-69)
     float m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0}, swn = 0.f;
     for (int i = lane; i < n; i += 64) {
@@ -152,11 +153,9 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
 #pragma unroll
     for (int e = 0; e < 9; ++e) Hd[e] = (double)wave_sum(H[e]);
     float R[9];
-    bool ok = kabsch_rotation(Hd, R);
+    const int code = kabsch_rotation(Hd, R);
     float t[3];
-    if (!ok) {  // SVD-failure branch of the reference (:79-88): identity rotation, zero translation
-#pragma unroll
-        for (int e = 0; e < 9; ++e) R[e] = (e % 4 == 0) ? 1.f : 0.f;
+    if (code == LS_KABSCH_NONFINITE) {  // the reference's SVD-failure branch (:79-88): identity rotation, zero translation
         t[0] = t[1] = t[2] = 0.f;
     } else {
 #pragma unroll
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
     if (lane == 0) {
         if (Rout) for (int e = 0; e < 9; ++e) Rout[(size_t)p * 9 + e] = R[e];
         if (tout) for (int e = 0; e < 3; ++e) tout[(size_t)p * 3 + e] = t[e];
-        if (flags) flags[p] = ok ? 0 : 1;
+        if (flags) flags[p] = code;
     }
     // residuals |R x1 + t - x2|   (:105-121)
     float rs = 0.f;
@@ -195,9 +194,9 @@ int greedy_match_launch(float* S, int n, int m, long long* m0, long long* m1, hi
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
-int kabsch_launch(const float* x1, const float* x2, const float* w, int nprob, int n, int pair_m, float* R, float* t,
+int kabsch_launch(const float* x1, const float* x2, const float* w, int nprob, int n, int pair_m, int raw_weights, float* R, float* t,
                   float* res, float* res_mean, int32_t* flags, hipStream_t st) {
-    hipLaunchKernelGGL(kabsch_kernel, dim3(cdiv(nprob, 4)), dim3(256), 0, st, x1, x2, w, nprob, n, pair_m, 1e-7f, R, t, res,
+    hipLaunchKernelGGL(kabsch_kernel, dim3(cdiv(nprob, 4)), dim3(256), 0, st, x1, x2, w, nprob, n, pair_m, raw_weights, 1e-7f, R, t, res,
                        res_mean, flags);
     LS_LAUNCH_CHECK();
     return LS_OK;

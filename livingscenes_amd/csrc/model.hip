@@ -58,7 +58,7 @@ int sdf_query_grad_launch(const float*, const float*, const float*, const float*
 int transpose_launch(const float*, int, int, float*, hipStream_t);
 int cosine_scores_launch(const float*, const float*, int, int, int, float*, float*, hipStream_t);
 int greedy_match_launch(float*, int, int, long long*, long long*, hipStream_t);
-int kabsch_launch(const float*, const float*, const float*, int, int, int, float*, float*, float*, float*, int32_t*, hipStream_t);
+int kabsch_launch(const float*, const float*, const float*, int, int, int, int, float*, float*, float*, float*, int32_t*, hipStream_t);
 size_t icp_workspace_bytes(int b, int n);
 int icp_run(const float*, const float*, const float*, const float*, int, int, int, int, float, unsigned, float*, float*, float*,
             int32_t*, void*, size_t, hipStream_t);
@@ -84,6 +84,9 @@ struct ls_model {
     int hint_policy = 0;           // LS_KNN_HINTS: 0 "mixed" (default) = previous-layer lists for the C = 32 layers, the sweep's own
                                    // auto hints elsewhere; 1 "prev" = previous-layer lists wherever they exist (composed after a
                                    // down-sampling layer); 2 "auto" = never use the previous layer
+    int debug_layers = -1;         // LS_DEBUG_LAYERS=n: ls_encode stops after n layers (outputs undefined) and prints the workspace plan:
+                                   // race hunting by comparing workspaces (scripts/diag/)
+    bool fps_side = true;          // LS_FPS_SIDE=0 runs the FPS chain on the caller's stream (A/B timing, race hunting)
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     bool profiling = false;
     std::vector<ProfRec> prof;          // pending (un-collected) event pairs
@@ -201,6 +204,87 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     return LS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ layer pieces
+// (shared by ls_encode and the per-operator exports ls_vn_edgeconv_* / ls_vn_lna_f32 / ls_encoder_tail_f32)
+static inline int layer_cin(const ls_model_desc& d, int i) { return i == 0 ? 1 : d.feat_dim[i - 1]; }
+static inline int layer_ncols(const ls_model_desc& d, int i) { return i == 0 ? 0 : (i >= d.atten_start_layer ? 10 : 4) * d.feat_dim[i]; }
+static inline int layer_pcols(const ls_model_desc& d, int i) { return (i >= d.atten_start_layer ? 4 : 2) * d.feat_dim[i]; }
+// floats of the per-point table(s) of edge-conv layer i: one combined table over the source points, or (destination points
+// selected by FPS rows) a neighbour-side table on the source points + a destination-side table on the selected points
+static size_t edge_table_floats(const ls_model_desc& d, int i, int B, int Ns, int Nd, bool rows) {
+    if (i == 0) return 0;
+    const int nc = layer_ncols(d, i), pc = layer_pcols(d, i);
+    return rows ? (size_t)B * 3 * ((size_t)Ns * pc + (size_t)Nd * (nc - pc)) : (size_t)B * Ns * 3 * nc;
+}
+struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; };
+
+// the folded VN-Linear contraction of layer i >= 1 (edge.hip header): cur [B,Ns,3,Cin] -> table(s) in T
+static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, float* T, hipStream_t gs,
+                       EdgeTables& et) {
+    const ls_model_desc& d = m->d;
+    const int Cin = layer_cin(d, i), nc = layer_ncols(d, i), pc = layer_pcols(d, i), qc = nc - pc;
+    const float* W = m->blob + d.off_edge[i];
+    int rc;
+    PROF(LS_K_GEMM_EDGE, i, gs);
+    if (dst_rows) {
+        // down-sampled layer: P table on all source points, Q table only on the FPS-selected destination points
+        float* Tq_w = T + (size_t)B * Ns * 3 * pc;
+        rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
+        if (rc == LS_OK) rc = gemm_dispatch_gather(cur, Cin, W + (size_t)pc * Cin, Cin, nullptr, Tq_w, qc, B * Nd * 3, qc, Cin, 0, dst_rows, Nd, Ns, gs);
+        et = EdgeTables{Tq_w, pc, qc, Nd, 0};
+    } else {
+        rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, gs);
+        et = EdgeTables{T + pc, nc, nc, Ns, 1};
+    }
+    return rc;
+}
+// gather + VN activation + mean-pool | attention of layer i >= 1 over the tables
+static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, const int32_t* knn, const int32_t* dst_rows, int B, int Nd,
+                      int Ns, float* out, hipStream_t st) {
+    const ls_model_desc& d = m->d;
+    const int Co = d.feat_dim[i];
+    if (i >= d.atten_start_layer) {
+        PROF(LS_K_EDGE_ATTN, i, st);
+        return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st);
+    }
+    PROF(LS_K_EDGE_POOL, i, st);
+    return edge_pool_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, out, st);
+}
+// residual global conv of layer i (vec_dgcnn_atten.py:222-225): out = VecLNA_G(cat(msg, mean_n msg))
+static size_t global_conv_gws_floats(const ls_model_desc& d, int i, int B, int Nd) {
+    const int Co = d.feat_dim[i];
+    return std::max(gemm_scratch_floats(B * Nd * 3, 2 * Co, Co), gemm_scratch_floats(B * 3, 4 * Co, Co));
+}
+static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, float* g, float* G, float* TG, float* gws, float* out, hipStream_t st) {
+    const ls_model_desc& d = m->d;
+    const int Co = d.feat_dim[i];
+    const float* Wg = m->blob + d.off_glob[i];
+    int rc;
+    { PROF(LS_K_MEAN, i, st); rc = mean_points_launch(msg, B, Nd, Co, g, st); }
+    if (rc != LS_OK) return rc;
+    {
+        PROF(LS_K_GEMM_GLOB, i, st);
+        rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, gws, st);
+        if (rc == LS_OK) rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, gws, st);
+    }
+    if (rc != LS_OK) return rc;
+    PROF(LS_K_VN_ACT, i, st);
+    return vn_act_rows_launch(TG, 2 * Co, G, 4 * Co, B, Nd, Co, d.neg_slope, out, st);
+}
+// conv_c + pooling + heads (vec_dgcnn_atten.py:231-250) + the encode epilogue (model_utils.py:182-195)
+static int encoder_tail(ls_model* m, const float* cur, int B, int NP, float* Tc, float* gws, const float* centroid, const float* scale0,
+                        float* z_so3, float* z_inv, float* s_out, float* t_out, hipStream_t st) {
+    const ls_model_desc& d = m->d;
+    const int Cl = d.feat_dim[d.num_layers - 1], Cdp = (int)align_up((size_t)d.c_dim + 1, 4);
+    const float* W = m->blob;
+    int rc;
+    { PROF(LS_K_GEMM_TAIL, 0, st); rc = gemm_dispatch_ws(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, Cdp, B * NP * 3, Cdp, Cl, 0, gws, st); }
+    if (rc != LS_OK) return rc;
+    PROF(LS_K_TAIL, 0, st);
+    return tail_launch(Tc, Cdp, B, NP, d.c_dim, W + d.off_inv_t, W + d.off_c_fc0_t, W + d.off_c_misc, d.neg_slope, d.scale_factor,
+                       d.center_pred, d.center_pred_scale, centroid, scale0, z_so3, z_inv, s_out, t_out, st);
+}
+
 extern "C" {
 
 int ls_version(void) { return 100; }
@@ -214,59 +298,68 @@ int ls_device_count(void) {
 }
 
 // ------------------------------------------------------------------------------------------------ leaf exports
+size_t ls_knn_workspace_bytes(int B, int Nd, int dst_n, int Ns, int C, int seeded, unsigned flags) {
+    if (B <= 0 || Nd <= 0 || Ns <= 0 || dst_n <= 0) return 0;
+    return knn_scratch_bytes(B, Nd, dst_n, Ns, C, seeded != 0, flags);
+}
 int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, const int32_t* seed_idx, int B, int Nd, int dst_n, int Ns,
-               int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* stream) {
+               int C, int K, unsigned flags, int32_t* idx_out, float* dist_out, void* workspace, size_t workspace_bytes, void* stream) {
     LS_REQUIRE(B > 0 && Nd > 0 && Ns > 0 && dst_n > 0, "knn: empty problem (B=%d Nd=%d Ns=%d)", B, Nd, Ns);
     LS_REQUIRE(K >= 1 && K <= 16, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const size_t sb = knn_scratch_bytes(B, Nd, dst_n, Ns, C, seed_idx != nullptr, flags);
-    void* scratch = nullptr;
-    if (sb) LS_HIP_CHECK(hipMallocAsync(&scratch, sb, (hipStream_t)stream));
-    int rc = knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, scratch, seed_idx, Nd, 0,
-                          (hipStream_t)stream);
-    if (sb) LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
-    return rc;
+    if (sb > workspace_bytes || (sb && !workspace)) {
+        set_error("knn: workspace %zu < required %zu (ls_knn_workspace_bytes)", workspace_bytes, sb);
+        return LS_ERR_WORKSPACE;
+    }
+    return knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, workspace, seed_idx, Nd, 0, (hipStream_t)stream);
 }
 int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out, float* pts_out,
                void* stream) {
     return fps_dispatch(pts, lengths, B, N, K, flags, idx_out, pts_out, (hipStream_t)stream);
 }
+size_t ls_gemm_workspace_bytes(int M, int N, int K) {
+    return (M > 0 && N > 0 && K > 0 && K % 4 == 0) ? gemm_scratch_floats(M, N, K) * sizeof(float) : 0;
+}
 int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
-                int relu, void* stream) {
-    const size_t sf = (M > 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0) ? gemm_scratch_floats(M, N, K) : 0;
-    if (!sf) return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream);
-    float* scratch = nullptr;   // split-K slabs of an under-filled, long-K problem
-    LS_HIP_CHECK(hipMallocAsync((void**)&scratch, sf * sizeof(float), (hipStream_t)stream));
-    const int rc = gemm_dispatch_ws(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, scratch, (hipStream_t)stream);
-    LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
-    return rc;
+                int relu, void* workspace, size_t workspace_bytes, void* stream) {
+    const size_t sb = (lda % 4 == 0 && ldw % 4 == 0) ? ls_gemm_workspace_bytes(M, N, K) : 0;
+    if (!sb) return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream);
+    if (sb > workspace_bytes || !workspace) {   // split-K slabs of an under-filled, long-K problem
+        set_error("gemm: workspace %zu < required %zu (ls_gemm_workspace_bytes)", workspace_bytes, sb);
+        return LS_ERR_WORKSPACE;
+    }
+    return gemm_dispatch_ws(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (float*)workspace, (hipStream_t)stream);
 }
 int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out, void* stream) {
     LS_REQUIRE(B > 0, "prologue: empty batch");
     return prologue_launch(x, B, N, pts_out, centroid_out, scale0_out, nullptr, (hipStream_t)stream);
 }
-int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* stream) {
+size_t ls_cosine_scores_workspace_bytes(int n, int m) { return (n > 0 && m > 0) ? (size_t)(n + m) * sizeof(float) : 0; }
+int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, float* scores, void* workspace, size_t workspace_bytes,
+                         void* stream) {
     LS_REQUIRE(n > 0 && m > 0 && D > 0, "cosine_scores: empty problem");
-    // inverse norms are staged behind the score matrix tail: scores buffer must hold n*m + n + m floats? no:
-    // keep the ABI simple -- use a small library-owned scratch per call via hipMallocAsync on the stream.
-    float* scratch = nullptr;
-    LS_HIP_CHECK(hipMallocAsync((void**)&scratch, (size_t)(n + m) * sizeof(float), (hipStream_t)stream));
-    int rc = cosine_scores_launch(m0, m1, n, m, D, scratch, scores, (hipStream_t)stream);
-    LS_HIP_CHECK(hipFreeAsync(scratch, (hipStream_t)stream));
-    return rc;
+    LS_REQUIRE(m0 && m1 && scores, "cosine_scores: null argument");
+    if (!workspace || workspace_bytes < ls_cosine_scores_workspace_bytes(n, m)) {   // the n + m inverse row norms
+        set_error("cosine_scores: workspace %zu < required %zu", workspace_bytes, ls_cosine_scores_workspace_bytes(n, m));
+        return LS_ERR_WORKSPACE;
+    }
+    return cosine_scores_launch(m0, m1, n, m, D, (float*)workspace, scores, (hipStream_t)stream);
 }
 int ls_greedy_match_f32(float* scores, int n, int m, int64_t* matches0, int64_t* matches1, void* stream) {
     LS_REQUIRE(n > 0 && m > 0, "greedy_match: empty problem");
     return greedy_match_launch(scores, n, m, (long long*)matches0, (long long*)matches1, (hipStream_t)stream);
 }
-int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, float* R, float* t, float* res,
-                          int32_t* flags_out, void* stream) {
+int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, unsigned flags, float* R, float* t,
+                          float* res, int32_t* flags_out, void* stream) {
     LS_REQUIRE(b > 0 && n > 0, "kabsch: empty problem");
-    return kabsch_launch(x1, x2, weights, b, n, 0, R, t, res, nullptr, flags_out, (hipStream_t)stream);
+    LS_REQUIRE(x1 && x2 && R && t, "kabsch: null argument");
+    return kabsch_launch(x1, x2, weights, b, n, 0, (flags & LS_FLAG_KABSCH_RAW_WEIGHTS) ? 1 : 0, R, t, res, nullptr, flags_out,
+                         (hipStream_t)stream);
 }
 int ls_kabsch_residual_matrix_f32(const float* src, const float* tgt, int n, int m, int P, float* res, void* stream) {
     LS_REQUIRE(n > 0 && m > 0 && P > 0, "kabsch_residual_matrix: empty problem");
-    return kabsch_launch(src, tgt, nullptr, n * m, P, m, nullptr, nullptr, nullptr, res, nullptr, (hipStream_t)stream);
+    return kabsch_launch(src, tgt, nullptr, n * m, P, m, 0, nullptr, nullptr, nullptr, res, nullptr, (hipStream_t)stream);
 }
 size_t ls_icp_workspace_bytes(int b, int n) { return icp_workspace_bytes(b, n); }
 int ls_icp_f32(const float* X, const float* Y, const float* R0, const float* T0, int b, int n, int m, int max_iter,
@@ -283,6 +376,8 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     ls_model* m = new ls_model();
     m->d = *desc;
     if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_DEBUG_LAYERS")) m->debug_layers = atoi(ev);
+    if (const char* ev = getenv("LS_FPS_SIDE")) m->fps_side = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_SEEDS")) m->seed_knn = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_HINTS")) m->hint_policy = !strcmp(ev, "prev") ? 1 : (!strcmp(ev, "auto") ? 2 : 0);
     if (const char* ev = getenv("LS_SDF_BF16X2")) m->sdf_bf16x2 = atoi(ev) != 0;
@@ -355,20 +450,23 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     if (rc != LS_OK) return rc;
 
     // ---- FPS chain on the side stream: depends on xyz only, overlaps with layers 0..first down-sample
+    hipStream_t fs = m->fps_side ? m->side : st;
     if (p.nlevels > 0) {
-        LS_HIP_CHECK(hipEventRecord(m->ev_fork, st));
-        LS_HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        if (m->fps_side) {
+            LS_HIP_CHECK(hipEventRecord(m->ev_fork, st));
+            LS_HIP_CHECK(hipStreamWaitEvent(fs, m->ev_fork, 0));
+        }
         size_t toff = 0;
         for (int l = 0; l < p.nlevels; ++l) {
             int32_t* idx = trace_fps ? trace_fps + toff : I(p.o_fps[l + 1]);
             toff += (size_t)B * p.levelN[l + 1];
             {
-                PROF(LS_K_FPS, l, m->side);
-                rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), m->side);
+                PROF(LS_K_FPS, l, fs);
+                rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), fs);
             }
             if (rc != LS_OK) return rc;
         }
-        LS_HIP_CHECK(hipEventRecord(m->ev_join, m->side));
+        if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_join, fs));
     }
 
     float* cur = F(p.o_fA);
@@ -380,10 +478,20 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     const int32_t* prev_knn = nullptr;
     const int32_t* prev_rows = nullptr;   // the previous layer's FPS selection (rows of its source set), if it down-sampled
     for (int i = 0; i < p.L; ++i) {
+        if (i == m->debug_layers) {
+            static bool printed = false;
+            if (!printed) {
+                printed = true;
+                fprintf(stderr, "LS_PLAN knn=%zu knn2=%zu knns=%zu hint=%zu inv=%zu fA=%zu fB=%zu msg=%zu T=%zu TG=%zu g=%zu G=%zu Tc=%zu gws=%zu total=%zu\n",
+                        p.o_knn, p.o_knn2, p.o_knns, p.o_hint, p.o_inv, p.o_fA, p.o_fB, p.o_msg, p.o_T, p.o_TG, p.o_g, p.o_G, p.o_Tc, p.o_gws, p.total);
+            }
+            if (p.nlevels > 0 && !joined && m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
+            return LS_OK;
+        }
         const int Ns = p.Ns[i], Nd = p.Nd[i], Co = p.Co[i];
         const int32_t* dst_rows = nullptr;
         if (p.level[i] >= 0) {
-            if (!joined) { LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0)); joined = true; }
+            if (!joined) { if (m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0)); joined = true; }
             dst_rows = trace_fps ? trace_fps + fps_off : I(p.o_fps[p.level[i] + 1]);
             fps_off += (size_t)B * Nd;
         }
@@ -399,10 +507,7 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
             { PROF(LS_K_EDGE_L0, i, st); rc = edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
         } else {
-            const int Cin = p.Cin[i], nc = p.ncols[i];
-            const int pc = (attn ? 4 : 2) * Co, qc = nc - pc;  // neighbour-side / destination-side column counts
-            const float* Tq;
-            int ldp, ldq, NQ, qvr;
+            const int Cin = p.Cin[i];
             // fork: the table GEMM(s) depend only on the layer input, like the k-NN -> run them on side2 (matrix cores /
             // HBM writes) concurrently with the VALU-bound k-NN on the caller's stream; join before the edge kernel.
             hipStream_t gs = m->overlap_gemm ? m->side2 : st;
@@ -410,20 +515,8 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
                 LS_HIP_CHECK(hipEventRecord(m->ev_feat[i], st));
                 LS_HIP_CHECK(hipStreamWaitEvent(gs, m->ev_feat[i], 0));
             }
-            if (dst_rows) {
-                // down-sampled layer: P table on all source points, Q table only on the FPS-selected destination points
-                float* Tq_w = T + (size_t)B * Ns * 3 * pc;
-                PROF(LS_K_GEMM_EDGE, i, gs);
-                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
-                if (rc == LS_OK)
-                    rc = gemm_dispatch_gather(cur, Cin, W + d.off_edge[i] + (size_t)pc * Cin, Cin, nullptr, Tq_w, qc, B * Nd * 3, qc, Cin,
-                                              0, dst_rows, Nd, Ns, gs);
-                Tq = Tq_w; ldp = pc; ldq = qc; NQ = Nd; qvr = 0;
-            } else {
-                PROF(LS_K_GEMM_EDGE, i, gs);
-                rc = gemm_dispatch(cur, Cin, W + d.off_edge[i], Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, gs);
-                Tq = T + pc; ldp = nc; ldq = nc; NQ = Ns; qvr = 1;
-            }
+            EdgeTables et;
+            rc = edge_tables(m, i, cur, dst_rows, B, Ns, Nd, T, gs, et);
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
             { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
@@ -444,42 +537,118 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
                 rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
-            if (attn) { PROF(LS_K_EDGE_ATTN, i, st); rc = edge_attn_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, mp, st); }
-            else { PROF(LS_K_EDGE_POOL, i, st); rc = edge_pool_launch(T, ldp, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, mp, st); }
+            rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st);
             if (rc != LS_OK) return rc;
         }
         if (glob) {
-            float* g = F(p.o_g);
-            float* G = F(p.o_G);
-            float* TG = F(p.o_TG);
-            const float* Wg = W + d.off_glob[i];
-            { PROF(LS_K_MEAN, i, st); rc = mean_points_launch(msg, B, Nd, Co, g, st); }
-            if (rc != LS_OK) return rc;
-            {
-                PROF(LS_K_GEMM_GLOB, i, st);
-                rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, F(p.o_gws), st);
-                if (rc == LS_OK) rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, F(p.o_gws), st);
-            }
-            if (rc != LS_OK) return rc;
-            { PROF(LS_K_VN_ACT, i, st); rc = vn_act_rows_launch(TG, 2 * Co, G, 4 * Co, B, Nd, Co, d.neg_slope, nxt, st); }
+            rc = global_conv(m, i, msg, B, Nd, F(p.o_g), F(p.o_G), F(p.o_TG), F(p.o_gws), nxt, st);
             if (rc != LS_OK) return rc;
         }
         std::swap(cur, nxt);
         prev_knn = knn;
         prev_rows = dst_rows;
     }
-    if (p.nlevels > 0 && !joined) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
+    if (p.nlevels > 0 && !joined && m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
 
     // ---- tail
-    const int Cl = p.Co[p.L - 1];
-    float* Tc = F(p.o_Tc);
-    { PROF(LS_K_GEMM_TAIL, 0, st); rc = gemm_dispatch_ws(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, p.Cdp, B * p.NP * 3, p.Cdp, Cl, 0, F(p.o_gws), st); }
+    return encoder_tail(m, cur, B, p.NP, F(p.o_Tc), F(p.o_gws), pre_normalised ? nullptr : centroid, pre_normalised ? nullptr : scale0,
+                        z_so3, z_inv, s_out, t_out, st);
+}
+
+// ------------------------------------------------------------------------------------------------ per-operator exports
+static int check_layer(const ls_model_t* m, int layer, bool want_attn, const char* who) {
+    LS_REQUIRE(m, "%s: null model", who);
+    LS_REQUIRE(layer >= 0 && layer < m->d.num_layers, "%s: layer %d out of range", who, layer);
+    LS_REQUIRE((layer >= m->d.atten_start_layer) == want_attn, "%s: layer %d is %s layer", who, layer, want_attn ? "a mean-pool" : "an attention");
+    return LS_OK;
+}
+size_t ls_vn_edgeconv_workspace_bytes(const ls_model_t* m, int layer, int B, int Ns, int Nd, int has_dst_rows) {
+    if (!m || layer < 0 || layer >= m->d.num_layers || B <= 0) return 0;
+    return align_up(edge_table_floats(m->d, layer, B, Ns, Nd, has_dst_rows != 0) * sizeof(float) + 16, 256);
+}
+static int edgeconv_export(ls_model_t* m, int layer, const float* src_f, const int32_t* knn, const int32_t* dst_rows, int B, int Ns, int Nd,
+                           float* out, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+    LS_REQUIRE(src_f && knn && out, "%s: null argument", who);
+    LS_REQUIRE(B > 0 && Ns >= m->d.num_knn && Nd > 0 && (dst_rows || Nd == Ns), "%s: bad sizes (B=%d Ns=%d Nd=%d)", who, B, Ns, Nd);
+    LS_REQUIRE(m->d.num_knn == 16, "%s: num_knn=%d unsupported (16)", who, m->d.num_knn);
+    if (layer == 0) {
+        LS_REQUIRE(!dst_rows, "%s: layer 0 does not down-sample", who);
+        PROF(LS_K_EDGE_L0, 0, st);
+        return edge_l0_launch(src_f, knn, m->blob + m->d.off_l0, B, Ns, m->d.feat_dim[0], m->d.neg_slope, out, st);
+    }
+    const size_t need = ls_vn_edgeconv_workspace_bytes(m, layer, B, Ns, Nd, dst_rows != nullptr);
+    if (!workspace || workspace_bytes < need) { set_error("%s: workspace %zu < required %zu", who, workspace_bytes, need); return LS_ERR_WORKSPACE; }
+    EdgeTables et;
+    int rc = LS_OK;
+    const char* dbg = getenv("LS_DEBUG_EDGE");   // race hunting: "notab" = tables already in the workspace, "tabonly" = stop after them
+    if (dbg && !strcmp(dbg, "notab")) {
+        const int nc = layer_ncols(m->d, layer), pc = layer_pcols(m->d, layer);
+        float* T = (float*)workspace;
+        et = dst_rows ? EdgeTables{T + (size_t)B * Ns * 3 * pc, pc, nc - pc, Nd, 0} : EdgeTables{T + pc, nc, nc, Ns, 1};
+    } else {
+        rc = edge_tables(m, layer, src_f, dst_rows, B, Ns, Nd, (float*)workspace, st, et);
+    }
     if (rc != LS_OK) return rc;
-    PROF(LS_K_TAIL, 0, st);
-    rc = tail_launch(Tc, p.Cdp, B, p.NP, d.c_dim, W + d.off_inv_t, W + d.off_c_fc0_t, W + d.off_c_misc, d.neg_slope,
-                     d.scale_factor, d.center_pred, d.center_pred_scale, pre_normalised ? nullptr : centroid,
-                     pre_normalised ? nullptr : scale0, z_so3, z_inv, s_out, t_out, st);
-    return rc;
+    if (dbg && !strcmp(dbg, "tabonly")) return LS_OK;
+    return edge_apply(m, layer, (const float*)workspace, et, knn, dst_rows, B, Nd, Ns, out, st);
+}
+int ls_vn_edgeconv_pool_f32(ls_model_t* m, int layer, const float* src_f, const int32_t* knn, const int32_t* dst_rows, int B, int Ns, int Nd,
+                            float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_layer(m, layer, false, "vn_edgeconv_pool");
+    if (rc != LS_OK) return rc;
+    return edgeconv_export(m, layer, src_f, knn, dst_rows, B, Ns, Nd, out, workspace, workspace_bytes, (hipStream_t)stream, "vn_edgeconv_pool");
+}
+int ls_vn_edgeconv_attn_f32(ls_model_t* m, int layer, const float* src_f, const int32_t* knn, const int32_t* dst_rows, int B, int Ns, int Nd,
+                            float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_layer(m, layer, true, "vn_edgeconv_attn");
+    if (rc != LS_OK) return rc;
+    return edgeconv_export(m, layer, src_f, knn, dst_rows, B, Ns, Nd, out, workspace, workspace_bytes, (hipStream_t)stream, "vn_edgeconv_attn");
+}
+
+struct LnaPlan { size_t o_g, o_G, o_TG, o_gws, total; };
+static LnaPlan lna_plan(const ls_model_desc& d, int layer, int B, int N) {
+    const size_t Co = (size_t)d.feat_dim[layer];
+    LnaPlan q{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    q.o_g = take((size_t)B * 3 * Co * 4);
+    q.o_G = take((size_t)B * 3 * 4 * Co * 4);
+    q.o_TG = take((size_t)B * N * 3 * 2 * Co * 4);
+    q.o_gws = take(global_conv_gws_floats(d, layer, B, N) * 4 + 256);
+    q.total = off;
+    return q;
+}
+size_t ls_vn_lna_workspace_bytes(const ls_model_t* m, int layer, int B, int N) {
+    if (!m || layer < m->d.res_global_start_layer || layer >= m->d.num_layers || B <= 0 || N <= 0) return 0;
+    return lna_plan(m->d, layer, B, N).total;
+}
+int ls_vn_lna_f32(ls_model_t* m, int layer, const float* f, int B, int N, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    LS_REQUIRE(m && f && out && workspace, "vn_lna: null argument");
+    LS_REQUIRE(layer >= m->d.res_global_start_layer && layer < m->d.num_layers, "vn_lna: layer %d has no residual global conv", layer);
+    LS_REQUIRE(B > 0 && N > 0, "vn_lna: empty problem");
+    const LnaPlan q = lna_plan(m->d, layer, B, N);
+    if (workspace_bytes < q.total) { set_error("vn_lna: workspace %zu < required %zu", workspace_bytes, q.total); return LS_ERR_WORKSPACE; }
+    char* ws = (char*)workspace;
+    return global_conv(m, layer, f, B, N, (float*)(ws + q.o_g), (float*)(ws + q.o_G), (float*)(ws + q.o_TG), (float*)(ws + q.o_gws), out,
+                       (hipStream_t)stream);
+}
+
+size_t ls_encoder_tail_workspace_bytes(const ls_model_t* m, int B, int NP) {
+    if (!m || B <= 0 || NP <= 0) return 0;
+    const int Cl = m->d.feat_dim[m->d.num_layers - 1], Cdp = (int)align_up((size_t)m->d.c_dim + 1, 4);
+    return align_up((size_t)B * NP * 3 * Cdp * 4, 256) + gemm_scratch_floats(B * NP * 3, Cdp, Cl) * 4 + 256;
+}
+int ls_encoder_tail_f32(ls_model_t* m, const float* f, const float* centroid, const float* scale0, int B, int NP, float* z_so3, float* z_inv,
+                        float* s, float* t, void* workspace, size_t workspace_bytes, void* stream) {
+    LS_REQUIRE(m && f && z_so3 && z_inv && s && t && workspace, "encoder_tail: null argument");
+    LS_REQUIRE(B > 0 && NP > 0, "encoder_tail: empty problem");
+    LS_REQUIRE((centroid == nullptr) == (scale0 == nullptr), "encoder_tail: centroid and scale0 go together");
+    const size_t need = ls_encoder_tail_workspace_bytes(m, B, NP);
+    if (workspace_bytes < need) { set_error("encoder_tail: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
+    const int Cdp = (int)align_up((size_t)m->d.c_dim + 1, 4);
+    float* Tc = (float*)workspace;
+    float* gws = (float*)((char*)workspace + align_up((size_t)B * NP * 3 * Cdp * 4, 256));
+    return encoder_tail(m, f, B, NP, Tc, gws, centroid, scale0, z_so3, z_inv, s, t, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ SDF decode

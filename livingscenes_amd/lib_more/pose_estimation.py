@@ -10,16 +10,26 @@ from ..lib_math.torch_se3 import inverse, transform
 
 def kabsch_transformation_estimation(x1, x2, weights=None, normalize_w=True, eps=1e-7, best_k=0, w_threshold=0):
     """pose_estimation.py:29-102.  x1,x2 [b,n,3] (+ weights [b,n]) -> R [b,3,3], t [b,3,1], residuals [b,n], flag.
-    flag mirrors the reference: True iff the SVD branch failed (here: a rank-deficient covariance in any problem)."""
-    if not normalize_w or eps != 1e-7:
-        raise NotImplementedError("only normalize_w=True, eps=1e-7 (the reference's only call pattern) is implemented")
-    if best_k > 0:
-        idx = torch.topk(weights[0], best_k).indices  # the reference's argpartition of batch item 0 (:59-63)
-        weights, x1, x2 = weights[:, idx], x1[:, idx], x2[:, idx]
-    if w_threshold > 0:
-        weights = torch.where(weights / (weights.sum(1, keepdim=True) + eps) < w_threshold, torch.zeros_like(weights), weights)
-    R, t, res, flags = ops.kabsch(x1, x2, weights, return_flags=True)
-    return R, t, res, flags.any()  # 0-dim bool tensor: truthy like the reference's flag, no host sync unless inspected
+    The default call pattern (weights None or given, no best_k / w_threshold) is one kernel launch.  The non-default paths
+    prepare the weights exactly as :49-66 do -- ones when None, divide by (sum + eps), best_k selection by batch item 0's
+    weights, zeroing of NORMALISED weights below w_threshold without renormalising -- and hand them to the kernel as final.
+    flag mirrors the reference: True iff its SVD branch would have failed (non-finite covariance); rank-deficient covariances
+    return a valid least-squares rotation with flag False, like torch.svd."""
+    if eps != 1e-7:
+        raise NotImplementedError("eps != 1e-7 is not used by the reference's call sites")
+    raw = (not normalize_w) or best_k > 0 or w_threshold > 0
+    if raw:
+        if weights is None:
+            weights = torch.ones(x1.shape[0], x1.shape[1], dtype=x1.dtype, device=x1.device)   # :49-50
+        if normalize_w:
+            weights = weights / (weights.sum(1, keepdim=True) + eps)                            # :52-54
+        if best_k > 0:   # :58-62 (np.argpartition of batch item 0; the SET of the best_k largest, order is irrelevant to Kabsch)
+            idx = torch.topk(weights[0], best_k).indices.sort().values
+            weights, x1, x2 = weights[:, idx], x1[:, idx], x2[:, idx]
+        if w_threshold > 0:                                                                     # :64-65
+            weights = torch.where(weights < w_threshold, torch.zeros_like(weights), weights)
+    R, t, res, status = ops.kabsch(x1, x2, weights, return_flags=True, raw_weights=raw)
+    return R, t, res, (status == 3).any()  # 0-dim bool tensor: truthy like the reference's flag, no host sync unless inspected
 
 
 def transformation_residuals(x1, x2, R, t):

@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import check, load, ptr, stream_ptr
+from ._lib import call, check, load, ptr, stream_ptr
 
 
 class MISE:
@@ -37,12 +37,12 @@ class MISE:
         """Back to the initial lattice (the buffers are kept: a pool of MISE objects serves many instances)."""
         if threshold is not None:
             self.threshold = float(threshold)
-        check(load().ls_mise_init(ptr(self._state), self._state.numel(), self.resolution_0, self.depth, stream_ptr(self.device)), "ls_mise_init")
+        call(self.device, "ls_mise_init", ptr(self._state), self._state.numel(), self.resolution_0, self.depth, stream_ptr(self.device))
 
     def query_device(self, box_size=1.0):
         """-> (idx [n] int32 lattice indices, pts [n,3] float32 = box_size * (p / resolution - 0.5)), device tensors (views)."""
-        check(load().ls_mise_query(ptr(self._state), self.resolution_0, self.depth, float(box_size), ptr(self._idx), ptr(self._pts),
-                                   self._cap, ptr(self._count), stream_ptr(self.device)), "ls_mise_query")
+        call(self.device, "ls_mise_query", ptr(self._state), self.resolution_0, self.depth, float(box_size), ptr(self._idx), ptr(self._pts),
+                                   self._cap, ptr(self._count), stream_ptr(self.device))
         n = int(self._count.item())   # the only host round trip of a round
         return self._idx[:n], self._pts[:n]
 
@@ -50,8 +50,8 @@ class MISE:
         values = values.to(torch.float32).contiguous()
         idx = idx.to(torch.int32).contiguous()
         assert idx.shape[0] == values.shape[0]
-        check(load().ls_mise_update(ptr(self._state), self.resolution_0, self.depth, ctypes.c_double(self.threshold), ptr(idx),
-                                    ptr(values), int(idx.shape[0]), stream_ptr(self.device)), "ls_mise_update")
+        call(self.device, "ls_mise_update", ptr(self._state), self.resolution_0, self.depth, ctypes.c_double(self.threshold), ptr(idx),
+                                    ptr(values), int(idx.shape[0]), stream_ptr(self.device))
 
     # ---- the reference's host-side surface (mise.pyx:87-165)
     def query(self):
@@ -69,7 +69,7 @@ class MISE:
     def to_dense_device(self):
         G = self.resolution + 1
         out = torch.empty(G, G, G, dtype=torch.float32, device=self.device)
-        check(load().ls_mise_to_dense(ptr(self._state), self.resolution_0, self.depth, ptr(out), stream_ptr(self.device)), "ls_mise_to_dense")
+        call(self.device, "ls_mise_to_dense", ptr(self._state), self.resolution_0, self.depth, ptr(out), stream_ptr(self.device))
         return out
 
     def to_dense(self):
@@ -147,8 +147,8 @@ class Generator3D:
             # launch every query first, read all counts back in one copy
             for b in active:
                 m = mises[b]
-                check(load().ls_mise_query(ptr(m._state), m.resolution_0, m.depth, float(box_size), ptr(m._idx), ptr(m._pts), m._cap,
-                                           ptr(m._count), stream_ptr(m.device)), "ls_mise_query")
+                call(m.device, "ls_mise_query", ptr(m._state), m.resolution_0, m.depth, float(box_size), ptr(m._idx), ptr(m._pts), m._cap,
+                                           ptr(m._count), stream_ptr(m.device))
             counts = torch.cat([mises[b]._count for b in active]).cpu().tolist()
             live = [(b, n) for b, n in zip(active, counts) if n > 0]
             if not live:
@@ -208,13 +208,12 @@ def marching_cubes(volume, isovalue):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
     args = (ptr(vol), nx, ny, nz, ctypes.c_double(iso))
-    check(load().ls_marching_cubes_f64(*args, None, 0, None, 0, ptr(counts), ptr(ws), ws_bytes, stream_ptr(dev)), "ls_marching_cubes_f64")
+    call(dev, "ls_marching_cubes_f64", *args, None, 0, None, 0, ptr(counts), ptr(ws), ws_bytes, stream_ptr(dev))
     nv, nf = (int(v) for v in counts.cpu())
     verts = torch.empty(nv, 3, dtype=torch.float64, device=dev)
     faces = torch.empty(nf, 3, dtype=torch.int64, device=dev)
     if nv:
-        check(load().ls_marching_cubes_f64(*args, ptr(verts), nv, ptr(faces), nf, ptr(counts), ptr(ws), ws_bytes, stream_ptr(dev)),
-              "ls_marching_cubes_f64")
+        call(dev, "ls_marching_cubes_f64", *args, ptr(verts), nv, ptr(faces), nf, ptr(counts), ptr(ws), ws_bytes, stream_ptr(dev))
     return verts, faces
 
 

@@ -5,13 +5,18 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, load, ptr, stream_ptr
+from ._lib import call, check, load, ptr, stream_ptr
 
 DEFAULT_FLAGS = 0  # canonical arithmetic: separately rounded multiply/add (oracle contract=0)
 
 
 def _f32(t):
     return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+def _scratch(nbytes, device):
+    """Caller-owned scratch for one operator call (torch's caching allocator: stream-ordered reuse, no hipMalloc per call)."""
+    return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
 
 
 def knn(dst, src, K=16, dst_rows=None, flags=DEFAULT_FLAGS, return_dist=False, seeds=None):
@@ -26,8 +31,9 @@ def knn(dst, src, K=16, dst_rows=None, flags=DEFAULT_FLAGS, return_dist=False, s
     if seeds is not None:
         seeds = seeds.to(torch.int32).contiguous()
         assert seeds.shape == (B, Nd, 16)
-    check(load().ls_knn_f32(ptr(dst), ptr(src), ptr(dst_rows), ptr(seeds), B, Nd, dst_n, Ns, C, K, flags, ptr(idx), ptr(dist),
-                            stream_ptr(src.device)), "ls_knn_f32")
+    ws = _scratch(load().ls_knn_workspace_bytes(B, Nd, dst_n, Ns, C, int(seeds is not None), flags), src.device)
+    call(src.device, "ls_knn_f32", ptr(dst), ptr(src), ptr(dst_rows), ptr(seeds), B, Nd, dst_n, Ns, C, K, flags, ptr(idx), ptr(dist),
+                            ptr(ws), 0 if ws is None else ws.numel(), stream_ptr(src.device))
     return (idx, dist) if return_dist else idx
 
 
@@ -39,7 +45,7 @@ def fps(pts, K, lengths=None, flags=DEFAULT_FLAGS, return_points=False):
     out = torch.empty(B, K, 3, dtype=torch.float32, device=pts.device) if return_points else None
     if lengths is not None:
         lengths = lengths.to(device=pts.device, dtype=torch.int32).contiguous()
-    check(load().ls_fps_f32(ptr(pts), ptr(lengths), B, N, K, flags, ptr(idx), ptr(out), stream_ptr(pts.device)), "ls_fps_f32")
+    call(pts.device, "ls_fps_f32", ptr(pts), ptr(lengths), B, N, K, flags, ptr(idx), ptr(out), stream_ptr(pts.device))
     return (idx, out) if return_points else idx
 
 
@@ -49,7 +55,9 @@ def gemm(A, W, bias=None, relu=False):
     M, K = A.shape
     N = W.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    check(load().ls_gemm_f32(ptr(A), K, ptr(W), K, ptr(bias), ptr(out), N, M, N, K, int(relu), stream_ptr(A.device)), "ls_gemm_f32")
+    ws = _scratch(load().ls_gemm_workspace_bytes(M, N, K), A.device)
+    call(A.device, "ls_gemm_f32", ptr(A), K, ptr(W), K, ptr(bias), ptr(out), N, M, N, K, int(relu), ptr(ws), 0 if ws is None else ws.numel(),
+                             stream_ptr(A.device))
     return out
 
 
@@ -60,7 +68,7 @@ def encode_prologue(x):
     pts = torch.empty(B, N, 3, dtype=torch.float32, device=x.device)
     cen = torch.empty(B, 3, dtype=torch.float32, device=x.device)
     sc = torch.empty(B, dtype=torch.float32, device=x.device)
-    check(load().ls_encode_prologue_f32(ptr(x), B, N, ptr(pts), ptr(cen), ptr(sc), stream_ptr(x.device)), "ls_encode_prologue_f32")
+    call(x.device, "ls_encode_prologue_f32", ptr(x), B, N, ptr(pts), ptr(cen), ptr(sc), stream_ptr(x.device))
     return pts, cen, sc
 
 
@@ -69,7 +77,8 @@ def cosine_scores(m0, m1):
     n, D = m0.shape
     m = m1.shape[0]
     S = torch.empty(n, m, dtype=torch.float32, device=m0.device)
-    check(load().ls_cosine_scores_f32(ptr(m0), ptr(m1), n, m, D, ptr(S), stream_ptr(m0.device)), "ls_cosine_scores_f32")
+    ws = _scratch(load().ls_cosine_scores_workspace_bytes(n, m), m0.device)
+    call(m0.device, "ls_cosine_scores_f32", ptr(m0), ptr(m1), n, m, D, ptr(S), ptr(ws), ws.numel(), stream_ptr(m0.device))
     return S
 
 
@@ -79,12 +88,13 @@ def greedy_match(scores):
     n, m = S.shape
     m0 = torch.empty(n, dtype=torch.int64, device=S.device)
     m1 = torch.empty(m, dtype=torch.int64, device=S.device)
-    check(load().ls_greedy_match_f32(ptr(S), n, m, ptr(m0), ptr(m1), stream_ptr(S.device)), "ls_greedy_match_f32")
+    call(S.device, "ls_greedy_match_f32", ptr(S), n, m, ptr(m0), ptr(m1), stream_ptr(S.device))
     return m0, m1
 
 
-def kabsch(x1, x2, weights=None, return_flags=False):
-    """x1,x2 [b,n,3] -> R [b,3,3], t [b,3,1], res [b,n] (, flags [b] int32)."""
+def kabsch(x1, x2, weights=None, return_flags=False, raw_weights=False):
+    """x1,x2 [b,n,3] -> R [b,3,3], t [b,3,1], res [b,n] (, status [b] int32: _lib.KABSCH_*).  raw_weights: use `weights` as
+    they are instead of normalising them (pose_estimation.py:52-54)."""
     x1, x2 = _f32(x1), _f32(x2)
     b, n, _ = x1.shape
     if weights is not None:
@@ -93,8 +103,9 @@ def kabsch(x1, x2, weights=None, return_flags=False):
     t = torch.empty(b, 3, dtype=torch.float32, device=x1.device)
     res = torch.empty(b, n, dtype=torch.float32, device=x1.device)
     fl = torch.empty(b, dtype=torch.int32, device=x1.device)
-    check(load().ls_kabsch_batched_f32(ptr(x1), ptr(x2), ptr(weights), b, n, ptr(R), ptr(t), ptr(res), ptr(fl),
-                                       stream_ptr(x1.device)), "ls_kabsch_batched_f32")
+    call(x1.device, "ls_kabsch_batched_f32", ptr(x1), ptr(x2), ptr(weights), b, n, _lib.FLAG_KABSCH_RAW_WEIGHTS if raw_weights else 0,
+                                       ptr(R), ptr(t), ptr(res), ptr(fl),
+                                       stream_ptr(x1.device))
     return (R, t.unsqueeze(2), res, fl) if return_flags else (R, t.unsqueeze(2), res)
 
 
@@ -104,8 +115,7 @@ def kabsch_residual_matrix(src, tgt):
     n, P, _ = src.shape
     m = tgt.shape[0]
     res = torch.empty(n, m, dtype=torch.float32, device=src.device)
-    check(load().ls_kabsch_residual_matrix_f32(ptr(src), ptr(tgt), n, m, P, ptr(res), stream_ptr(src.device)),
-          "ls_kabsch_residual_matrix_f32")
+    call(src.device, "ls_kabsch_residual_matrix_f32", ptr(src), ptr(tgt), n, m, P, ptr(res), stream_ptr(src.device))
     return res
 
 
@@ -119,8 +129,8 @@ def icp(X, Y, R0, T0, max_iter=100, rel_rmse_thr=1e-6, flags=DEFAULT_FLAGS):
     rmse = torch.empty(b, dtype=torch.float32, device=X.device)
     iters = torch.empty(b, dtype=torch.int32, device=X.device)
     ws = torch.empty(load().ls_icp_workspace_bytes(b, n), dtype=torch.uint8, device=X.device)
-    check(load().ls_icp_f32(ptr(X), ptr(Y), ptr(R0), ptr(T0), b, n, m, max_iter, rel_rmse_thr, flags, ptr(R), ptr(T),
-                            ptr(rmse), ptr(iters), ptr(ws), ws.numel(), stream_ptr(X.device)), "ls_icp_f32")
+    call(X.device, "ls_icp_f32", ptr(X), ptr(Y), ptr(R0), ptr(T0), b, n, m, max_iter, rel_rmse_thr, flags, ptr(R), ptr(T),
+                            ptr(rmse), ptr(iters), ptr(ws), ws.numel(), stream_ptr(X.device))
     return R, T, rmse, iters
 
 
@@ -133,7 +143,7 @@ class HipModel:
             raise _lib.LsError("HipModel needs a HIP device: the MI355X path has no CPU fallback")
         self.desc = desc
         self._h = ctypes.c_void_p()
-        self._ws = None
+        self._ws = {}
         with torch.cuda.device(self.device):
             check(load().ls_model_create(ctypes.byref(desc), blob.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self._h)),
                   "ls_model_create")
@@ -150,9 +160,12 @@ class HipModel:
             pass
 
     def _workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Grow-only scratch, one buffer per STREAM the handle is used on (two streams driving one handle must not share it)."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
 
     def profile_begin(self):
         check(load().ls_profile_begin(self._h), "ls_profile_begin")
@@ -195,9 +208,8 @@ class HipModel:
         if trace:
             tk = torch.empty(B * sum(nds) * 16, dtype=torch.int32, device=dev)
             tf = torch.empty(max(1, B * sum(fps_n)), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            check(load().ls_encode(self._h, ptr(x), B, N, int(pre_normalised), flags, ptr(z_so3), ptr(z_inv), ptr(s), ptr(t),
-                                   ptr(tk), ptr(tf), ptr(ws), ws.numel(), stream_ptr(dev)), "ls_encode")
+        call(dev, "ls_encode", self._h, ptr(x), B, N, int(pre_normalised), flags, ptr(z_so3), ptr(z_inv), ptr(s), ptr(t),
+                               ptr(tk), ptr(tf), ptr(ws), ws.numel(), stream_ptr(dev))
         if not trace:
             return z_so3, z_inv, s, t
         knn_l, fps_l, o = [], [], 0
@@ -209,6 +221,47 @@ class HipModel:
             fps_l.append(tf[o:o + B * nf].view(B, nf))
             o += B * nf
         return z_so3, z_inv, s, t, knn_l, fps_l
+
+    # ---- the encoder's layer operators on their own (same code path as ls_encode)
+    def edgeconv(self, layer, src_f, knn, dst_rows=None, _ws=None):
+        """Edge-conv layer `layer` without its residual global conv: src_f [B,Ns,3,C_in] (layer 0: cloud [B,Ns,3]), knn [B,Nd,16]
+        int32, dst_rows [B,Nd] int32 or None -> [B,Nd,3,C_out]."""
+        src_f = _f32(src_f)
+        knn = knn.to(torch.int32).contiguous()
+        B, Ns = src_f.shape[0], src_f.shape[1]
+        Nd = knn.shape[1]
+        if dst_rows is not None:
+            dst_rows = dst_rows.to(torch.int32).contiguous()
+        Co = int(self.desc.feat_dim[layer])
+        out = torch.empty(B, Nd, 3, Co, dtype=torch.float32, device=src_f.device)
+        ws = _ws if _ws is not None else _scratch(load().ls_vn_edgeconv_workspace_bytes(self._h, layer, B, Ns, Nd, int(dst_rows is not None)), src_f.device)
+        fn = "ls_vn_edgeconv_attn_f32" if layer >= self.desc.atten_start_layer else "ls_vn_edgeconv_pool_f32"
+        call(src_f.device, fn, self._h, layer, ptr(src_f), ptr(knn), ptr(dst_rows), B, Ns, Nd, ptr(out), ptr(ws), 0 if ws is None else ws.numel(),
+             stream_ptr(src_f.device))
+        return out
+
+    def vn_lna_global(self, layer, f):
+        """Residual global conv of `layer`: f [B,N,3,C] -> VecLNA_G(cat(f, mean_n f)) [B,N,3,C]."""
+        f = _f32(f)
+        B, N = f.shape[0], f.shape[1]
+        out = torch.empty_like(f)
+        ws = _scratch(load().ls_vn_lna_workspace_bytes(self._h, layer, B, N), f.device)
+        call(f.device, "ls_vn_lna_f32", self._h, layer, ptr(f), B, N, ptr(out), ptr(ws), ws.numel(), stream_ptr(f.device))
+        return out
+
+    def encoder_tail(self, f, centroid=None, scale0=None):
+        """f [B,NP,3,C_last] -> (z_so3 [B,c,3], z_inv [B,c], s [B], t [B,3])."""
+        f = _f32(f)
+        B, NP = f.shape[0], f.shape[1]
+        C, dev = self.desc.c_dim, f.device
+        z_so3 = torch.empty(B, C, 3, dtype=torch.float32, device=dev)
+        z_inv = torch.empty(B, C, dtype=torch.float32, device=dev)
+        s, t = torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, 3, dtype=torch.float32, device=dev)
+        ws = _scratch(load().ls_encoder_tail_workspace_bytes(self._h, B, NP), dev)
+        call(dev, "ls_encoder_tail_f32", self._h, ptr(f), ptr(None if centroid is None else _f32(centroid)),
+                                         ptr(None if scale0 is None else _f32(scale0)), B, NP, ptr(z_so3), ptr(z_inv), ptr(s), ptr(t),
+                                         ptr(ws), ws.numel(), stream_ptr(dev))
+        return z_so3, z_inv, s, t
 
     def sdf_decode(self, query, z_so3, z_inv, s, t, max_ws_bytes=2 << 30):
         """query [B,M,3] + code -> sdf [B,M]; queries are processed in chunks that keep the workspace bounded."""
@@ -224,9 +277,8 @@ class HipModel:
             out = sdf if mc == M else torch.empty(B, mc, dtype=torch.float32, device=query.device)
             need = load().ls_sdf_workspace_bytes(self._h, B, mc)
             ws = self._workspace(need)
-            with torch.cuda.device(query.device):
-                check(load().ls_sdf_decode(self._h, ptr(q), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, mc, ptr(out), ptr(ws),
-                                           ws.numel(), stream_ptr(query.device)), "ls_sdf_decode")
+            call(query.device, "ls_sdf_decode", self._h, ptr(q), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, mc, ptr(out), ptr(ws),
+                                       ws.numel(), stream_ptr(query.device))
             if mc != M:
                 sdf[:, m0:m0 + mc] = out
         return sdf
@@ -244,9 +296,8 @@ class HipModel:
             q, ri, out = query[r0:r0 + rc], row_inst[r0:r0 + rc], sdf[r0:r0 + rc]
             need = load().ls_sdf_rows_workspace_bytes(self._h, B, rc)
             ws = self._workspace(need)
-            with torch.cuda.device(query.device):
-                check(load().ls_sdf_decode_rows(self._h, ptr(q), ptr(ri), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, rc, ptr(out), ptr(ws),
-                                                ws.numel(), stream_ptr(query.device)), "ls_sdf_decode_rows")
+            call(query.device, "ls_sdf_decode_rows", self._h, ptr(q), ptr(ri), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, rc, ptr(out), ptr(ws),
+                                            ws.numel(), stream_ptr(query.device))
         return sdf
 
     def sdf_decode_train(self, query, z_so3, z_inv, s, t):
@@ -258,9 +309,8 @@ class HipModel:
         sdf = torch.empty(B, M, dtype=torch.float32, device=query.device)
         need = load().ls_sdf_train_workspace_bytes(self._h, B, M)
         ws = torch.empty(need, dtype=torch.uint8, device=query.device)
-        with torch.cuda.device(query.device):
-            check(load().ls_sdf_decode_train(self._h, ptr(query), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, M, ptr(sdf), ptr(ws),
-                                             ws.numel(), stream_ptr(query.device)), "ls_sdf_decode_train")
+        call(query.device, "ls_sdf_decode_train", self._h, ptr(query), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, M, ptr(sdf), ptr(ws),
+                                         ws.numel(), stream_ptr(query.device))
         return sdf, (query, z_so3, z_inv, s, t, sdf, ws)
 
     def sdf_backward(self, saved, grad_sdf, need_query_grad=True):
@@ -272,7 +322,6 @@ class HipModel:
         gq = torch.empty(B, M, 3, dtype=torch.float32, device=dev) if need_query_grad else None
         gso3, ginv = torch.empty_like(z_so3), torch.empty_like(z_inv)
         gs, gt = torch.empty_like(s), torch.empty_like(t)
-        with torch.cuda.device(dev):
-            check(load().ls_sdf_backward(self._h, ptr(query), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, M, ptr(sdf), ptr(g), ptr(ws),
-                                         ws.numel(), ptr(gq), ptr(gso3), ptr(ginv), ptr(gs), ptr(gt), stream_ptr(dev)), "ls_sdf_backward")
+        call(dev, "ls_sdf_backward", self._h, ptr(query), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, M, ptr(sdf), ptr(g), ptr(ws),
+                                     ws.numel(), ptr(gq), ptr(gso3), ptr(ginv), ptr(gs), ptr(gt), stream_ptr(dev))
         return gq, gso3, ginv, gs, gt

@@ -42,8 +42,14 @@ CODE_KEYS = ("z_so3", "z_inv", "s", "t")
 
 def pack_codes(emb):
     """{z_so3 [B,C,3], z_inv [B,C], s [B], t [B,1,3]} -> [B, 4C+4] rows (one message per shard)."""
-    B = emb["z_inv"].shape[0]
-    return torch.cat([emb["z_so3"].reshape(B, -1), emb["z_inv"].reshape(B, -1), emb["s"].reshape(B, 1), emb["t"].reshape(B, 3)], 1).contiguous()
+    B, C = emb["z_inv"].shape      # explicit widths: reshape(B, -1) is ambiguous for an empty shard (B = 0)
+    return torch.cat([emb["z_so3"].reshape(B, 3 * C), emb["z_inv"].reshape(B, C), emb["s"].reshape(B, 1), emb["t"].reshape(B, 3)], 1).contiguous()
+
+
+def empty_codes(c_dim, device, dtype=torch.float32):
+    """The codes of an EMPTY shard (a rank that owns no instance: fewer instances than ranks, common for a small 3RScan
+    scene on an 8-GPU node): zero-row tensors of the right widths, so the rank still takes part in the collectives."""
+    return unpack_codes(torch.zeros(0, 4 * c_dim + 4, device=device, dtype=dtype))
 
 
 def unpack_codes(rows):
@@ -61,7 +67,7 @@ def all_gather_codes(emb, counts=None):
     rows = pack_codes(emb)
     if counts is None:
         counts = [rows.shape[0]] * ws
-    mx = max(counts)
+    mx = max(max(counts), 1)     # at least one (zero) row per message: an all-empty exchange stays a valid collective
     pad = rows.new_zeros(mx, rows.shape[1])
     pad[: rows.shape[0]] = rows
     bufs = [torch.empty_like(pad) for _ in range(ws)]
@@ -77,7 +83,7 @@ def gather_codes(emb, dst=0, counts=None):
     rows = pack_codes(emb)
     if counts is None:
         counts = [rows.shape[0]] * ws
-    mx = max(counts)
+    mx = max(max(counts), 1)
     pad = rows.new_zeros(mx, rows.shape[1])
     pad[: rows.shape[0]] = rows
     bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
@@ -93,6 +99,9 @@ def sharded_encode(model, x_all):
     rank, ws = world()
     n = x_all.shape[0]
     lo, hi = shard_range(n, rank, ws)
-    emb = model.encode(x_all[lo:hi].contiguous())
+    if hi > lo:
+        emb = model.encode(x_all[lo:hi].contiguous())
+    else:   # this rank owns nothing (n < world size): ls_encode rejects B = 0, and skipping the all-gather would deadlock the others
+        emb = empty_codes(model.encoder.c_dim, x_all.device)
     counts = [shard_range(n, r, ws)[1] - shard_range(n, r, ws)[0] for r in range(ws)]
     return all_gather_codes(emb, counts)

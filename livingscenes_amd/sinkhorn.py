@@ -12,7 +12,7 @@ import math
 import numpy as np
 import torch
 
-from ._lib import check, load, ptr, stream_ptr
+from ._lib import call, check, load, ptr, stream_ptr
 
 
 def softmin(eps, x, y, h, need_grad=False):
@@ -20,8 +20,7 @@ def softmin(eps, x, y, h, need_grad=False):
     N, M = x.shape[0], y.shape[0]
     out = torch.empty(N, dtype=torch.float32, device=x.device)
     grad = torch.empty(N, 3, dtype=torch.float32, device=x.device) if need_grad else None
-    check(load().ls_sinkhorn_softmin_f32(ptr(x), ptr(y), ptr(h), N, M, float(eps), ptr(out), ptr(grad), stream_ptr(x.device)),
-          "ls_sinkhorn_softmin_f32")
+    call(x.device, "ls_sinkhorn_softmin_f32", ptr(x), ptr(y), ptr(h), N, M, float(eps), ptr(out), ptr(grad), stream_ptr(x.device))
     return (out, grad) if need_grad else out
 
 

@@ -101,6 +101,7 @@ def main():
 
     # ---------------------------------------------------------------- 1. VN layer known-answer vectors
     g = torch.Generator().manual_seed(1234)
+    torch.manual_seed(4321)   # the modules below draw their initial weights from the GLOBAL generator: seeded -> reproducible fixture
     out = {}
     x = torch.randn(2, 6, 3, 5, 4, generator=g)
     lin = vl.VecLinear(6, 8, mode="so3")
@@ -135,6 +136,51 @@ def main():
     for i, t in enumerate(CAPTURE["fps"]):
         out[f"fps_idx_{i}"] = t.to(torch.int32)
     np.savez_compressed(os.path.join(HERE, "encoder_small.npz"), **t2n(out))
+
+    # ---------------------------------------------------------------- 2b. the same forward, PER LAYER (hooks on the reference's own
+    # modules; nothing is recomputed here): fixture of the isolated operator tests (ls_vn_edgeconv_* / ls_vn_lna_f32 /
+    # ls_encoder_tail_f32).  V_list[i] receives the graph feature y = cat(nbr - ctr, ctr) [B,2C,3,Nd,K] (vec_dgcnn_atten.py:160):
+    # its second channel half at k = 0 is the layer's destination feature; global_conv_list[j] receives cat(msg, mean) and returns
+    # the layer output (:222-225).  Stored in the library's row layout [B,N,3,C].
+    cap = {}
+
+    def rows(f):  # [B,C,3,N] -> [B,N,3,C]
+        return f.permute(0, 3, 2, 1).contiguous()
+    hooks = []
+    ggf, layer_no = net.get_graph_feature, [0]
+
+    def record_graph_inputs(*a, **kw):   # the reference's own method, arguments recorded on the way in (:196-199)
+        cap[f"src_{layer_no[0]}"], cap[f"dst_in_{layer_no[0]}"] = rows(kw["src_f"]), rows(kw["dst_f"])
+        layer_no[0] += 1
+        return ggf(*a, **kw)
+    net.get_graph_feature = record_graph_inputs
+    for j in range(len(net.global_conv_list)):
+        i = j + cfg_s["res_global_start_layer"]
+
+        def pre_g(mod, args, i=i):
+            x_ = args[0]
+            cap[f"msg_{i}"] = rows(x_[:, : x_.shape[1] // 2])
+
+        def post_g(mod, args, outp, i=i):
+            cap[f"out_{i}"] = rows(outp)
+        hooks.append(net.global_conv_list[j].register_forward_pre_hook(pre_g))
+        hooks.append(net.global_conv_list[j].register_forward_hook(post_g))
+    CAPTURE["knn"].clear(), CAPTURE["fps"].clear()
+    with torch.no_grad():
+        center2, scale2, z_so3_2, z_inv_2 = net(xs)
+    for h in hooks:
+        h.remove()
+    del net.get_graph_feature
+    assert torch.equal(z_so3_2, z_so3) and torch.equal(z_inv_2, z_inv)
+    # layers without a global conv hand their message straight to the next layer as its source features
+    # (not stored twice: msg_i == out_i == src_{i+1} for i < res_global_start_layer)
+    layers = {"x": xs, "center": center2, "scale": scale2, "z_so3": z_so3_2, "z_inv": z_inv_2}
+    layers.update(cap)
+    for i, t in enumerate(CAPTURE["knn"]):
+        layers[f"knn_idx_{i}"] = t.to(torch.int32)
+    for i, t in enumerate(CAPTURE["fps"]):
+        layers[f"fps_idx_{i}"] = t.to(torch.int32)
+    np.savez_compressed(os.path.join(HERE, "encoder_small_layers.npz"), **t2n(layers))
 
     # ---------------------------------------------------------------- 3. released config through the UNMODIFIED model_utils.Shape_Prior
     for dotted in ["lib_shape_prior", "lib_shape_prior.core", "lib_shape_prior.core.lib",

@@ -1,0 +1,87 @@
+"""BASELINE configs[1]+[2] at FULL batch, exactly as bench.py runs it: 64 instances x 1024 points (the 32-object scene and its
+rescan, seed 1000), 8 model handles on 8 streams all in flight, GPU_MAX_HW_QUEUES=16.  Kernel dispatch depends on B (candidate
+split heuristics, un-split grids, XCD remap, handles sharing the chip), so the B <= 3 encoder parity cases of
+test_hip_parity.py do not cover this configuration.
+
+Checks (reference: model_utils.py:165-197, lib_more/matcher_new.py:109-139, lib_more/pose_estimation.py:29-102):
+  * 8 instances spread over the batch (rows 0, 9, ..., 63) against oracle.net.shape_prior_encode: z_so3 / z_inv / s / t within
+    1e-4 of max-norm, FPS and layer-0 k-NN indices exact, per-layer k-NN agreement > 99.5 %;
+  * all 8 handles return bit-identical codes, matches and poses (and equal to a later single traced pass);
+  * sequential_matcher assignments BIT-EXACT and Kabsch poses within 1e-4 against oracle.more run on the HIP codes.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from livingscenes_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def fullbatch(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("fullbatch") / "out.npz")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    subprocess.run([sys.executable, os.path.join(REPO, "tests", "tools", "fullbatch_worker.py"), out, "32", "1024", "8"],
+                   check=True, env=env, cwd=REPO, timeout=900)
+    return dict(np.load(out))
+
+
+def test_fullbatch_handles_are_bit_identical(fullbatch):
+    r = fullbatch
+    assert int(r["hw_queues"]) == 16 and int(r["handles"]) == 8
+    for i in range(1, 8):
+        for k in ("z_so3", "z_inv", "s", "t", "m0", "m1", "pose_R", "pose_t"):
+            assert np.array_equal(r[f"h{i}_{k}"], r[f"h0_{k}"]), (i, k)
+    for k in ("z_so3", "z_inv", "s"):
+        assert np.array_equal(r[f"tr_{k}"], r[f"h0_{k}"]), k
+    assert np.array_equal(r["tr_t"], r["h0_t"].reshape(64, 3))
+
+
+def test_fullbatch_encode_vs_oracle(fullbatch):
+    from oracle import net
+    r = fullbatch
+    ecfg = synth.default_encoder_cfg()
+    ew = synth.make_encoder_weights(ecfg, 0)
+    scene = synth.make_scene_pair(32, 1024, seed=1000)
+    x = torch.cat([scene["ref"], scene["rescan"]], 0).transpose(1, 2).contiguous()
+    assert np.array_equal(x.numpy(), r["x"])                 # the worker ran the bench batch
+    sel = [0, 9, 18, 27, 36, 45, 54, 63]
+    tr = {}
+    ref = net.shape_prior_encode(ew, ecfg, x[sel], trace=tr)
+    for k in ("z_so3", "z_inv", "s", "t"):
+        assert relerr(r[f"h0_{k}"][sel], ref[k].numpy()) < TOL, k
+    assert np.array_equal(r["knn_0"][sel], tr["knn_idx_0"].numpy().astype(np.int32))
+    for j, i in enumerate(ecfg["down_sample_layers"]):
+        assert np.array_equal(r[f"fps_{j}"][sel], tr[f"fps_idx_{i}"].numpy().astype(np.int32)), f"fps level {j}"
+    for i in range(1, ecfg["num_layers"]):
+        rate = (r[f"knn_{i}"][sel] == tr[f"knn_idx_{i}"].numpy()).mean()
+        assert rate > 0.995, f"layer {i}: k-NN index agreement {rate:.5f}"
+
+
+def test_fullbatch_match_and_register_vs_oracle(fullbatch):
+    from oracle import more
+    r = fullbatch
+    n = 32
+    z_inv, z_so3, t = torch.from_numpy(r["h0_z_inv"]), torch.from_numpy(r["h0_z_so3"]), torch.from_numpy(r["h0_t"])
+    ref = more.sequential_matcher(z_inv[:n], z_inv[n:])
+    assert np.array_equal(r["h0_m0"], ref["matches0"].numpy())
+    assert np.array_equal(r["h0_m1"], ref["matches1"].numpy())
+    j = ref["matches0"].clamp(min=0)
+    p1 = z_so3[:n] + t[:n]
+    p2 = (z_so3[n:] + t[n:]).index_select(0, j)
+    R, tt, _, _ = more.kabsch_transformation_estimation(p1, p2)
+    assert relerr(r["h0_pose_R"], R.numpy()) < TOL
+    assert relerr(r["h0_pose_t"], tt.numpy()) < TOL

@@ -471,10 +471,10 @@ def test_kabsch_vs_golden(golden):
     assert (torch.det(R.cpu()) > 0.999).all()  # the reflection cases (16..31) still yield proper rotations
     Rw, tw, resw = ops.kabsch(x1, x2, torch.from_numpy(g["kab_w"]).to(_dev()))
     assert relerr(Rw, g["kab_Rw"]) < TOL and relerr(tw, g["kab_tw"]) < TOL and relerr(resw, g["kab_resw"]) < TOL
-    # degenerate input (all points identical): reference's SVD-failure branch -> identity + flag
+    # degenerate input (all points identical -> zero covariance): torch.svd succeeds (U = V = I): identity, status RANK0
     z = torch.ones(2, 16, 3, device=_dev())
     R0, t0, _, fl0 = ops.kabsch(z, z, return_flags=True)
-    assert (fl0 == 1).all() and torch.equal(R0.cpu(), torch.eye(3).repeat(2, 1, 1))
+    assert (fl0 == 2).all() and torch.equal(R0.cpu(), torch.eye(3).repeat(2, 1, 1))
 
 
 def test_residual_matrix_and_eq_matchers(golden):

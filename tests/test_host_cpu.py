@@ -50,10 +50,18 @@ def test_abi_fails_loudly_without_device(lib):
 def test_argument_validation_without_device(lib):
     # shape checks happen on the host before any launch
     P = ctypes.c_void_p
-    assert lib.ls_knn_f32(P(16), P(16), None, None, 1, 8, 8, 8, 5, 16, 0, P(16), None, None) == -1
+    assert lib.ls_knn_f32(P(16), P(16), None, None, 1, 8, 8, 8, 5, 16, 0, P(16), None, None, 0, None) == -1
     assert b"multiple of 32" in lib.ls_last_error()
-    assert lib.ls_knn_f32(P(16), P(16), None, None, 1, 8, 8, 8, 32, 17, 0, P(16), None, None) == -1
-    assert lib.ls_gemm_f32(P(16), 6, P(16), 8, None, P(16), 8, 4, 4, 6, 0, None) == -1
+    assert lib.ls_knn_f32(P(16), P(16), None, None, 1, 8, 8, 8, 32, 17, 0, P(16), None, None, 0, None) == -1
+    assert lib.ls_gemm_f32(P(16), 6, P(16), 8, None, P(16), 8, 4, 4, 6, 0, None, 0, None) == -1
+    # the library never allocates scratch behind an operator call: a missing / short caller workspace is an error, not a hipMalloc
+    need = lib.ls_knn_workspace_bytes(4, 512, 512, 512, 64, 0, 0)
+    assert need > 0 and lib.ls_knn_f32(P(16), P(16), None, None, 4, 512, 512, 512, 64, 16, 0, P(16), None, P(16), need - 1, None) == -3
+    assert b"workspace" in lib.ls_last_error()
+    gneed = lib.ls_gemm_workspace_bytes(192, 1024, 512)
+    assert gneed > 0 and lib.ls_gemm_f32(P(16), 512, P(16), 512, None, P(16), 1024, 192, 1024, 512, 0, None, 0, None) == -3
+    assert lib.ls_cosine_scores_workspace_bytes(32, 32) == 64 * 4
+    assert lib.ls_cosine_scores_f32(P(16), P(16), 32, 32, 256, P(16), None, 0, None) == -3
     assert lib.ls_fps_f32(P(16), None, 1, 100000, 8, 0, P(16), None, None) == -1
     assert b"too large" in lib.ls_last_error()
 
@@ -204,6 +212,19 @@ got = sharding.gather_codes(mine, dst=0, counts=counts)
 assert (got is None) == (rank != 0)
 if rank == 0:
     assert all(torch.equal(got[k], full[k]) for k in full)
+# fewer instances than ranks (ADVICE r1): rank 1's shard is EMPTY -- it must neither call encode (ls_encode rejects B = 0) nor
+# skip the collective (the other rank would block forever)
+class _Stub:
+    class encoder: c_dim = C
+    calls = 0
+    def encode(self, x):
+        _Stub.calls += 1
+        assert x.shape[0] > 0
+        return {k: v[: x.shape[0]].clone() for k, v in full.items()}
+one = sharding.sharded_encode(_Stub(), torch.zeros(1, 3, 16))
+assert _Stub.calls == (1 if rank == 0 else 0)
+assert all(torch.equal(one[k], full[k][:1]) for k in full), "n < world_size mismatch"
+assert sharding.gather_codes(sharding.empty_codes(C, "cpu"), dst=0, counts=[0, 0]) is None or rank == 0
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
