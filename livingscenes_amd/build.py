@@ -13,16 +13,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblivingscenes_hip.so")
 SOURCES = ["model.hip", "knn.hip", "knn_mfma.hip", "knn_xyz.hip", "fps.hip", "gemm.hip", "edge.hip", "pointwise.hip", "sdf.hip", "match.hip", "icp.hip", "mise.hip", "mcubes.hip", "sinkhorn.hip"]
+# -fno-slp-vectorize: no COMPILER-FORMED packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Measured on MI355X (round 2,
+# scripts/diag/edge_determinism.py): the attention edge kernel built WITH those instructions was not reproducible while its waves
+# shared CUs with the bf16-MFMA GEMM of other streams -- the last 16 lanes of a wave occasionally consumed a stale operand (1e-6..1e-5
+# relative on a few points per launch; 4..19 of 48 launches; never when the kernel ran alone); without them 0 of 96, at fewer
+# registers (129 -> 119 VGPRs) and the same speed (whole bench 39.7k -> 40.0k obj/s with the flag on every file).  Kernels that
+# use packed math on purpose (k-NN distance tiles, the GEMM's bf16 split) spell it with explicit vector types, are unaffected by
+# the flag, and are covered by the bit-exactness tests incl. tests/test_hip_fullbatch.py (8 handles in flight).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-         "-ffp-contract=fast-honor-pragmas"]
-# Per-file extra flags.  -fno-slp-vectorize: no compiler-formed packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in the
-# gather kernels.  Measured on MI355X (round 2, scripts/diag/edge_determinism.py): the attention edge kernel built WITH those
-# instructions was not reproducible while its waves shared CUs with the bf16-MFMA GEMM of other streams -- the last 16 lanes of a
-# wave occasionally consumed a packed-op result early (1e-6..1e-5 relative on a few points per launch; 4..19 of 48 launches);
-# without them 0 of 96, at FEWER registers (118 vs 165 VGPRs).  Kernels that use packed math on purpose (k-NN distance tiles,
-# the GEMM's bf16 split) spell it with explicit vector types and are unaffected by the flag.
-EXTRA_FLAGS = {"edge.hip": ["-fno-slp-vectorize"], "pointwise.hip": ["-fno-slp-vectorize"], "sdf.hip": ["-fno-slp-vectorize"],
-               "match.hip": ["-fno-slp-vectorize"], "icp.hip": ["-fno-slp-vectorize"], "sinkhorn.hip": ["-fno-slp-vectorize"]}
+         "-ffp-contract=fast-honor-pragmas", "-fno-slp-vectorize"]
+EXTRA_FLAGS = {}   # per-file additions: {"file.hip": [flags]}
 
 
 def _newest_src():
