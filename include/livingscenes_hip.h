@@ -307,6 +307,18 @@ int ls_marching_cubes_f64(const double* volume, int nx, int ny, int nz, double i
                           long long* faces, long long cap_f, long long* counts_out, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* libsimplify.simplify_mesh(mesh, f_target, agressiveness) as called by Generator3D.extract_mesh with (mesh, simplify_nfaces, 5.0)
+ * (occnet_utils/mesh_extractor2.py:205-208; occnet_utils/utils/libsimplify/__init__.py:7-17, simplify_mesh.pyx:34-88,
+ * Simplify.h:345-445): quadric-error edge-collapse decimation down to `target_faces` triangles.  A sequential greedy algorithm the
+ * reference runs on the CPU too: HOST arrays in and out.  vertices [nv,3] float64, faces [nf,3] int64 -> vertices_out (room for
+ * nv rows), faces_out (room for nf rows), counts_out {nv', nf'}; vertices, faces and their ORDER are bit-identical to the reference.
+ * initial_border: the value Vertex::border holds while the INITIAL edge costs are computed -- the reference never initialises it
+ * (simplify_mesh.pyx:42 copies an uninitialised temporary; Simplify.h resets it only after the costs, :683): 1 = what every build of
+ * the reference made here reads (non-zero: initial costs from the best of a, b, midpoint) and what the fixtures pin; 0 = as published. */
+int ls_simplify_mesh_f64_host(const double* vertices_host, long long nv, const long long* faces_host, long long nf, int target_faces,
+                              double aggressiveness, int initial_border, double* vertices_out_host, long long* faces_out_host,
+                              long long* counts_out_host);
+
 /* ------------------------------------------------------------------------------------------------
  * Live per-kernel timing (bench.py's roofline leg): while enabled, every kernel ls_encode / ls_sdf_decode
  * launches is bracketed by hipEvents on the stream it is launched on.  ls_profile_end synchronises those

@@ -114,6 +114,7 @@ SIGNATURES = {
     "ls_mise_to_dense": (_I, [_P, _I, _I, _P, _P]),
     "ls_mcubes_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ls_marching_cubes_f64": (_I, [_P, _I, _I, _I, ctypes.c_double, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _P, _SZ, _P]),
+    "ls_simplify_mesh_f64_host": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, ctypes.c_double, _I, _P, _P, _P]),
     "ls_profile_begin": (_I, [_P]),
     "ls_profile_end": (_I, [_P, ctypes.POINTER(ProfileEntry), _I, ctypes.POINTER(ctypes.c_int)]),
 }

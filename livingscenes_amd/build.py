@@ -23,6 +23,9 @@ SOURCES = ["model.hip", "knn.hip", "knn_mfma.hip", "knn_xyz.hip", "fps.hip", "ge
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
          "-ffp-contract=fast-honor-pragmas", "-fno-slp-vectorize"]
 EXTRA_FLAGS = {}   # per-file additions: {"file.hip": [flags]}
+# host-only translation units (no device code): g++, strict fp (no contraction: simplify.cpp reproduces the reference's doubles bit for bit)
+HOST_SOURCES = ["simplify.cpp"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
 def _newest_src():
@@ -50,6 +53,16 @@ def build(force=False, verbose=False):
         if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
             continue
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s in HOST_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".cpp", ".o"))
+        objs.append(obj)
+        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+            continue
+        cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -175,9 +175,9 @@ class Generator3D:
     def extract_mesh(self, occ_hat, z, c=None, stats_dict=None):
         """mesh_extractor2.py:161-214: pad with -1e6 (watertight), marching cubes at the logit threshold, undo the library's 0.5
         shift and the padding, normalise to the bounding box."""
-        if self.with_normals or self.simplify_nfaces is not None or self.refinement_step > 0:
-            raise NotImplementedError("normals / simplification / refinement are off in the released extraction settings and "
-                                      "not implemented")
+        if self.with_normals or self.refinement_step > 0:
+            raise NotImplementedError("with_normals / refinement_step > 0 are off in every released configuration "
+                                      "(configs/more_3rscan.yaml:19-26, room4cates.yaml:32-39) and not implemented")
         n_x, n_y, n_z = occ_hat.shape
         box_size = 1 + self.padding
         threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
@@ -190,6 +190,10 @@ class Generator3D:
         vertices -= 1
         vertices /= np.array([n_x - 1, n_y - 1, n_z - 1])
         vertices = box_size * (vertices - 0.5)
+        if vertices.shape[0] == 0:                       # mesh_extractor2.py:196-197: an empty mesh is returned as it is
+            return make_mesh(vertices, triangles)
+        if self.simplify_nfaces is not None:             # :205-208 -- the released configs set 5000 / 100000
+            vertices, triangles = simplify_mesh_arrays(vertices, triangles, self.simplify_nfaces, 5.0)
         return make_mesh(vertices, triangles)
 
 
@@ -215,6 +219,27 @@ def marching_cubes(volume, isovalue):
     if nv:
         call(dev, "ls_marching_cubes_f64", *args, ptr(verts), nv, ptr(faces), nf, ptr(counts), ptr(ws), ws_bytes, stream_ptr(dev))
     return verts, faces
+
+
+def simplify_mesh_arrays(vertices, faces, f_target=10000, agressiveness=7.0, initial_border=1):
+    """libsimplify.mesh_simplify (simplify_mesh.pyx:34-88): quadric edge-collapse decimation to f_target faces -> (vertices
+    float64 [nv',3], faces int64 [nf',3]), bit-identical to the reference (csrc/simplify.cpp; host code, as in the reference).
+    initial_border=1 reproduces the reference as it actually runs (its uninitialised Vertex::border reads non-zero while the
+    initial edge costs are computed, see csrc/simplify.cpp); 0 is the algorithm as published."""
+    v = np.ascontiguousarray(vertices, np.float64)
+    f = np.ascontiguousarray(faces, np.int64)
+    vo, fo = np.empty_like(v), np.empty_like(f)
+    counts = np.zeros(2, np.int64)
+    P = ctypes.c_void_p
+    check(load().ls_simplify_mesh_f64_host(P(v.ctypes.data), v.shape[0], P(f.ctypes.data), f.shape[0], int(f_target), float(agressiveness),
+                                           int(initial_border), P(vo.ctypes.data), P(fo.ctypes.data), P(counts.ctypes.data)), "ls_simplify_mesh_f64_host")
+    return vo[: counts[0]].copy(), fo[: counts[1]].copy()
+
+
+def simplify_mesh(mesh, f_target=10000, agressiveness=7.0):
+    """occnet_utils/utils/libsimplify/__init__.py:7-17 (same name and arguments): mesh in, simplified mesh out."""
+    v, f = simplify_mesh_arrays(mesh.vertices, mesh.faces, f_target, agressiveness)
+    return make_mesh(v, f)
 
 
 class SimpleMesh:

@@ -423,6 +423,43 @@ def test_more_solver_mesh_from_latent(small_prior):
     assert len(mesh.faces) > 50 and np.allclose(np.asarray(mesh.vertices), want, rtol=0, atol=1e-12)
 
 
+@pytest.mark.gpu
+def test_more_solver_from_released_mesh_extractor_section(small_prior):
+    """More_Solver built from the VERBATIM mesh_extractor section of the released configs/more_3rscan.yaml:19-26 (it sets
+    simplify_nfaces: 5000, which round 1 refused): _mesh_from_latent extracts (MISE 32 -> 128, marching cubes) and decimates like
+    Generator3D.extract_mesh (mesh_extractor2.py:205-208 -> libsimplify.simplify_mesh(mesh, 5000, 5.0))."""
+    import yaml
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    from livingscenes_amd import mesh_extractor2
+    released = yaml.safe_load("""
+mesh_extractor:
+  threshold: 0.5
+  resolution0: 32
+  upsampling_steps: 2
+  sample: False
+  simplify_nfaces: 5000
+  points_batch_size: 10000
+  refinement_step: 0
+""")
+    sp, _ = small_prior
+    code = sp.encode(synth.make_instances(1, 128, seed=23).to(_dev()))
+    solver = More_Solver(released, model=sp)
+    canon = {k: v.clone() for k, v in code.items()}
+    canon["t"], canon["s"] = torch.zeros_like(code["t"]), torch.ones_like(code["s"])
+    grid = solver.mesh_extractor.eval_grid(canon, sp.decoder)
+    solver.mesh_extractor.threshold = 1.0 / (1.0 + np.exp(-float(np.median(grid))))   # untrained weights: put the level set inside the box
+    mesh = solver._mesh_from_latent(code)
+    nf = len(mesh.faces)
+    assert 50 < nf <= 5001
+    # the same grid without decimation has (many) more faces, and decimating it by hand gives the same mesh
+    solver.mesh_extractor.simplify_nfaces = None
+    full = solver.mesh_extractor.extract_mesh(solver.mesh_extractor.eval_grid(canon, sp.decoder), None, canon)
+    assert len(full.faces) > nf
+    v, f = mesh_extractor2.simplify_mesh_arrays(np.asarray(full.vertices), np.asarray(full.faces), 5000, 5.0)
+    want = v * float(code["s"]) + code["t"].view(-1).cpu().numpy()
+    assert np.array_equal(f, np.asarray(mesh.faces)) and np.allclose(np.asarray(mesh.vertices), want, rtol=0, atol=1e-12)
+
+
 # ------------------------------------------------------------------------------------------------ code optimisation (SURVEY 8 f-1)
 @pytest.mark.gpu
 def test_more_solver_optimize_code_vs_oracle_loop(small_prior):
