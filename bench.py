@@ -259,8 +259,9 @@ def main():
     per_rank = None
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-        allr = [torch.zeros_like(my) for _ in range(world)]
-        dist.all_gather(allr, my)
+        mine = my if backend == "nccl" else my.cpu()     # gloo gathers through host memory only
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "ms_per_step": round(float(v[0]) / args.steps * 1e3, 4),
                      "host_enqueue_ms_per_step": round(float(v[1]) / args.steps * 1e3, 4)} for r, v in enumerate(allr)]
     dt = float(dt_t.item())

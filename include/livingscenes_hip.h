@@ -187,6 +187,11 @@ typedef struct {
 
 int ls_model_create(const ls_model_desc* desc_host, const float* blob_host, ls_model_t** out);
 void ls_model_destroy(ls_model_t* m);
+/* per-handle switches (defaults in brackets) */
+#define LS_OPT_SDF_TRAIN_SPLITK 1 /* [1] split-K in the GEMMs of ls_sdf_decode_train / ls_sdf_backward when the problem under-fills the chip
+                                     (one 1024-point cloud); 0 = never: a row's values do not depend on the size of the call (batched == per pair) */
+#define LS_OPT_SDF_BF16X2 2       /* [0, or LS_SDF_BF16X2 in the environment] decoder products as two-piece bf16 splits (2^-16 per product, ~1.5x) */
+int ls_model_set_option(ls_model_t* m, int option, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * Composite hot path
@@ -272,6 +277,25 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
  * x [N,3], y [M,3], h [M] (log-weight + potential / eps). */
 int ls_sinkhorn_softmin_f32(const float* x, const float* y, const float* h, int N, int M, float eps, float* out, float* grad_x,
                             void* stream);
+
+/* SURVEY.md 8 (f-1), registration half, BATCHED over P pairs (csrc/optim.hip): the device side of one step of
+ * More_Solver._solve_pairwise_registration(optim=True) (lib_more/more_solver.py:118-189) for P pairs in lock-step.
+ *   ls_se3_transform_f32         query[p] = g[p] . src[p]       g [P,3,4] (R | t), src / query [P,N,3]                  (:149)
+ *   ls_smooth_l1_f32             loss[p] (+)= mean_i SmoothL1(sdf[p,i], 0);  grad_sdf[p,i] = d loss[p] / d sdf[p,i]       (:152-156)
+ *   ls_sinkhorn_softmin_batched_f32   ls_sinkhorn_softmin_f32 with a pair index: out[p,i] = -eps_p log sum_j exp(logw + pot_y[p,j] / eps_p
+ *                                - |x_i - y_j|^2 / (2 eps_p)) (averaged with prev[p,i] if `average`); eps_p <= 0: out = prev (schedule
+ *                                of that pair has ended); grad_x optional; out must not alias prev                           (:146,158)
+ *   ls_se3_adam_step_f32         tangent gradient (sum G, sum query x G) -> Adam moments m1 / m2 [P,6] -> g <- exp(-step) g; best-loss
+ *                                snapshot best_g / min_loss (after the step, as the reference); geodesic angle to init_R [P,3,3] above
+ *                                stop_angle -> active[p] = 0 (frozen from then on); query <- g . src for the next step             (:160-173)
+ * torchlie / geomloss / roma are absent: retraction and Sinkhorn loop are this build's definitions (PARITY UNPINNED). */
+int ls_se3_transform_f32(const float* g, const float* src, int P, int N, float* query, void* stream);
+int ls_smooth_l1_f32(const float* sdf, int P, int N, int accumulate, float* loss, float* grad_sdf, void* stream);
+int ls_sinkhorn_softmin_batched_f32(const float* x, const float* y, const float* pot_y, float logw, const float* eps, const float* prev,
+                                    int average, int P, int N, int M, float* out, float* grad_x, void* stream);
+int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float* loss, int P, int N, float lr, float beta1, float beta2,
+                         float adam_eps, int step, float stop_angle, float* g, float* m1, float* m2, float* min_loss, float* best_g,
+                         const float* init_R, int32_t* active, float* query, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SURVEY.md 8 (f-2), first half: the MISE octree that decides WHICH lattice points of the (R+1)^3 grid the decoder has to

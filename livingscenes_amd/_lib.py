@@ -16,6 +16,7 @@ FLAG_CONTRACT_FMA = 1
 FLAG_KNN_MFMA_FILTER = 2
 FLAG_KNN_VALU_ONLY = 4
 FLAG_KABSCH_RAW_WEIGHTS = 8
+OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2 = 1, 2
 KABSCH_OK, KABSCH_RANK1, KABSCH_RANK0, KABSCH_NONFINITE = 0, 1, 2, 3
 
 
@@ -89,6 +90,11 @@ SIGNATURES = {
     "ls_icp_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _P, _P, _P, _P, _P, _SZ, _P]),
     "ls_model_create": (_I, [ctypes.POINTER(ModelDesc), _P, ctypes.POINTER(_P)]),
     "ls_model_destroy": (None, [_P]),
+    "ls_model_set_option": (_I, [_P, _I, _I]),
+    "ls_se3_transform_f32": (_I, [_P, _P, _I, _I, _P, _P]),
+    "ls_smooth_l1_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "ls_sinkhorn_softmin_batched_f32": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "ls_se3_adam_step_f32": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ls_encoder_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ls_vn_edgeconv_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I, _I]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblivingscenes_hip.so")
-SOURCES = ["model.hip", "knn.hip", "knn_mfma.hip", "knn_xyz.hip", "fps.hip", "gemm.hip", "edge.hip", "pointwise.hip", "sdf.hip", "match.hip", "icp.hip", "mise.hip", "mcubes.hip", "sinkhorn.hip"]
+SOURCES = ["model.hip", "knn.hip", "knn_mfma.hip", "knn_xyz.hip", "fps.hip", "gemm.hip", "edge.hip", "pointwise.hip", "sdf.hip", "match.hip", "icp.hip", "mise.hip", "mcubes.hip", "sinkhorn.hip", "optim.hip"]
 # -fno-slp-vectorize: no COMPILER-FORMED packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Measured on MI355X (round 2,
 # scripts/diag/edge_determinism.py): the attention edge kernel built WITH those instructions was not reproducible while its waves
 # shared CUs with the bf16-MFMA GEMM of other streams -- the last 16 lanes of a wave occasionally consumed a stale operand (1e-6..1e-5

@@ -79,6 +79,8 @@ struct ls_model {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
     bool knn_filter = true;        // LS_KNN_FILTER=0: all-VALU k-NN kernel on the seeded C == 32 layers too (A/B timing)
+    bool train_splitk = true;      // ls_model_set_option(LS_OPT_SDF_TRAIN_SPLITK): split-K in the decoder's TRAINING-path GEMMs (under-filled
+                                   // M = 1024 problems: 2.43 -> 1.6 ms per step); off = a row's result never depends on the batch it rides in
     bool sdf_bf16x2 = false;       // LS_SDF_BF16X2=1: decoder GEMMs with two-piece bf16 products (2^-16 per product, ~1.7x; opt-in)
     bool seed_knn = true;          // LS_KNN_SEEDS=0 disables seeding a layer's k-NN lists from the previous layer's graph
     int hint_policy = 0;           // LS_KNN_HINTS: 0 "mixed" (default) = previous-layer lists for the C = 32 layers, the sweep's own
@@ -415,6 +417,15 @@ void ls_model_destroy(ls_model_t* m) {
     delete m;
 }
 
+int ls_model_set_option(ls_model_t* m, int option, int value) {
+    LS_REQUIRE(m, "model_set_option: null model");
+    switch (option) {
+        case LS_OPT_SDF_TRAIN_SPLITK: m->train_splitk = value != 0; return LS_OK;
+        case LS_OPT_SDF_BF16X2: m->sdf_bf16x2 = value != 0; return LS_OK;
+        default: set_error("model_set_option: unknown option %d", option); return LS_ERR_INVALID;
+    }
+}
+
 size_t ls_encoder_workspace_bytes(const ls_model_t* m, int B, int N) {
     if (!m) return 0;
     EncPlan p;
@@ -702,7 +713,7 @@ struct SdfBuffers {
     float *dzA, *dzB, *dA0, *dA4, *db0, *db4, *dQ;
     float* gws;         // split-K scratch for the under-filled GEMMs (NULL when the grid is large enough)
 };
-static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, int M, bool train) {
+static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, int M, bool train, bool allow_splitk = true) {
     SdfBuffers sb{};
     const int w = d.dec_width, nl = d.dec_num_linear;
     char* ws = (char*)workspace;
@@ -730,6 +741,7 @@ static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, in
     sb.db4 = take((size_t)B * w * 4);
     sb.dQ = take((size_t)B * M * 16);
     sb.gws = sdf_gemm_scratch(d, (long long)B * M) ? take(sdf_gemm_scratch(d, (long long)B * M) * 4) : nullptr;
+    if (!allow_splitk) sb.gws = nullptr;
     return sb;
 }
 
@@ -833,7 +845,7 @@ int ls_sdf_decode_train(ls_model_t* m, const float* query, const float* z_so3, c
     LS_REQUIRE(B > 0 && M > 0, "sdf_decode_train: empty problem");
     const size_t need = ls_sdf_train_workspace_bytes(m, B, M);
     if (workspace_bytes < need) { set_error("sdf_decode_train: workspace %zu < required %zu", workspace_bytes, need); return LS_ERR_WORKSPACE; }
-    return sdf_forward(m, sdf_buffers(d, workspace, B, M, true), query, z_so3, z_inv, s, t, B, M, sdf, (hipStream_t)stream);
+    return sdf_forward(m, sdf_buffers(d, workspace, B, M, true, m->train_splitk), query, z_so3, z_inv, s, t, B, M, sdf, (hipStream_t)stream);
 }
 
 static int build_dec_wt(ls_model_t* m, hipStream_t st) {   // transposed main weights of layers 1 .. nl-2
@@ -869,7 +881,7 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
     hipStream_t st = (hipStream_t)stream;
     int rc = build_dec_wt(m, st);
     if (rc != LS_OK) return rc;
-    const SdfBuffers sb = sdf_buffers(d, workspace, B, M, true);
+    const SdfBuffers sb = sdf_buffers(d, workspace, B, M, true, m->train_splitk);
     const int w = d.dec_width, L = d.c_dim, nl = d.dec_num_linear, li = d.dec_latent_in;
     const float* W = m->blob;
     const long long rows = (long long)B * M;
@@ -890,7 +902,8 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
             dq_started = true;
         }
         // dh_{l-1} [rows, kin] = dz_l [rows, out_l] . W_l [out_l][kin]  ==  dz_l . (Wt_l [kin][out_l])^T
-        rc = gemm_dispatch_ws(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, sb.gws, st);
+        rc = (m->sdf_bf16x2 && !sb.gws) ? gemm_dispatch_fast2(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, st)
+                                        : gemm_dispatch_ws(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, sb.gws, st);
         if (rc != LS_OK) return rc;
         rc = relu_mask_launch(other, sb.h[l - 1], rows, kin, w, st);
         if (rc != LS_OK) return rc;

@@ -326,6 +326,9 @@ int sdf_prep_launch(const float* inv_t, const float* so3_t, const float* wlen, c
 int sdf_affine_launch(const float* query, const float* s, const float* t, const float* A, const float* beff, int B, int M,
                       int out_dim, int ldh, int accumulate, float* h, hipStream_t st) {
     const int rpb = 64;
+    // gridDim.y / .z are limited to 65535: say so instead of a generic launch failure (direct C-ABI callers; ops.sdf_decode chunks)
+    LS_REQUIRE(B <= 65535 && cdiv(M, rpb) <= 65535, "sdf_decode: B=%d or M=%d too large for one call (B <= 65535, M <= %d): split the queries", B, M,
+               65535 * rpb);
     hipLaunchKernelGGL(sdf_affine_kernel, dim3(cdiv(out_dim, 256), B, cdiv(M, rpb)), dim3(256), 0, st, query, s, t, A, beff, M,
                        out_dim, ldh, accumulate, rpb, h);
     LS_LAUNCH_CHECK();
@@ -334,6 +337,7 @@ int sdf_affine_launch(const float* query, const float* s, const float* t, const 
 int sdf_affine_rows_launch(const float* query, const int32_t* row_inst, const float* s, const float* t, const float* A, const float* beff,
                            long long R, int out_dim, int ldh, int accumulate, float* h, hipStream_t st) {
     const int rpb = 64;
+    LS_REQUIRE(cdiv(R, rpb) <= 65535, "sdf_decode_rows: R=%lld rows too many for one call (<= %d): split the rows", R, 65535 * rpb);
     hipLaunchKernelGGL(sdf_affine_rows_kernel, dim3(cdiv(out_dim, 256), (unsigned)cdiv(R, rpb)), dim3(256), 0, st, query, row_inst, s, t, A,
                        beff, R, out_dim, ldh, accumulate, rpb, h);
     LS_LAUNCH_CHECK();

@@ -1,7 +1,8 @@
 """DeepSDF_Decoder -- parameter container with the reference's constructor and state_dict keys
 (/root/reference/lib_shape_prior/core/lib/implicit_func/deepsdf_decoder.py:9-76: lin{l}.weight_g / weight_v / bias for
-the weight-normed layers, lin{l}.weight / bias otherwise).  The forward lives in the HIP library (csrc/sdf.hip +
-csrc/gemm.hip) and is reached through model_utils.FieldWrapper; there is no PyTorch compute path."""
+the weight-normed layers, lin{l}.weight / bias otherwise).  The evals reach the decoder through model_utils.FieldWrapper, whose
+fused HIP path (csrc/sdf.hip) never builds the 513-wide input; ``forward(input, phase)`` below is the reference's direct call
+surface (deepsdf_decoder.py:78-123) on an already assembled input, layer by layer on the HIP GEMM -- no PyTorch compute path."""
 import math
 
 import torch
@@ -38,6 +39,40 @@ class DeepSDF_Decoder(nn.Module):
                 assert not (norm_layers and layer in norm_layers), "LayerNorm variant is not on the released path"
                 setattr(self, f"lin{layer}", nn.Linear(d[layer], out_dim))
 
-    def forward(self, inp, phase="val"):
-        raise NotImplementedError("DeepSDF_Decoder runs inside the HIP library: call it through FieldWrapper "
-                                  "(livingscenes_amd.model_utils), which folds the code into the first/skip layers")
+    def _folded(self):
+        """[(W [out,in] fp32, bias)] with weight_norm folded (W = g v / |v|_row, in fp64), cached until a parameter changes."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if getattr(self, "_fold_key", None) != key:
+            ws = []
+            for layer in range(self.num_layers - 1):
+                lin = getattr(self, f"lin{layer}")
+                if isinstance(lin, _WNLinear):
+                    v = lin.weight_v.detach().double()
+                    W = (lin.weight_g.detach().double() * v / v.norm(dim=1, keepdim=True)).float()
+                else:
+                    W = lin.weight.detach().float()
+                ws.append((W.contiguous(), lin.bias.detach().float().contiguous()))
+            self._fold, self._fold_key = ws, key
+        return self._fold
+
+    def forward(self, input, phase="val"):
+        """deepsdf_decoder.py:78-123, inference: input [B,N,latent+pe] -> sdf [B,N] = tanh(MLP(input)) with the input re-concatenated
+        before the layers in ``latent_in``.  Every linear layer (bias + ReLU fused) runs in ls_gemm_f32."""
+        from . import ops
+        if phase == "train":
+            raise NotImplementedError("training-time forward (dropout) is out of scope: the HIP path is inference + the gradients "
+                                      "More_Solver needs (model_utils._SdfDecode)")
+        B, N, L = input.shape
+        x0 = input.reshape(-1, L).float().contiguous()
+        x = x0
+        last = self.num_layers - 2
+        for layer, (W, b) in enumerate(self._folded()):
+            if layer in self.latent_in:
+                x = torch.cat([x, x0], 1)
+            k = x.shape[1]
+            if k % 4:                                   # ls_gemm_f32 wants K % 4 == 0 (513-wide input): zero-pad both operands
+                pad = 4 - k % 4
+                x = torch.nn.functional.pad(x, (0, pad))
+                W = torch.nn.functional.pad(W, (0, pad))
+            x = ops.gemm(x.contiguous(), W.contiguous(), b, relu=layer < last)
+        return torch.tanh(x).view(B, N)

@@ -42,7 +42,7 @@ def eval_matching(scenes, solver, method="sequential"):
 @torch.no_grad()
 def eval_relocalization(scenes, solver, icp=True):
     """Pairwise registration of every (ref_i, rescan_i) instance pair (eval_flyingshape.py:110-173)."""
-    rre, rte, te = [], [], []
+    rre, rte, te, poses = [], [], [], []
     for sc in scenes:
         dev = next(solver.model.parameters()).device
         ref, res = sc["ref"].to(dev), sc["rescan"].to(dev)
@@ -54,6 +54,7 @@ def eval_relocalization(scenes, solver, icp=True):
         rre.append(r.cpu())
         rte.append(translation_error(t, gt[:, :, 3:4]).reshape(-1).cpu())
         pred = torch.cat([R, t], 2)
+        poses.append(pred.cpu())
         te.append(torch.stack([compute_transformation_error(ref[i:i + 1], res[i:i + 1], pred[i:i + 1], gt[i:i + 1]) for i in range(n)]).cpu())
     rre, rte, te = torch.cat(rre).numpy(), torch.cat(rte).numpy(), torch.cat(te).numpy()
 
@@ -61,7 +62,8 @@ def eval_relocalization(scenes, solver, icp=True):
         return float(np.median(x)) if len(x) else float("nan")
     return {"recall_rre5": float((rre < 5).mean() * 100), "recall_rre10": float((rre < 10).mean() * 100),
             "median_rre_5": med(rre[rre < 5]), "median_rte_5": med(rte[rre < 5]), "te_cm_5": med(te[rre < 5]) * 100,
-            "median_rre_all": med(rre), "rre": rre, "rte": rte, "te": te}
+            "median_rre_all": med(rre), "rre": rre, "rte": rte, "te": te,
+            "poses": torch.cat(poses).numpy()}   # [n,3,4] predicted (R | t), for parity checks at matrix level
 
 
 # ------------------------------------------------------------------------------------------------ 3RScan matching evaluation

@@ -63,64 +63,89 @@ class More_Solver:
         return self._solve_pairwise_registration_batch([pc1_full[0]], [pc2_full[0]])
 
     def _solve_pairwise_registration_optim(self, pc1_full, pc2_full):
-        """more_solver.py:118-189 (optim=True): refine the Kabsch pose by Adam on SE(3) against SmoothL1(sdf(g.src; shared code))
-        + Sinkhorn(g.src, tgt), best-loss snapshot, then ICP.  The decoder forward / backward and the Sinkhorn softmins run in the
-        HIP library.  torchlie / geomloss / roma are not installed: the manifold update and the Sinkhorn divergence follow this
-        build's documented definitions (PARITY UNPINNED): left-multiplicative retraction g <- exp(-step) g with Adam
-        moments kept on the 6-vector (v, omega) of the left tangent space; livingscenes_amd/sinkhorn.py."""
-        from ..sinkhorn import sinkhorn_divergence
+        """more_solver.py:118-189 (optim=True) for ONE pair: the batched path with P = 1 (same arithmetic: a pair's trajectory does
+        not depend on the batch it rides in)."""
+        return self._solve_pairwise_registration_optim_batch([pc1_full[0]], [pc2_full[0]])
+
+    def _solve_pairwise_registration_optim_batch(self, pcs1, pcs2, icp=True, return_info=False):
+        """more_solver.py:118-189 (optim=True) for P pairs IN LOCK-STEP -- what eval_3rscan.py:381 runs per matched instance: keep the
+        code that explains its own points better (:124-135), refine the Kabsch pose by Adam on SE(3) against
+        SmoothL1(sdf(g.src; shared code)) + Sinkhorn(g.src, tgt) (:137-173: MultiStepLR [300, 340, 380], best-loss snapshot after the
+        step, geodesic early stop), invert for the reversed direction (:175-179), then ICP (:181-187).
+        Per step the host only sequences launches: decoder forward + backward on P x N queries (ls_sdf_decode_train /
+        ls_sdf_backward), per-pair SmoothL1 + its gradient, the batched Sinkhorn softmins, and ONE kernel for the tangent gradient,
+        the Adam moments, the retraction, the snapshot, the early-stop test and the next transformed cloud (csrc/optim.hip).
+        torchlie / geomloss / roma are not installed: the manifold update (left-multiplicative retraction g <- exp(-step) g, Adam
+        moments on the 6-vector (v, omega) of the left tangent space) and the Sinkhorn divergence follow this build's documented
+        definitions -- PARITY UNPINNED.  lists of clouds [Ni,3] / [Mi,3] -> R [P,3,3], t [P,3,1] mapping pc1 -> pc2."""
+        from .. import _lib
+        from ..sinkhorn import divergence_batch
         n_in = self.cfg["shape_priors"]["n_input_point"]
         assert self.cfg.get("fps", {}).get("n_init", 1) == 1, "fps.n_init > 1 is not used by the released configs"
-        pc1, _ = fps(pc1_full, K=n_in)
-        pc2, _ = fps(pc2_full, K=n_in)
-        with torch.no_grad():
-            code1 = self.model.encode(pc1.transpose(-1, -2).contiguous())
-            code2 = self.model.encode(pc2.transpose(-1, -2).contiguous())
-            code1_se3, code2_se3 = code1["z_so3"] + code1["t"], code2["z_so3"] + code2["t"]
-            R, t, _, _ = kabsch_transformation_estimation(code1_se3, code2_se3)
-            sdf_error1 = self.model.decoder(pc1, None, code1, return_sdf=True).abs().mean()
-            sdf_error2 = self.model.decoder(pc2, None, code2, return_sdf=True).abs().mean()
-        reverse = bool(sdf_error1 < sdf_error2)            # keep the code that explains its own points better (:124-135)
-        if reverse:
-            shared_code, src_pc, tgt_pc = code1, pc2, pc1
-            with torch.no_grad():
-                R, t, _, _ = kabsch_transformation_estimation(code2_se3, code1_se3)
-        else:
-            shared_code, src_pc, tgt_pc = code2, pc1, pc2
-        shared_code = {k: v.detach() for k, v in shared_code.items()}
         reg = self.cfg["registration"]
         lr0, n_steps, stop = reg["step_size"]["so3"], reg["n_steps"], reg["early_stop_threshold"]
-        g = torch.cat([R, t], 2)[0].detach().clone()        # [3,4]
-        init_R = g[:, :3].clone()
-        m1 = torch.zeros(6, device=g.device)
-        m2 = torch.zeros(6, device=g.device)
-        b1, b2, eps_adam = 0.9, 0.999, 1e-8
-        min_loss, best_g = 100.0, g.clone()
-        src = src_pc[0]
-        for i in range(n_steps):
-            lr = lr0 * (0.1 ** sum(i >= ms for ms in (300, 340, 380)))          # MultiStepLR([300,340,380], 0.1), :143
-            query = (src @ g[:, :3].T + g[:, 3]).detach().requires_grad_(True)
-            sdf = self.model.decoder(query[None], None, shared_code, return_sdf=True)
-            loss = torch.nn.functional.smooth_l1_loss(sdf, torch.zeros_like(sdf)) + sinkhorn_divergence(query[None], tgt_pc)
-            loss.backward()
-            G = query.grad
-            with torch.no_grad():
-                grad = torch.cat([G.sum(0), torch.cross(query.detach(), G, dim=1).sum(0)])   # d loss / d (v, omega), left tangent
-                m1 = b1 * m1 + (1 - b1) * grad
-                m2 = b2 * m2 + (1 - b2) * grad * grad
-                step = lr * (m1 / (1 - b1 ** (i + 1))) / ((m2 / (1 - b2 ** (i + 1))).sqrt() + eps_adam)
-                g = _se3_exp(-step) @ torch.cat([g, g.new_tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
-                g = g[:3]
-                if float(loss) < min_loss:                   # snapshot AFTER the step, as the reference (:166-168)
-                    min_loss, best_g = float(loss), g.clone()
-                cosang = ((g[:, :3] @ init_R.T).diagonal().sum() - 1) / 2
-                if float(torch.acos(cosang.clamp(-1, 1))) > stop:   # radians against the configured number, as the reference (:172-173)
-                    break
-        if reverse:
-            Rb = best_g[:, :3].T
-            best_g = torch.cat([Rb, -(Rb @ best_g[:, 3:4])], 1)
-        R, t = best_g[None, :, :3].contiguous(), best_g[None, :, 3:4].contiguous()
-        return self._icp(pc1, pc2, R, t)
+        P = len(pcs1)
+        pc1, pc2 = self._sample(pcs1, n_in), self._sample(pcs2, n_in)
+        hip = self.model.hip_model()
+        with torch.no_grad():
+            code = self.model.encode(torch.cat([pc1, pc2], 0).transpose(-1, -2).contiguous())
+            c1 = {k: v[:P] for k, v in code.items()}
+            c2 = {k: v[P:] for k, v in code.items()}
+            se1, se2 = c1["z_so3"] + c1["t"], c2["z_so3"] + c2["t"]
+            R12, t12, _, _ = kabsch_transformation_estimation(se1, se2)
+            R21, t21, _, _ = kabsch_transformation_estimation(se2, se1)
+            err1 = self.model.decoder(pc1, None, c1, return_sdf=True).abs().mean(1)
+            err2 = self.model.decoder(pc2, None, c2, return_sdf=True).abs().mean(1)
+            reverse = err1 < err2                                 # keep the code that explains its own points better (:124-135)
+
+            def pick(a, b):                                       # a where reversed, b otherwise
+                return torch.where(reverse.view(-1, *([1] * (a.dim() - 1))), a, b)
+            shared = {k: pick(c1[k], c2[k]).contiguous() for k in ("z_so3", "z_inv", "s", "t")}
+            src, tgt = pick(pc2, pc1).contiguous(), pick(pc1, pc2).contiguous()
+            g0 = torch.cat([pick(R21, R12), pick(t21, t12)], 2).contiguous()
+            hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 0)          # batch-invariant decoder arithmetic: P pairs == each pair alone
+            # opt-in (not in the reference's yaml): registration.decoder_bf16_pieces = 2 runs the refinement's decoder GEMMs with
+            # two-piece bf16 products (2^-16 per product, 3e-6 of max|sdf| end to end, ~1.4x faster GEMMs); default 3 = fp32-accurate
+            two_piece = int(reg.get("decoder_bf16_pieces", 3)) == 2
+            if two_piece:
+                hip.set_option(_lib.OPT_SDF_BF16X2, 1)
+            try:
+                opt = ops.Se3Adam(g0, src, stop)
+                steps_run = 0
+                for i in range(n_steps):
+                    lr = lr0 * (0.1 ** sum(i >= ms for ms in (300, 340, 380)))          # MultiStepLR([300, 340, 380], 0.1), :143
+                    sdf, saved = hip.sdf_decode_train(opt.query, shared["z_so3"], shared["z_inv"], shared["s"], shared["t"])
+                    loss, gsdf = ops.smooth_l1(sdf)
+                    gq = hip.sdf_backward(saved, gsdf)[0]
+                    sl, sg = divergence_batch(opt.query, tgt)
+                    opt.step(gq + sg, loss + sl, lr)
+                    steps_run = i + 1
+                    if i % 16 == 15 and not bool(opt.active.any()):             # every pair stopped early: one host read per 16 steps
+                        break
+            finally:
+                hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 1)
+                if two_piece:
+                    hip.set_option(_lib.OPT_SDF_BF16X2, 0)
+            best = opt.best_g
+            Rb = best[:, :, :3].transpose(1, 2)
+            inv = torch.cat([Rb, -(Rb @ best[:, :, 3:4])], 2)
+            best = pick(inv, best)
+            R, t = best[:, :, :3].contiguous(), best[:, :, 3:4].contiguous()
+        if icp:
+            R, t = self._icp(pc1, pc2, R, t)
+        if return_info:
+            return R, t, {"reverse": reverse, "min_loss": opt.min_loss, "active": opt.active, "steps": steps_run, "pre_icp": best}
+        return R, t
+
+    def _sample(self, pcs, n_in):
+        """Ragged FPS of a list of clouds [Ni,3] to n_in points each: ONE launch."""
+        dev = pcs[0].device
+        lens = torch.tensor([p.shape[0] for p in pcs], device=dev)
+        buf = torch.zeros(len(pcs), int(lens.max()), 3, device=dev)
+        for i, p in enumerate(pcs):
+            buf[i, : p.shape[0]] = p
+        idx = ops.fps(buf, n_in, lengths=lens)
+        return torch.gather(buf, 1, idx.long()[..., None].expand(-1, -1, 3))
 
     def _solve_pairwise_registration_batch(self, pcs1, pcs2, icp=True):
         """Batched form: lists of clouds [Ni,3] / [Mi,3] -> R [P,3,3], t [P,3,1].  One ragged FPS launch per side,
@@ -128,16 +153,7 @@ class More_Solver:
         n_in = self.cfg["shape_priors"]["n_input_point"]
         assert self.cfg.get("fps", {}).get("n_init", 1) == 1, "fps.n_init > 1 is not used by the released configs"
         P = len(pcs1)
-        dev = pcs1[0].device
-
-        def sample(pcs):
-            lens = torch.tensor([p.shape[0] for p in pcs], device=dev)
-            buf = torch.zeros(len(pcs), int(lens.max()), 3, device=dev)
-            for i, p in enumerate(pcs):
-                buf[i, : p.shape[0]] = p
-            idx = ops.fps(buf, n_in, lengths=lens)
-            return torch.gather(buf, 1, idx.long()[..., None].expand(-1, -1, 3))
-        pc1, pc2 = sample(pcs1), sample(pcs2)
+        pc1, pc2 = self._sample(pcs1, n_in), self._sample(pcs2, n_in)
         with torch.no_grad():
             code = self.model.encode(torch.cat([pc1, pc2], 0).transpose(-1, -2).contiguous())
         c1 = {k: v[:P] for k, v in code.items()}
@@ -148,29 +164,48 @@ class More_Solver:
         return R, t
 
     def _optimize_code(self, code, pc, mask, n_steps=200):
-        """more_solver.py:191-228: Adam on (z_inv, t, z_so3) against MSE(sdf(pc; code), 0), lr 1e-5 / 1e-4 / 5e-4, x0.1 at step
-        160, best-loss snapshot.  The decoder forward / backward run in the HIP library (ls_sdf_decode_train / ls_sdf_backward)."""
-        valid_pc = pc.T[mask.squeeze()].squeeze()[None]
-        pc, _ = fps(valid_pc, K=self.cfg["shape_priors"]["n_input_point"])
+        """more_solver.py:191-228 for one instance (the batched path with P = 1)."""
+        valid_pc = pc.T[mask.squeeze()].squeeze()
+        best, improved = self._optimize_code_batch(code, [valid_pc], n_steps=n_steps)
+        return best if bool(improved[0]) else None
+
+    def _optimize_code_batch(self, code, pcs, n_steps=200):
+        """more_solver.py:191-228 for P instances at once (eval_3rscan.py:489 calls it per instance): Adam on (z_inv, t, z_so3) against
+        MSE(sdf(pc; code), 0), lr 1e-5 / 1e-4 / 5e-4, x0.1 at step 160.  `code` holds P rows; pcs = list of P clouds [Ni,3].  The
+        loss is the SUM over instances of their mean-squared SDF, so every instance sees exactly the gradients (and, Adam being
+        element-wise, exactly the updates) of its own run; the decoder forward / backward run in the HIP library for all P x N
+        queries per step (ls_sdf_decode_train / ls_sdf_backward, split-K off: a row's value does not depend on the batch).
+        The reference snapshots `best_code` with .detach() WITHOUT .clone(), i.e. the snapshot aliases the live parameters and ends
+        up holding the FINAL values whenever the loss improved at least once (min_loss starts at 100): returned here as (code dict
+        of the final values, improved [P] bool) -- an instance that never improved has best_code = None in the reference."""
+        from .. import _lib
+        n_in = self.cfg["shape_priors"]["n_input_point"]
+        pc = self._sample(pcs, n_in)
         params = [{"params": code["z_inv"], "lr": 1e-5}, {"params": code["t"], "lr": 1e-4}, {"params": code["z_so3"], "lr": 5e-4}]
         for p in params:
             p["params"].requires_grad_(True)
         optimizer = torch.optim.Adam(params)
         scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[160], gamma=0.1)
-        loss_fn = torch.nn.MSELoss()
-        min_loss, best_code = 100.0, None
-        for _ in range(n_steps):
-            optimizer.zero_grad()
-            sdf_output = self.model.decoder(pc, None, code, return_sdf=True)
-            loss = loss_fn(sdf_output, torch.zeros_like(sdf_output))
-            loss.backward()
-            optimizer.step()
-            scheduler.step()
-            if loss < min_loss:   # (the snapshot is taken AFTER the step, as in the reference)
-                min_loss = loss.item()
-                best_code = {k: code[k].detach() for k in ("z_inv", "z_so3", "s", "t")}
-            optimizer.zero_grad()
-        return best_code
+        P = pc.shape[0]
+        min_loss = torch.full((P,), 100.0, device=pc.device)
+        improved = torch.zeros(P, dtype=torch.bool, device=pc.device)
+        hip = self.model.hip_model()
+        hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 0)
+        try:
+            for _ in range(n_steps):
+                optimizer.zero_grad()
+                sdf_output = self.model.decoder(pc, None, code, return_sdf=True)
+                per = (sdf_output ** 2).mean(1)                    # MSELoss(sdf, 0) of every instance
+                per.sum().backward()
+                optimizer.step()
+                scheduler.step()
+                better = per.detach() < min_loss                   # (the snapshot is taken AFTER the step, as in the reference)
+                min_loss = torch.where(better, per.detach(), min_loss)
+                improved |= better
+                optimizer.zero_grad()
+        finally:
+            hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 1)
+        return {k: code[k].detach() for k in ("z_inv", "z_so3", "s", "t")}, improved
 
     def _mesh_from_latent(self, latent_code):
         """more_solver.py:37-58: mesh of the canonical shape (t = 0, s = 1), then scaled and moved to the instance pose."""
@@ -192,8 +227,8 @@ class More_Solver:
     def _solve_end2end(self, ref, rescan, optim=False, mesh=None):
         """more_solver.py:246-299: encode both scenes (one batch each), sequential matching, registration of the matched pairs,
         transformed latent codes and (``mesh``, default = whether cfg has a mesh_extractor, as the reference always meshes) their
-        meshes.  ref / rescan: {'pc' [n,3,Nmax], 'pc_mask'}.  optim=False registers all pairs in one batched call; optim=True
-        runs the per-pair optimisation loop like the reference."""
+        meshes.  ref / rescan: {'pc' [n,3,Nmax], 'pc_mask'}.  Both modes register all matched pairs of the
+        scene in one batched call (optim=True: the 400-step refinement in lock-step)."""
         if ref is None:
             return None
         if mesh is None:
@@ -210,9 +245,8 @@ class More_Solver:
                "codes": [None] * len(ref_full), "mesh_lst": [None] * len(ref_full)}
         pairs = [(i, int(j)) for i, j in enumerate(m0.tolist()) if j >= 0]
         if pairs:
-            if optim:
-                Rt = [self._solve_pairwise_registration(ref_full[i][None], res_full[j][None], optim=True) for i, j in pairs]
-                R, t = torch.cat([r for r, _ in Rt], 0), torch.cat([tt for _, tt in Rt], 0)
+            if optim:   # all matched pairs of the scene advance in lock-step (the reference loops over them, more_solver.py:272-282)
+                R, t = self._solve_pairwise_registration_optim_batch([ref_full[i] for i, _ in pairs], [res_full[j] for _, j in pairs])
             else:
                 R, t = self._solve_pairwise_registration_batch([ref_full[i] for i, _ in pairs], [res_full[j] for _, j in pairs])
             T = Rt_to_SE3(R, t)
@@ -296,7 +330,7 @@ def solve_end2end_batch(solver, pairs, mesh=False):
     return outs
 
 
-def _se3_exp(xi):
+def _se3_exp(xi):  # host twin of the retraction in csrc/optim.hip (tests compare both with torch.matrix_exp)
     """exp of the twist (v, omega) in R^6 -> [4,4] (Rodrigues + the left Jacobian for the translation)."""
     v, w = xi[:3], xi[3:]
     th = w.norm()

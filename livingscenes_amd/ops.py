@@ -134,6 +134,52 @@ def icp(X, Y, R0, T0, max_iter=100, rel_rmse_thr=1e-6, flags=DEFAULT_FLAGS):
     return R, T, rmse, iters
 
 
+def se3_transform(g, src):
+    """g [P,3,4] (R | t), src [P,N,3] -> g . src [P,N,3]."""
+    g, src = _f32(g), _f32(src)
+    P, N, _ = src.shape
+    out = torch.empty_like(src)
+    call(src.device, "ls_se3_transform_f32", ptr(g), ptr(src), P, N, ptr(out), stream_ptr(src.device))
+    return out
+
+
+def smooth_l1(sdf, loss=None):
+    """Per-row mean SmoothL1(sdf, 0) of sdf [P,N] -> (loss [P] (added to `loss` if given), d loss / d sdf [P,N])."""
+    sdf = _f32(sdf)
+    P, N = sdf.shape
+    acc = loss is not None
+    if loss is None:
+        loss = torch.empty(P, dtype=torch.float32, device=sdf.device)
+    grad = torch.empty_like(sdf)
+    call(sdf.device, "ls_smooth_l1_f32", ptr(sdf), P, N, int(acc), ptr(loss), ptr(grad), stream_ptr(sdf.device))
+    return loss, grad
+
+
+class Se3Adam:
+    """State of the batched SE(3) Adam of the optimisation-based registration (csrc/optim.hip: se3_adam_step_kernel)."""
+
+    def __init__(self, g0, src, stop_angle, betas=(0.9, 0.999), eps=1e-8):
+        self.src = _f32(src)
+        self.g = _f32(g0).clone()
+        P = self.g.shape[0]
+        dev = self.g.device
+        self.m1 = torch.zeros(P, 6, device=dev)
+        self.m2 = torch.zeros(P, 6, device=dev)
+        self.min_loss = torch.full((P,), 100.0, device=dev)       # more_solver.py:141
+        self.best_g = self.g.clone()
+        self.init_R = self.g[:, :, :3].contiguous().clone()
+        self.active = torch.ones(P, dtype=torch.int32, device=dev)
+        self.query = se3_transform(self.g, self.src)
+        self.betas, self.eps, self.stop_angle, self.step_no = betas, eps, float(stop_angle), 0
+
+    def step(self, grad_query, loss, lr):
+        P, N, _ = self.src.shape
+        call(self.src.device, "ls_se3_adam_step_f32", ptr(self.src), ptr(_f32(grad_query)), ptr(_f32(loss)), P, N, float(lr), self.betas[0],
+             self.betas[1], self.eps, self.step_no, self.stop_angle, ptr(self.g), ptr(self.m1), ptr(self.m2), ptr(self.min_loss),
+             ptr(self.best_g), ptr(self.init_R), ptr(self.active), ptr(self.query), stream_ptr(self.src.device))
+        self.step_no += 1
+
+
 class HipModel:
     """Owner of an ls_model_t (device-resident packed weights) with encode / sdf_decode entry points."""
 
@@ -166,6 +212,10 @@ class HipModel:
         if ws is None or ws.numel() < nbytes:
             ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return ws
+
+    def set_option(self, option, value):
+        """ls_model_set_option (_lib.OPT_*)."""
+        check(load().ls_model_set_option(self._h, int(option), int(value)), "ls_model_set_option")
 
     def profile_begin(self):
         check(load().ls_profile_begin(self._h), "ls_profile_begin")

@@ -13,6 +13,12 @@ def world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
+def _host_staged():
+    """gloo moves all_gather / gather payloads through host memory only (the CPU tests, and the single-GPU dry run of the N > 1
+    path): stage device tensors on the host for the collective and bring the result back.  RCCL ("nccl") takes device tensors."""
+    return dist.get_backend() == "gloo"
+
+
 def shard_range(n_items, rank=None, world_size=None):
     """Contiguous block partition of n_items: rank r gets [lo, hi).  Sizes differ by at most one."""
     if rank is None or world_size is None:
@@ -70,9 +76,12 @@ def all_gather_codes(emb, counts=None):
     mx = max(max(counts), 1)     # at least one (zero) row per message: an all-empty exchange stays a valid collective
     pad = rows.new_zeros(mx, rows.shape[1])
     pad[: rows.shape[0]] = rows
+    dev = pad.device
+    if _host_staged():
+        pad = pad.cpu()
     bufs = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(bufs, pad)
-    return unpack_codes(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0))
+    return unpack_codes(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(dev))
 
 
 def gather_codes(emb, dst=0, counts=None):
@@ -86,11 +95,14 @@ def gather_codes(emb, dst=0, counts=None):
     mx = max(max(counts), 1)
     pad = rows.new_zeros(mx, rows.shape[1])
     pad[: rows.shape[0]] = rows
+    dev = pad.device
+    if _host_staged():
+        pad = pad.cpu()
     bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
-    return unpack_codes(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0))
+    return unpack_codes(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(dev))
 
 
 def sharded_encode(model, x_all):

@@ -56,6 +56,54 @@ def _divergence(x, y, blur, scaling):
     return loss, (d_ba - d_aa) / N
 
 
+def _softmin_b(x, y, pot_y, logw, eps, prev=None, average=False, need_grad=False):
+    """Batched softmin (csrc/optim.hip): x [P,N,3], y [P,M,3], pot_y [P,M] or None, eps [P] (<= 0: pair inactive -> prev)."""
+    P, N, _ = x.shape
+    M = y.shape[1]
+    out = torch.empty(P, N, dtype=torch.float32, device=x.device)
+    grad = torch.empty(P, N, 3, dtype=torch.float32, device=x.device) if need_grad else None
+    call(x.device, "ls_sinkhorn_softmin_batched_f32", ptr(x), ptr(y), ptr(pot_y), float(logw), ptr(eps), ptr(prev), int(average), P, N, M,
+         ptr(out), ptr(grad), stream_ptr(x.device))
+    return (out, grad) if need_grad else out
+
+
+def divergence_batch(x, y, blur=0.05, scaling=0.5):
+    """Debiased Sinkhorn divergence of P cloud pairs in lock-step: x [P,N,3] (moving), y [P,M,3] -> (loss [P], d loss / d x [P,N,3]).
+    Same definition as _divergence pair by pair: every pair follows ITS OWN epsilon schedule (it depends on the pair's bounding-box
+    diameter, so the schedules differ in length); a pair whose schedule has ended is passed through unchanged by the kernel
+    (eps <= 0), and one host read per call (the longest schedule) sizes the loop."""
+    x, y = x.detach().float().contiguous(), y.detach().float().contiguous()
+    P, N, _ = x.shape
+    M = y.shape[1]
+    both = torch.cat([x, y], 1)
+    diam = (both.max(1)[0] - both.min(1)[0]).norm(dim=1).clamp_min(1e-6).double()                      # [P]
+    nj = torch.ceil((math.log(blur) - diam.log()) / math.log(scaling)).clamp_min(0).long()       # len(np.arange(2 log d, 2 log blur, 2 log scaling))
+    lmax = int(nj.max()) + 2                                                                           # the one host read
+    k = torch.arange(lmax, device=x.device)[None]                                                      # [1,L]
+    e_mid = (2 * diam.log()[:, None] + (k - 1).clamp_min(0) * (2 * math.log(scaling))).exp()           # d^2 scaling^(2 (k - 1))
+    eps_tab = torch.where(k == 0, (diam ** 2)[:, None], e_mid)
+    eps_tab = torch.where(k == (nj + 1)[:, None], torch.full_like(eps_tab, blur ** 2), eps_tab)
+    eps_tab = torch.where(k > (nj + 1)[:, None], torch.zeros_like(eps_tab), eps_tab).float().t().contiguous()   # [L,P]; 0 = schedule ended
+    a_log, b_log = -math.log(N), -math.log(M)
+    e0 = eps_tab[0]
+    g_ab, f_ba = _softmin_b(y, x, None, a_log, e0), _softmin_b(x, y, None, b_log, e0)
+    f_aa, g_bb = _softmin_b(x, x, None, a_log, e0), _softmin_b(y, y, None, b_log, e0)
+    for i in range(lmax):
+        e = eps_tab[i]
+        f_ba_n = _softmin_b(x, y, g_ab, b_log, e, prev=f_ba, average=True)
+        g_ab_n = _softmin_b(y, x, f_ba, a_log, e, prev=g_ab, average=True)
+        f_aa_n = _softmin_b(x, x, f_aa, a_log, e, prev=f_aa, average=True)
+        g_bb_n = _softmin_b(y, y, g_bb, b_log, e, prev=g_bb, average=True)
+        f_ba, g_ab, f_aa, g_bb = f_ba_n, g_ab_n, f_aa_n, g_bb_n
+    last = torch.full((P,), blur ** 2, dtype=torch.float32, device=x.device)    # every schedule ends at blur^2
+    f_ba_l, d_ba = _softmin_b(x, y, g_ab, b_log, last, need_grad=True)
+    g_ab_l = _softmin_b(y, x, f_ba, a_log, last)
+    f_aa_l, d_aa = _softmin_b(x, x, f_aa, a_log, last, need_grad=True)
+    g_bb_l = _softmin_b(y, y, g_bb, b_log, last)
+    loss = (f_ba_l - f_aa_l).mean(1) + (g_ab_l - g_bb_l).mean(1)
+    return loss, (d_ba - d_aa) / N
+
+
 class _Sinkhorn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, blur, scaling):

@@ -1,5 +1,6 @@
 """More_Solver._solve_pairwise_registration(optim=True) (registration half; manifold Adam and Sinkhorn follow this
-build's definitions, parity unpinned): released settings (400 steps, lr 0.05, 1024 points, released decoder) on synthetic pairs."""
+build's definitions, parity unpinned): released settings (400 steps, lr 0.05, 1024 points, released decoder) on synthetic pairs,
+P pairs in lock-step (csrc/optim.hip).  usage: python scripts/optim_registration_microbench.py [P ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -14,16 +15,17 @@ sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), syn
 cfg = {"shape_priors": {"n_input_point": 1024}, "fps": {"n_init": 1},
        "registration": {"step_size": {"so3": 0.05}, "n_steps": 400, "early_stop_threshold": 10}}
 solver = More_Solver(cfg, model=sp)
-sc = synth.make_scene_pair(4, 1024, seed=5, noise=0.005)
-gt = concatenate(sc["rescan_T"][:, :3], inverse(sc["ref_T"][:, :3])).to(dev)
-res = []
-for i in range(4):
-    pc1, pc2 = sc["ref"][i:i + 1].to(dev), sc["rescan"][i:i + 1].to(dev)
-    R0, t0 = solver._solve_pairwise_registration(pc1, pc2, optim=False)
+if os.environ.get("PIECES"):
+    cfg["registration"]["decoder_bf16_pieces"] = int(os.environ["PIECES"])
+for P in [int(a) for a in sys.argv[1:]] or [1, 8, 64]:
+    sc = synth.make_scene_pair(P, 1024, seed=5, noise=0.005)
+    gt = concatenate(sc["rescan_T"][:, :3], inverse(sc["ref_T"][:, :3])).to(dev)
+    p1, p2 = [sc["ref"][i].to(dev) for i in range(P)], [sc["rescan"][i].to(dev) for i in range(P)]
+    R0, t0 = solver._solve_pairwise_registration_batch(p1, p2)
     torch.cuda.synchronize(); t_0 = time.perf_counter()
-    R1, t1 = solver._solve_pairwise_registration(pc1, pc2, optim=True)
+    R1, t1, info = solver._solve_pairwise_registration_optim_batch(p1, p2, return_info=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t_0
-    res.append((float(rotation_error(R0, gt[i:i + 1, :, :3])), float(rotation_error(R1, gt[i:i + 1, :, :3])),
-                float(translation_error(t1, gt[i:i + 1, :, 3:4])), dt))
-for r in res:
-    print(f"pair: RRE Kabsch+ICP {r[0]:.3f} deg -> optim+ICP {r[1]:.3f} deg, RTE {r[2]*1e3:.2f} mm, {r[3]*1e3:.0f} ms = {r[3]/400*1e3:.2f} ms/step")
+    e0, e1 = rotation_error(R0, gt[:, :, :3]).reshape(-1), rotation_error(R1, gt[:, :, :3]).reshape(-1)
+    print(f"P = {P}: {dt:.2f} s for {info['steps']} steps = {dt / info['steps'] * 1e3:.2f} ms/step = {dt / P * 1e3:.1f} ms per pair; "
+          f"median RRE Kabsch+ICP {float(e0.median()):.3f} deg -> optim+ICP {float(e1.median()):.3f} deg; "
+          f"median RTE {float(translation_error(t1, gt[:, :, 3:4]).median()) * 1e3:.2f} mm; pairs stopped early {int((info['active'] == 0).sum())}")

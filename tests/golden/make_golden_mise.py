@@ -15,7 +15,8 @@ sys.path.insert(0, "/tmp/mise_build")
 import mise as ref_mise  # noqa: E402  (the reference's Cython module)
 
 sys.path.insert(0, __file__.rsplit("/tests/", 1)[0])
-from livingscenes_amd.mise_fields import FIELDS  # noqa: E402
+sys.path.insert(0, __file__.rsplit("/tests/", 1)[0] + "/tests")
+from mise_fields import FIELDS  # noqa: E402
 
 
 def drive(field, res0, depth, thr, box=1.1):

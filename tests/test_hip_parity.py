@@ -471,10 +471,40 @@ def test_kabsch_vs_golden(golden):
     assert (torch.det(R.cpu()) > 0.999).all()  # the reflection cases (16..31) still yield proper rotations
     Rw, tw, resw = ops.kabsch(x1, x2, torch.from_numpy(g["kab_w"]).to(_dev()))
     assert relerr(Rw, g["kab_Rw"]) < TOL and relerr(tw, g["kab_tw"]) < TOL and relerr(resw, g["kab_resw"]) < TOL
-    # degenerate input (all points identical -> zero covariance): torch.svd succeeds (U = V = I): identity, status RANK0
+    # degenerate input (all points identical): the covariance is zero up to the eps of the weight normalisation (rank 0 or a
+    # rank-1 remnant of ~1e-15).  torch.svd SUCCEEDS on such a matrix, so the reference returns a rotation with flag False; here:
+    # identity (the smallest member of the least-squares family), status RANK0 / RANK1, and the high-level flag stays False
     z = torch.ones(2, 16, 3, device=_dev())
     R0, t0, _, fl0 = ops.kabsch(z, z, return_flags=True)
-    assert (fl0 == 2).all() and torch.equal(R0.cpu(), torch.eye(3).repeat(2, 1, 1))
+    assert ((fl0 == 1) | (fl0 == 2)).all() and torch.allclose(R0.cpu(), torch.eye(3).repeat(2, 1, 1), atol=1e-6)
+    zero = torch.zeros(2, 16, 3, device=_dev())
+    _, _, _, flz = ops.kabsch(zero, zero, return_flags=True)
+    assert (flz == 2).all()
+    from livingscenes_amd.lib_more.pose_estimation import kabsch_transformation_estimation
+    assert not bool(kabsch_transformation_estimation(z, z)[3])
+    bad = z.clone()
+    bad[0, 0, 0] = float("nan")                       # non-finite input: the reference's SVD-exception branch -> identity, flag True
+    Rn, tn, _, fn = kabsch_transformation_estimation(bad, z)
+    assert bool(fn) and torch.equal(Rn[0].cpu(), torch.eye(3)) and float(tn[0].abs().max()) == 0.0
+    # a rank-1 covariance (all points on one line): a proper rotation that maps the line direction correctly
+    line = torch.linspace(-1, 1, 16, device=_dev())[None, :, None] * torch.tensor([[[1.0, 2.0, -1.0]]], device=_dev())
+    Rz = torch.tensor([[[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]], device=_dev())
+    moved = line @ Rz.transpose(1, 2) + 0.5
+    R1, t1, res1, fl1 = ops.kabsch(line, moved, return_flags=True)
+    assert int(fl1[0]) == 1 and abs(float(torch.det(R1[0].cpu())) - 1) < 1e-5 and float(res1.max()) < 1e-5
+    # non-default weight paths (pose_estimation.py:58-66): best_k with weights=None, w_threshold on NORMALISED weights without renormalising
+    from oracle import more
+    g2 = torch.Generator().manual_seed(4)
+    a, w = torch.randn(3, 40, 3, generator=g2), torch.rand(3, 40, generator=g2)
+    bq = a @ torch.linalg.qr(torch.randn(3, 3, generator=g2))[0].T + 0.3
+    Rk, tk, _, _ = kabsch_transformation_estimation(a.to(_dev()), bq.to(_dev()), best_k=10)       # weights=None + best_k: ones (:49-50)
+    assert Rk.shape == (3, 3, 3)
+    wn = w / (w.sum(1, keepdim=True) + 1e-7)
+    thr = float(wn.median())
+    wt = torch.where(wn < thr, torch.zeros_like(wn), wn)
+    Rr, tr, _, _ = more.kabsch_transformation_estimation(a, bq, wt, normalize_w=False)
+    Rh, th, _, _ = kabsch_transformation_estimation(a.to(_dev()), bq.to(_dev()), w.to(_dev()), w_threshold=thr)
+    assert relerr(Rh, Rr) < TOL and relerr(th, tr) < TOL
 
 
 def test_residual_matrix_and_eq_matchers(golden):
@@ -490,24 +520,59 @@ def test_residual_matrix_and_eq_matchers(golden):
 
 
 def test_icp_vs_oracle():
+    """ls_icp_f32 vs the oracle's restatement of pytorch3d.ops.iterative_closest_point (PARITY UNPINNED: pytorch3d is absent),
+    problem by problem (the kernel stops every problem on its own, i.e. it equals independent batch-1 calls).  ICP is a
+    fixed-point iteration on a DISCRETE nearest-neighbour assignment: the two sides agree to 1e-4 exactly when they end on the
+    same assignment, and a single neighbour that flips in the last iterations (distances equal to ~1e-7) moves the least-squares
+    pose by ~1/n.  So: iteration counts within 1, final assignments >= 99.5 % equal, pose within 1e-4 where the assignment is
+    identical (required for most problems) and within 1e-3 otherwise."""
     from livingscenes_amd import ops
     from oracle import more
-    sc = synth.make_scene_pair(4, 1024, seed=3, noise=0.002)
+    P = 6
+    sc = synth.make_scene_pair(P, 1024, seed=3, noise=0.002)
     X, Y = sc["ref"], sc["rescan"]
     gt = more.se3_concatenate(sc["rescan_T"][:, :3], more.se3_inverse(sc["ref_T"][:, :3]))
     rng = np.random.default_rng(1)
     # perturbed ground truth as initial guess (column convention) -> row convention for ICP
-    dR = torch.from_numpy(np.stack([synth._rand_rot(rng) for _ in range(4)]).astype(np.float32))
+    dR = torch.from_numpy(np.stack([synth._rand_rot(rng) for _ in range(P)]).astype(np.float32))
     dR = torch.matrix_exp(0.05 * (dR - dR.transpose(1, 2)))
     R0 = (dR @ gt[:, :, :3]).transpose(1, 2).contiguous()
     T0 = (gt[:, :, 3] + 0.02).contiguous()
-    Rr, Tr, rmse_r, it_r, _ = more.iterative_closest_point(X, Y, R0, T0)
     R, T, rmse, iters = ops.icp(X.to(_dev()), Y.to(_dev()), R0.to(_dev()), T0.to(_dev()))
-    # per-problem stopping (HIP) vs all-problem stopping (oracle batch): compare problem by problem
-    for p in range(4):
+    R, T, iters = R.cpu(), T.cpu(), iters.cpu()
+    exact = 0
+    for p in range(P):
         Rp, Tp, rp, ip, _ = more.iterative_closest_point(X[p:p + 1], Y[p:p + 1], R0[p:p + 1], T0[p:p + 1])
-        assert relerr(R[p:p + 1], Rp) < 1e-3 and relerr(T[p:p + 1], Tp) < 1e-3, p
+        assert abs(int(iters[p]) - ip) <= 1, (p, int(iters[p]), ip)
+        nn_h = more._nn1(X[p:p + 1] @ R[p:p + 1] + T[p:p + 1, None], Y[p:p + 1])
+        nn_o = more._nn1(X[p:p + 1] @ Rp + Tp[:, None], Y[p:p + 1])
+        agree = float((nn_h == nn_o).float().mean())
+        assert agree >= 0.995, (p, agree)
+        tol = 1e-4 if agree == 1.0 else 1e-3
+        exact += agree == 1.0
+        assert relerr(R[p:p + 1], Rp) < tol and relerr(T[p:p + 1], Tp) < tol, (p, agree)
         assert abs(float(rmse[p]) - float(rp)) < 1e-4 * max(float(rp), 1e-3)
+    assert exact >= P - 1, f"only {exact} of {P} problems ended on the oracle's nearest-neighbour assignment"
+
+
+def test_deepsdf_decoder_direct_forward_vs_oracle():
+    """DeepSDF_Decoder.forward(input [B,M,513], 'val') -- the reference class's own call surface (deepsdf_decoder.py:78-123), not
+    only the fused FieldWrapper route -- against oracle.net.decoder_forward, released widths and the small config."""
+    from livingscenes_amd.deepsdf_decoder import DeepSDF_Decoder
+    from oracle import net
+    for dcfg in (synth.small_decoder_cfg(), synth.default_decoder_cfg()):
+        dw = synth.make_decoder_weights(dcfg, 2)
+        dec = DeepSDF_Decoder(**dcfg)
+        dec.load_state_dict(dw, strict=True)
+        dec = dec.to(_dev())
+        g = torch.Generator().manual_seed(9)
+        inp = torch.randn(2, 257, dcfg["latent_size"] + dcfg["pe_dim"], generator=g) * 0.2
+        ref = net.decoder_forward(dw, dcfg, inp)
+        with torch.no_grad():
+            out = dec(inp.to(_dev()), "val")
+        assert out.shape == (2, 257) and relerr(out, ref) < TOL
+    with pytest.raises(NotImplementedError):
+        dec(inp.to(_dev()), "train")
 
 
 def test_sdf_dense_grid_mise_resolution():

@@ -15,7 +15,7 @@ def _dev():
 
 
 def relerr(a, b):
-    a, b = a.detach().cpu().double(), (b.detach().cpu() if torch.is_tensor(b) else torch.as_tensor(b)).double()
+    a, b = ((v.detach().cpu() if torch.is_tensor(v) else torch.as_tensor(v)).double() for v in (a, b))
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
@@ -241,7 +241,11 @@ def test_more_solver_matching_registration_end2end(small_prior):
     Rk, tk, _, _ = more.kabsch_transformation_estimation(c1["z_so3"] + c1["t"], c2["z_so3"] + c2["t"])
     Ri, Ti, _, _, _ = more.iterative_closest_point(p1, p2, Rk.transpose(1, 2).contiguous(), tk.squeeze(2))
     assert R.shape == (1, 3, 3) and t.shape == (1, 3, 1)
-    assert relerr(R, Ri.transpose(1, 2)) < 1e-3 and relerr(t, Ti.unsqueeze(2)) < 1e-3
+    # same nearest-neighbour assignment at the fixed point => same least-squares pose, to 1e-4 (see test_icp_vs_oracle)
+    nn_h = more._nn1(p1 @ R.cpu().transpose(1, 2) + t.cpu().transpose(1, 2), p2)
+    nn_o = more._nn1(p1 @ Ri + Ti[:, None], p2)
+    tol = 1e-4 if torch.equal(nn_h, nn_o) else 1e-3
+    assert relerr(R, Ri.transpose(1, 2)) < tol and relerr(t, Ti.unsqueeze(2)) < tol
     with pytest.raises(KeyError):   # optim=True needs cfg['registration'] (test_optim_registration_refines_the_pose covers it)
         solver._solve_pairwise_registration(ref_x[:1].to(d), res_x[:1].to(d), optim=True)
     # --- matching on encoded scenes, every method returns int64 maps consistent with the oracle
@@ -297,7 +301,7 @@ def test_flyingshape_style_harness_vs_oracle(small_prior):
     m = harness.eval_matching(scenes, solver)
     r = harness.eval_relocalization(scenes, solver, icp=False)
     ok = tot = 0
-    rre = []
+    rre, poses = [], []
     for sc in scenes:
         cr = net.shape_prior_encode(ew, ecfg, sc["ref"].transpose(1, 2).contiguous())
         cs = net.shape_prior_encode(ew, ecfg, sc["rescan"].transpose(1, 2).contiguous())
@@ -307,8 +311,14 @@ def test_flyingshape_style_harness_vs_oracle(small_prior):
         gt = more.se3_concatenate(sc["rescan_T"][:, :3], more.se3_inverse(sc["ref_T"][:, :3]))
         e = more.rotation_error(R, gt[:, :, :3]).reshape(-1)
         rre.append(torch.minimum(torch.minimum(e, (180 - e).abs()), (90 - e).abs()))
+        poses.append(torch.cat([R, t], 2))
     assert abs(m["object_recall"] - 100.0 * ok / tot) < 1e-9
-    assert np.allclose(r["rre"], torch.cat(rre).numpy(), atol=2e-2)  # degrees; acos amplifies fp32 round-off near 0/180
+    # parity at the level of the rotation matrices / translations (north_star: pose within 1e-4 rel) ...
+    want = torch.cat(poses).numpy()
+    assert relerr(r["poses"][:, :, :3], want[:, :, :3]) < 1e-4 and relerr(r["poses"][:, :, 3], want[:, :, 3]) < 1e-4
+    # ... the angle in degrees is an ill-conditioned function of the matrix near 0 (acos'(1) is infinite): an R error of 1e-6
+    # moves a 0.02-degree angle by ~0.01 degree, so the DERIVED metric is compared at 2e-2 degrees
+    assert np.allclose(r["rre"], torch.cat(rre).numpy(), atol=2e-2)
 
 
 # ------------------------------------------------------------------------------------------------ MISE (first half)
@@ -322,7 +332,7 @@ def test_mise_device_matches_reference_golden():
     """csrc/mise.hip through the reference's MISE surface (query / update / to_dense) on the golden cases recorded from the
     reference's Cython MISE: the same lattice points are queried in every round and the dense grid is bit-identical."""
     from livingscenes_amd.mesh_extractor2 import MISE
-    from livingscenes_amd.mise_fields import FIELDS
+    from mise_fields import FIELDS
     g = _golden_mise()
     for key in sorted(k[:-4] for k in g.files if k.endswith("_cfg")):
         res0, depth, thr = g[key + "_cfg"]
@@ -525,6 +535,86 @@ def test_optim_registration_refines_the_pose(small_prior):
 
 
 @pytest.mark.gpu
+def test_optim_registration_batch_equals_per_pair(small_prior):
+    """_solve_pairwise_registration_optim_batch (P pairs in lock-step, one launch sequence per Adam step) == the same function pair
+    by pair, to 1e-5: clouds of different sizes and extents (different epsilon schedules of the Sinkhorn loop), both directions of
+    the shared-code choice, and the info the kernel keeps per pair (min loss, stop flags)."""
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    sp, _ = small_prior
+    dev = _dev()
+    cfg = {"shape_priors": {"n_input_point": 128}, "fps": {"n_init": 1},
+           "registration": {"step_size": {"so3": 0.01}, "n_steps": 24, "early_stop_threshold": 10}}
+    solver = More_Solver(cfg, model=sp)
+    p1, p2 = [], []
+    for i, (n, scale) in enumerate(((300, 1.0), (128, 0.4), (500, 2.5), (222, 1.3), (150, 0.7))):
+        sc = synth.make_scene_pair(1, n, seed=90 + i, noise=0.002)
+        p1.append((sc["ref"][0] * scale).to(dev))
+        p2.append((sc["rescan"][0] * scale).to(dev))
+    R, t, info = solver._solve_pairwise_registration_optim_batch(p1, p2, return_info=True)
+    assert R.shape == (5, 3, 3) and t.shape == (5, 3, 1) and info["steps"] == 24
+    for i in range(5):
+        Ri, ti, inf_i = solver._solve_pairwise_registration_optim_batch([p1[i]], [p2[i]], return_info=True)
+        assert bool(inf_i["reverse"][0]) == bool(info["reverse"][i])
+        assert relerr(info["pre_icp"][i:i + 1], inf_i["pre_icp"]) < 1e-5, i          # the refined pose before ICP
+        assert abs(float(info["min_loss"][i]) - float(inf_i["min_loss"][0])) < 1e-5 * max(abs(float(inf_i["min_loss"][0])), 1e-3)
+        assert relerr(R[i:i + 1], Ri) < 1e-4 and relerr(t[i:i + 1], ti) < 1e-4, i
+    # the single-pair entry point of the reference's signature is the same path
+    Rs, ts = solver._solve_pairwise_registration(p1[2][None], p2[2][None], optim=True)
+    assert relerr(Rs, R[2:3]) < 1e-4
+    # geodesic early stop: a threshold of 0 rad freezes every pair after its first step
+    solver.cfg["registration"]["early_stop_threshold"] = 0.0
+    _, _, info0 = solver._solve_pairwise_registration_optim_batch(p1[:2], p2[:2], return_info=True)
+    assert info0["steps"] == 16 and not bool(info0["active"].any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,N,M", [(3, 256, 300), (2, 1024, 1024)])
+def test_sinkhorn_divergence_batch_vs_oracle(P, N, M):
+    """sinkhorn.divergence_batch (per-pair epsilon schedules inside one launch sequence) against the torch-CPU restatement pair by
+    pair (UNPINNED w.r.t. geomloss): loss and gradient; clouds of different extent so that the schedules differ in length."""
+    from livingscenes_amd.sinkhorn import divergence_batch
+    from oracle import sinkhorn as osk
+    g = torch.Generator().manual_seed(P * 1000 + N)
+    xs, ys = [], []
+    for p in range(P):
+        scale = (0.3, 1.0, 3.0)[p % 3]
+        y = (torch.rand(M, 3, generator=g) - 0.5) * scale
+        x = y[torch.randint(0, M, (N,), generator=g)] + 0.05 * scale * torch.randn(N, 3, generator=g)
+        xs.append(x), ys.append(y)
+    loss, grad = divergence_batch(torch.stack(xs).to(_dev()), torch.stack(ys).to(_dev()))
+    for p in range(P):
+        xr = xs[p].clone().requires_grad_(True)
+        ref = osk.sinkhorn_divergence(xr, ys[p])
+        ref.backward()
+        assert abs(float(loss[p]) - float(ref)) < 2e-4 * max(abs(float(ref)), 1e-6) + 2e-7, p
+        assert relerr(grad[p], xr.grad) < 5e-4, p
+
+
+@pytest.mark.gpu
+def test_optimize_code_batch_equals_per_instance(small_prior):
+    """_optimize_code_batch (P instances per Adam step) == _optimize_code instance by instance."""
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    sp, _ = small_prior
+    dev = _dev()
+    solver = More_Solver({"shape_priors": {"n_input_point": 128}}, model=sp)
+    clouds = [synth.make_instances(1, n, seed=50 + i)[0].T.contiguous().to(dev) for i, n in enumerate((200, 128, 321))]
+    x = torch.stack([solver._sample([c], 128)[0] for c in clouds]).transpose(1, 2).contiguous()
+    with torch.no_grad():
+        code = sp.encode(x)
+    start = {k: v.detach().clone() for k, v in code.items()}
+    best, improved = solver._optimize_code_batch({k: v.detach().clone() for k, v in start.items()}, clouds, n_steps=30)
+    assert bool(improved.all())
+    for i, c in enumerate(clouds):
+        one = {k: v[i:i + 1].detach().clone() for k, v in start.items()}
+        pc = c.T.contiguous()
+        mask = torch.ones(1, c.shape[0], dtype=torch.bool, device=dev)
+        bi = solver._optimize_code(one, pc, mask, n_steps=30)
+        for k in ("z_inv", "z_so3", "t"):
+            moved = float((bi[k] - start[k][i:i + 1]).abs().max())
+            assert moved > 0 and float((best[k][i:i + 1] - bi[k]).abs().max()) < 1e-5 * max(moved, 1e-6) + 1e-9, (i, k)
+
+
+@pytest.mark.gpu
 def test_solve_end2end_batch_equals_per_pair(small_prior):
     """lib_more.more_solver.solve_end2end_batch (all scans / pairs of several scenes in single launches) returns what
     _solve_end2end returns pair by pair: same matches, same registrations, same transformed codes."""
@@ -584,3 +674,57 @@ def test_ragged_decode_and_batched_mise_equal_per_instance(small_prior):
     grids = gen.eval_grid_batch(canon, sp.decoder)
     for b in range(3):
         assert np.array_equal(grids[b], gen.eval_grid({k: v[b:b + 1] for k, v in canon.items()}, sp.decoder)), b
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU path on one device
+_SHARD_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from livingscenes_amd import sharding, synth
+from livingscenes_amd.model_utils import Shape_Prior
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% int(sys.argv[1]), rank=int(sys.argv[2]), world_size=int(sys.argv[3]))
+rank = dist.get_rank()
+dev = torch.device("cuda:0")                       # both ranks share the one device of the test box: a logic check, not a measurement
+ecfg, dcfg = synth.small_encoder_cfg(), synth.small_decoder_cfg()
+if rank == 0:
+    ew, dw = synth.make_encoder_weights(ecfg, 4), synth.make_decoder_weights(dcfg, 4)
+else:                                              # other ranks start from zeros and receive rank 0's weights
+    ew = {k: torch.zeros(s) for k, s in synth.encoder_param_shapes(ecfg).items()}
+    dw = {k: torch.zeros_like(v) for k, v in synth.make_decoder_weights(dcfg, 4).items()}
+sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=dev)
+sharding.broadcast_weights(sp, src=0)
+for n in (7, 2, 1):                                # ragged shards (4 + 3), one instance per rank, and an EMPTY shard on rank 1
+    x = synth.make_instances(n, 128, seed=30 + n).to(dev)
+    with torch.no_grad():
+        allc = sharding.sharded_encode(sp, x)
+        whole = sp.encode(x)
+    for k in ("z_so3", "z_inv", "s", "t"):
+        assert allc[k].shape == whole[k].shape, (n, k, allc[k].shape, whole[k].shape)
+        assert torch.equal(allc[k], whole[k]), (n, k)   # sharded == unsharded, bit for bit (a row's code does not depend on its batch)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_encode_world_size_2_on_one_device(tmp_path):
+    """The N > 1 path of SURVEY 8(e) on the single-GPU test box: two processes (gloo rendezvous, both on cuda:0) broadcast the
+    weights, encode their block of the instance list and all-gather the codes; every rank must end up with exactly the codes of
+    the unsharded encode -- including ragged shards and an empty one (fewer instances than ranks)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER % os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(port), str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"rank {r} ok" in out, err[-3000:]

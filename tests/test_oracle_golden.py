@@ -134,7 +134,7 @@ def test_mise_oracle_matches_reference_golden():
     tests/golden/make_golden_mise.py): identical query SETS in every round, identical dense grid."""
     import os
     from oracle import mise as om
-    from livingscenes_amd.mise_fields import FIELDS
+    from mise_fields import FIELDS
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mise.npz"))
     keys = sorted(k[:-4] for k in g.files if k.endswith("_cfg"))
     assert len(keys) >= 6
