@@ -191,6 +191,9 @@ void ls_model_destroy(ls_model_t* m);
 #define LS_OPT_SDF_TRAIN_SPLITK 1 /* [1] split-K in the GEMMs of ls_sdf_decode_train / ls_sdf_backward when the problem under-fills the chip
                                      (one 1024-point cloud); 0 = never: a row's values do not depend on the size of the call (batched == per pair) */
 #define LS_OPT_SDF_BF16X2 2       /* [0, or LS_SDF_BF16X2 in the environment] decoder products as two-piece bf16 splits (2^-16 per product, ~1.5x) */
+#define LS_OPT_ENCODE_GRAPH 3     /* [0, or LS_ENCODE_GRAPH in the environment] ls_encode replays a captured hipGraph of its ~170 launches (one per
+                                     (workspace, B, N, flags, stream); needs a non-NULL stream; profiled / traced calls always enqueue directly).
+                                     Off by default: on ROCm 7.2 the replay measured slower than direct enqueue (22.2k vs 29.6k obj/s, one step in flight) */
 int ls_model_set_option(ls_model_t* m, int option, int value);
 
 /* ------------------------------------------------------------------------------------------------
@@ -200,6 +203,8 @@ int ls_model_set_option(ls_model_t* m, int option, int value);
 /* Shape_Prior.encode(x), model_utils.py:165-197, = prologue + VecDGCNN_att.forward
  * (vec_dgcnn_atten.py:177-252) + epilogue (t = center + centroid, s = scale_0 * pred_scale).
  *   x [B,3,N] -> z_so3 [B,c_dim,3], z_inv [B,c_dim], s [B], t [B,3]
+ * Host cost: ~170 launches (0.7 ms of host time per 64-instance call).  With LS_OPT_ENCODE_GRAPH the sequence is captured into a hipGraph
+ * on first use per (workspace, B, N, flags, stream) and replayed afterwards (x and the outputs may move between calls).
  * trace_knn / trace_fps (nullable): per-layer k-NN / FPS indices for the parity tests, packed
  * back to back: knn layer i at offset sum_{j<i} B*Nd_j*K (int32), fps level l at sum B*Nd_l.
  * If pre_normalised != 0, x is taken as already centred/scaled (prologue skipped, centroid 0, scale_0 1):

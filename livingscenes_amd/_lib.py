@@ -16,7 +16,7 @@ FLAG_CONTRACT_FMA = 1
 FLAG_KNN_MFMA_FILTER = 2
 FLAG_KNN_VALU_ONLY = 4
 FLAG_KABSCH_RAW_WEIGHTS = 8
-OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2 = 1, 2
+OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2, OPT_ENCODE_GRAPH = 1, 2, 3
 KABSCH_OK, KABSCH_RANK1, KABSCH_RANK0, KABSCH_NONFINITE = 0, 1, 2, 3
 
 

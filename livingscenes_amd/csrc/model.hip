@@ -86,6 +86,14 @@ struct ls_model {
     int hint_policy = 0;           // LS_KNN_HINTS: 0 "mixed" (default) = previous-layer lists for the C = 32 layers, the sweep's own
                                    // auto hints elsewhere; 1 "prev" = previous-layer lists wherever they exist (composed after a
                                    // down-sampling layer); 2 "auto" = never use the previous layer
+    // captured launch sequences of ls_encode, one per (workspace, B, N, mode): OPT-IN (LS_ENCODE_GRAPH=1 / ls_model_set_option).
+    // Measured on MI355X / ROCm 7.2 (round 2, bench.py, B = 64): replaying the ~170-node graph costs the host MORE than enqueueing
+    // the kernels directly -- one step in flight 22.2k obj/s (2.53 ms of host time per step) vs 29.6k (1.98 ms) direct; eight steps in
+    // flight 38.1k vs 39.4k -- so the direct path stays the default.
+    struct EncGraph { void* ws; size_t ws_bytes; int B, N, pre; unsigned flags; hipStream_t st; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<EncGraph> graphs;
+    bool use_graph = false;
+    bool graph_broken = false;     // a capture / instantiate failed once on this handle: stay on the direct path
     int debug_layers = -1;         // LS_DEBUG_LAYERS=n: ls_encode stops after n layers (outputs undefined) and prints the workspace plan:
                                    // race hunting by comparing workspaces (scripts/diag/)
     bool fps_side = true;          // LS_FPS_SIDE=0 runs the FPS chain on the caller's stream (A/B timing, race hunting)
@@ -127,7 +135,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_hint, o_inv, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_hint, o_inv, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -202,6 +210,9 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_Tc = take((size_t)B * p.NP * 3 * p.Cdp * 4);
     maxGws = std::max(maxGws, gemm_scratch_floats(B * p.NP * 3, p.Cdp, p.Co[p.L - 1]));
     p.o_gws = take(maxGws * 4 + 256);
+    // staging of the captured-graph path: the graph reads x from / writes the codes to FIXED addresses inside the workspace
+    p.o_xin = take((size_t)B * 3 * N * 4);
+    p.o_out = take((size_t)B * (4 * (size_t)d.c_dim + 4) * 4);
     p.total = off;
     return LS_OK;
 }
@@ -379,6 +390,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     m->d = *desc;
     if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
     if (const char* ev = getenv("LS_DEBUG_LAYERS")) m->debug_layers = atoi(ev);
+    if (const char* ev = getenv("LS_ENCODE_GRAPH")) m->use_graph = atoi(ev) != 0;
     if (const char* ev = getenv("LS_FPS_SIDE")) m->fps_side = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_SEEDS")) m->seed_knn = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_HINTS")) m->hint_policy = !strcmp(ev, "prev") ? 1 : (!strcmp(ev, "auto") ? 2 : 0);
@@ -412,6 +424,7 @@ void ls_model_destroy(ls_model_t* m) {
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
@@ -422,6 +435,7 @@ int ls_model_set_option(ls_model_t* m, int option, int value) {
     switch (option) {
         case LS_OPT_SDF_TRAIN_SPLITK: m->train_splitk = value != 0; return LS_OK;
         case LS_OPT_SDF_BF16X2: m->sdf_bf16x2 = value != 0; return LS_OK;
+        case LS_OPT_ENCODE_GRAPH: m->use_graph = value != 0; return LS_OK;
         default: set_error("model_set_option: unknown option %d", option); return LS_ERR_INVALID;
     }
 }
@@ -433,18 +447,13 @@ size_t ls_encoder_workspace_bytes(const ls_model_t* m, int B, int N) {
     return p.total;
 }
 
-int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, unsigned flags, float* z_so3, float* z_inv,
-              float* s_out, float* t_out, int32_t* trace_knn, int32_t* trace_fps, void* workspace, size_t workspace_bytes,
-              void* stream) {
-    LS_REQUIRE(m && x && z_so3 && z_inv && s_out && t_out && workspace, "encode: null argument");
-    LS_REQUIRE(B > 0 && N >= 16, "encode: need B>0, N>=16 (B=%d N=%d)", B, N);
+}  // extern "C"
+
+// the launch sequence of Shape_Prior.encode on `st` (+ the handle's side streams, forked from and joined back into `st`)
+static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B, int N, int pre_normalised, unsigned flags, float* z_so3,
+                          float* z_inv, float* s_out, float* t_out, int32_t* trace_knn, int32_t* trace_fps, void* workspace, hipStream_t st) {
     const ls_model_desc& d = m->d;
-    EncPlan p;
-    int rc = make_plan(d, B, N, p);
-    if (rc != LS_OK) return rc;
-    if (workspace_bytes < p.total) { set_error("encode: workspace %zu < required %zu", workspace_bytes, p.total); return LS_ERR_WORKSPACE; }
-    LS_REQUIRE(p.Ns[p.L - 1] >= 16 || true, "unreachable");
-    hipStream_t st = (hipStream_t)stream;
+    int rc = LS_OK;
     char* ws = (char*)workspace;
     auto F = [&](size_t o) { return (float*)(ws + o); };
     auto I = [&](size_t o) { return (int32_t*)(ws + o); };
@@ -564,6 +573,70 @@ int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, u
     // ---- tail
     return encoder_tail(m, cur, B, p.NP, F(p.o_Tc), F(p.o_gws), pre_normalised ? nullptr : centroid, pre_normalised ? nullptr : scale0,
                         z_so3, z_inv, s_out, t_out, st);
+}
+
+namespace ls { int scatter_codes_launch(const float* packed, int B, int c, float* z_so3, float* z_inv, float* s, float* t, hipStream_t st); }
+
+// One encode = ~170 kernel launches, 1.35 ms of host time per 64-instance step in round 1 (the GPU needs 1.6 ms).  The launch
+// sequence depends only on (B, N, flags, workspace), so it is CAPTURED once per such key into a hipGraph (stream capture incl. the
+// fork / join onto the handle's side streams) and replayed: a call is then one D2D copy of x into the workspace, one graph launch
+// and one tiny kernel that scatters the packed codes to the caller's output tensors (the graph itself only ever touches fixed
+// addresses inside the caller's workspace, so the caller's x / output pointers may change freely between calls).
+static int encode_graphed(ls_model_t* m, const EncPlan& p, const float* x, int B, int N, int pre_normalised, unsigned flags, float* z_so3,
+                          float* z_inv, float* s_out, float* t_out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    char* ws = (char*)workspace;
+    float* xin = (float*)(ws + p.o_xin);
+    float* packed = (float*)(ws + p.o_out);
+    const int c = m->d.c_dim;
+    float* g_zso3 = packed;
+    float* g_zinv = g_zso3 + (size_t)B * c * 3;
+    float* g_s = g_zinv + (size_t)B * c;
+    float* g_t = g_s + B;
+    ls_model::EncGraph* hit = nullptr;
+    for (auto& g : m->graphs)
+        if (g.ws == workspace && g.ws_bytes == workspace_bytes && g.B == B && g.N == N && g.pre == pre_normalised && g.flags == flags && g.st == st) hit = &g;
+    if (!hit) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { (void)hipGetLastError(); m->graph_broken = true; return 1; }
+        const int rc = encode_enqueue(m, p, xin, B, N, pre_normalised, flags, g_zso3, g_zinv, g_s, g_t, nullptr, nullptr, workspace, st);
+        e = hipStreamEndCapture(st, &graph);
+        if (rc != LS_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); m->graph_broken = true; return rc != LS_OK ? rc : 1; }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(graph); m->graph_broken = true; return 1; }
+        if (m->graphs.size() >= 8) {   // a handle serves a few shapes; drop the oldest beyond that
+            (void)hipGraphExecDestroy(m->graphs.front().exec);
+            (void)hipGraphDestroy(m->graphs.front().graph);
+            m->graphs.erase(m->graphs.begin());
+        }
+        m->graphs.push_back(ls_model::EncGraph{workspace, workspace_bytes, B, N, pre_normalised, flags, st, graph, exec});
+        hit = &m->graphs.back();
+    }
+    LS_HIP_CHECK(hipMemcpyAsync(xin, x, (size_t)B * 3 * N * sizeof(float), hipMemcpyDeviceToDevice, st));
+    LS_HIP_CHECK(hipGraphLaunch(hit->exec, st));
+    return scatter_codes_launch(packed, B, c, z_so3, z_inv, s_out, t_out, st);
+}
+
+extern "C" {
+
+int ls_encode(ls_model_t* m, const float* x, int B, int N, int pre_normalised, unsigned flags, float* z_so3, float* z_inv,
+              float* s_out, float* t_out, int32_t* trace_knn, int32_t* trace_fps, void* workspace, size_t workspace_bytes,
+              void* stream) {
+    LS_REQUIRE(m && x && z_so3 && z_inv && s_out && t_out && workspace, "encode: null argument");
+    LS_REQUIRE(B > 0 && N >= 16, "encode: need B>0, N>=16 (B=%d N=%d)", B, N);
+    EncPlan p;
+    int rc = make_plan(m->d, B, N, p);
+    if (rc != LS_OK) return rc;
+    if (workspace_bytes < p.total) { set_error("encode: workspace %zu < required %zu", workspace_bytes, p.total); return LS_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    // the captured path: not while per-launch profiling events or the index traces are requested (tests / bench's profiled pass), not
+    // on the legacy NULL stream (it cannot be captured), and not with the debugging knobs
+    if (m->use_graph && !m->graph_broken && !m->profiling && !trace_knn && !trace_fps && st != nullptr && m->debug_layers < 0) {
+        rc = encode_graphed(m, p, x, B, N, pre_normalised, flags, z_so3, z_inv, s_out, t_out, workspace, workspace_bytes, st);
+        if (rc <= 0) return rc;    // 0 = done, < 0 = error; 1 = capture unavailable on this runtime: fall through to the direct path
+    }
+    return encode_enqueue(m, p, x, B, N, pre_normalised, flags, z_so3, z_inv, s_out, t_out, trace_knn, trace_fps, workspace, st);
 }
 
 // ------------------------------------------------------------------------------------------------ per-operator exports

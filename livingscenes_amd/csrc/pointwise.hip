@@ -315,6 +315,23 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     }
 }
 
+// packed codes [z_so3 B*c*3 | z_inv B*c | s B | t B*3] (fixed addresses written by a captured encode graph) -> the caller's tensors
+__global__ __launch_bounds__(256) void scatter_codes_kernel(const float* __restrict__ packed, int n_so3, int n_inv, int n_s, int n_t,
+                                                            float* __restrict__ z_so3, float* __restrict__ z_inv, float* __restrict__ s,
+                                                            float* __restrict__ t) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_so3) z_so3[i] = packed[i];
+    else if (i < n_so3 + n_inv) z_inv[i - n_so3] = packed[i];
+    else if (i < n_so3 + n_inv + n_s) s[i - n_so3 - n_inv] = packed[i];
+    else if (i < n_so3 + n_inv + n_s + n_t) t[i - n_so3 - n_inv - n_s] = packed[i];
+}
+int scatter_codes_launch(const float* packed, int B, int c, float* z_so3, float* z_inv, float* s, float* t, hipStream_t st) {
+    const int total = B * (4 * c + 4);
+    hipLaunchKernelGGL(scatter_codes_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, packed, B * c * 3, B * c, B, B * 3, z_so3, z_inv, s, t);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
 size_t prologue_scratch_floats(int B) { (void)B; return 0; }
 int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, float* /*unused*/, hipStream_t st) {
     LS_REQUIRE(N >= 3 && N <= 8192, "prologue: N=%d out of range (3..8192)", N);

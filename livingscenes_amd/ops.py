@@ -83,9 +83,12 @@ def cosine_scores(m0, m1):
 
 
 def greedy_match(scores):
-    """scores [n,m] (copied; the kernel destroys its input) -> (matches0 [n], matches1 [m]) int64."""
-    S = _f32(scores).clone()
+    """scores [n,m] -> (matches0 [n], matches1 [m]) int64.  (The large-problem kernel normalises its input in place: copied then;
+    the single-wave kernel of n * m <= 1024 keeps the matrix in registers and leaves `scores` untouched.)"""
+    S = _f32(scores)
     n, m = S.shape
+    if n * m > 1024:
+        S = S.clone()
     m0 = torch.empty(n, dtype=torch.int64, device=S.device)
     m1 = torch.empty(m, dtype=torch.int64, device=S.device)
     call(S.device, "ls_greedy_match_f32", ptr(S), n, m, ptr(m0), ptr(m1), stream_ptr(S.device))

@@ -91,17 +91,20 @@ class VecDGCNN_att(nn.Module):
         self._hip_key = None
 
     # ------------------------------------------------------------------ HIP model cache
-    def _key(self, extra=()):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(extra)
-
     def hip_model(self, decoder=None):
-        """Packed device model (encoder [+ decoder]); rebuilt when any parameter tensor changed."""
-        dev = next(self.parameters()).device
-        extra = () if decoder is None else tuple((p.data_ptr(), p._version) for p in decoder.parameters())
-        key = self._key(extra) + (str(dev),)
+        """Packed device model (encoder [+ decoder]); rebuilt when any parameter tensor changed (storage or in-place version).
+        The parameter LIST is cached per decoder object (walking the module tree costs more than the check itself: this runs on
+        every encode), the per-tensor (data_ptr, _version) check is not."""
+        cache = getattr(self, "_hip_plist", None)
+        if cache is None or cache[0] is not decoder:
+            plist = list(self.parameters()) + ([] if decoder is None else list(decoder.parameters()))
+            self._hip_plist = cache = (decoder, plist)
+        plist = cache[1]
+        key = tuple([(p.data_ptr(), p._version) for p in plist])
         if self._hip is None or self._hip_key != key:
             if self._hip is not None:
                 self._hip.close()
+            dev = plist[0].device
             enc_w = {k: v for k, v in self.state_dict().items()}
             dec_w = dec_cfg = None
             if decoder is not None:

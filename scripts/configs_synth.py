@@ -4,7 +4,7 @@ with no data-path collective, livingscenes_amd/sharding.py):
   configs[3]  3RScan-style end to end: 16 scenes x (1 reference + 2 rescans) x 8-24 instances of 1 024 .. 60 000 raw points ->
               ragged FPS + encode, sequential matching, Kabsch + ICP registration of the matched pairs, SDF reconstruction
               (MISE 32 -> 128 + marching cubes) of every transformed code   (More_Solver._solve_end2end, more_solver.py:246-299;
-              the Adam refinement of eval_3rscan's optim=True is timed on a few pairs only: ~1.1 s per pair)
+              + the Adam refinement of eval_3rscan's optim=True on every matched pair, 64 pairs in lock-step)
   configs[4]  dense SDF reconstruction: 128^3 query grid per instance, 256 instances, decoder GEMM path
 """
 import argparse, os, sys, time
@@ -19,6 +19,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=16)
 ap.add_argument("--dense-instances", type=int, default=256)
 ap.add_argument("--skip-dense", action="store_true")
+ap.add_argument("--optim-pairs", type=int, default=-1, help="matched pairs put through the optim=True refinement (-1 = all, 0 = skip)")
+ap.add_argument("--optim-chunk", type=int, default=64, help="pairs advanced in lock-step per call")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
@@ -104,14 +106,20 @@ torch.cuda.synchronize(); tm = time.perf_counter() - t0
 nm = sum(m is not None for o in outs for m in o["mesh_lst"])
 print(f"  batched incl. SDF reconstruction (16 MISE octrees in lock-step, ragged decoder calls): {tm:.2f} s total, "
       f"{(tm - tb) / max(nm, 1) * 1e3:.1f} ms per mesh, {nm / tm:.1f} matched-and-meshed objects/s")
-pairs = [(scenes[0][0][0], scenes[0][1][0])]
-ref, res = pairs[0]
-full = lambda scn, i: scn["pc"][i].T[scn["pc_mask"][i].reshape(-1)][None]
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for i in range(3):
-    solver._solve_pairwise_registration(full(ref, i), full(res, i), optim=True)
-torch.cuda.synchronize()
-print(f"  optim=True refinement (400 Adam steps, eval_3rscan's setting): {(time.perf_counter() - t0) / 3:.2f} s per pair")
+# eval_3rscan's optim=True refinement (400 Adam steps per matched pair, more_solver.py:118-189; eval_3rscan.py:381) of EVERY matched pair,
+# 64 pairs in lock-step per call (csrc/optim.hip); round 1 ran it pair by pair at 1.1 s per pair
+reg1 = [o["ref_pc_lst"][i] for o in outs for i, j in enumerate(o["matches"].tolist()) if j >= 0]
+reg2 = [o["rescan_pc_lst"][j] for o in outs for i, j in enumerate(o["matches"].tolist()) if j >= 0]
+if args.optim_pairs >= 0:
+    reg1, reg2 = reg1[:args.optim_pairs], reg2[:args.optim_pairs]
+if reg1:
+    solver._solve_pairwise_registration_optim_batch(reg1[:2], reg2[:2])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for c0 in range(0, len(reg1), args.optim_chunk):
+        solver._solve_pairwise_registration_optim_batch(reg1[c0:c0 + args.optim_chunk], reg2[c0:c0 + args.optim_chunk])
+    torch.cuda.synchronize(); to = time.perf_counter() - t0
+    print(f"  optim=True refinement of {len(reg1)} matched pairs, {args.optim_chunk} in lock-step per call (400 Adam steps each: decoder forward + "
+          f"backward, Sinkhorn, SE(3) Adam on the device): {to:.1f} s = {to / len(reg1) * 1e3:.1f} ms per pair")
 
 # ---------------------------------------------------------------------------------------------------------- configs[4]
 if not args.skip_dense:

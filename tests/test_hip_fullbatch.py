@@ -85,3 +85,30 @@ def test_fullbatch_match_and_register_vs_oracle(fullbatch):
     R, tt, _, _ = more.kabsch_transformation_estimation(p1, p2)
     assert relerr(r["h0_pose_R"], R.numpy()) < TOL
     assert relerr(r["h0_pose_t"], tt.numpy()) < TOL
+
+
+def test_encode_graph_replay_is_bit_identical():
+    """LS_OPT_ENCODE_GRAPH (opt-in): the captured hipGraph of ls_encode's launch sequence (incl. the fork / join onto the FPS side
+    stream), replayed with x and the outputs at NEW addresses every call, returns exactly the codes of the direct path."""
+    from livingscenes_amd import _lib
+    from livingscenes_amd.model_utils import Shape_Prior
+    dev = torch.device("cuda:0")
+    ecfg, dcfg = synth.small_encoder_cfg(), synth.small_decoder_cfg()
+    sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 1), synth.make_decoder_weights(dcfg, 1), device=dev)
+    xs = [synth.make_instances(5, 256, seed=70 + i).to(dev) for i in range(3)]
+    st = torch.cuda.Stream(device=dev)
+    with torch.no_grad():
+        direct = [sp.encode(x) for x in xs]
+        torch.cuda.synchronize()
+        sp.hip_model().set_option(_lib.OPT_ENCODE_GRAPH, 1)
+        with torch.cuda.stream(st):
+            for rep in range(2):
+                keep = []
+                for x, want in zip(xs, direct):
+                    got = sp.encode(x.clone())          # a fresh input address every call
+                    keep.append(got)
+                st.synchronize()
+                for got, want in zip(keep, direct):
+                    for k in ("z_so3", "z_inv", "s", "t"):
+                        assert torch.equal(got[k], want[k]), (rep, k)
+        sp.hip_model().set_option(_lib.OPT_ENCODE_GRAPH, 0)

@@ -461,6 +461,30 @@ def test_greedy_match_bit_exact_on_golden_scores(golden):
     assert np.array_equal(m0.cpu().numpy(), g["seq_n32_m0"])
 
 
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 40), (37, 1), (32, 32), (20, 51), (51, 20), (7, 146), (40, 40), (64, 48)])
+def test_greedy_match_random_shapes_bit_exact(n, m):
+    """The greedy assignment loop on random rectangular score matrices -- single-wave register kernel (n * m <= 1024) and the
+    workgroup kernel above that -- incl. exact ties (first row-major maximum wins), all-negative matrices (the renormalisation
+    divides by a negative number: the order flips) and duplicated rows."""
+    from livingscenes_amd import ops
+    from oracle import more
+    g = torch.Generator().manual_seed(n * 100 + m)
+    for case in ("normal", "ties", "negative", "dup_rows"):
+        S = torch.randn(n, m, generator=g)
+        if case == "ties":
+            S = torch.randint(0, 4, (n, m), generator=g).float() * 0.25
+        if case == "negative":
+            S = -S.abs() - 0.1
+        if case == "dup_rows" and n > 1:
+            S[n // 2] = S[0]
+        ref = more._greedy_assign(S, n, m)
+        keep = S.clone()
+        m0, m1 = ops.greedy_match(S.to(_dev()))
+        assert np.array_equal(m0.cpu().numpy(), ref["matches0"].numpy()), case
+        assert np.array_equal(m1.cpu().numpy(), ref["matches1"].numpy()), case
+        assert torch.equal(S, keep)
+
+
 def test_kabsch_vs_golden(golden):
     from livingscenes_amd import ops
     g = golden("registration")
