@@ -159,6 +159,9 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # LS_BENCH_FORCE_DIST=1: run the collective code path (RCCL init, weight broadcast, barriers, all-reduce / all-gather) even with
+    # ONE rank -- the only way to exercise the "nccl" backend on the single-GPU test box
+    multi = world > 1 or bool(os.environ.get("LS_BENCH_FORCE_DIST"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -171,8 +174,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # LS_BENCH_FORCE_DIST without a launcher
+            for k, v in (("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(k, v)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         else:
@@ -192,7 +198,7 @@ def main():
         ew = {k: torch.zeros(s) for k, s in synth.encoder_param_shapes(ecfg).items()}
         dw = {k: torch.zeros_like(v) for k, v in synth.make_decoder_weights(dcfg, 0).items()}
     sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=dev)
-    if world > 1:
+    if multi:
         parallel.broadcast_weights(sp, src=0)
     nfl = max(1, args.inflight)
     if nfl > 1:
@@ -218,7 +224,7 @@ def main():
         return emb, m, R, t
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
 
     def run(n, events=None):
@@ -257,7 +263,7 @@ def main():
     my = torch.tensor([dt, dt_host], device=dev, dtype=torch.float64)
     dt_t = my[:1].clone()
     per_rank = None
-    if world > 1:
+    if multi:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         mine = my if backend == "nccl" else my.cpu()     # gloo gathers through host memory only
         allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -284,7 +290,7 @@ def main():
         for s_ in sps:
             s_.knn_flags = 0
         dt_f = torch.tensor([dt_fma], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(dt_f, op=dist.ReduceOp.MAX)
         dt_fma = float(dt_f.item())
 
@@ -292,7 +298,7 @@ def main():
     # sanity of the measured work (outside the timed region): matches are the identity permutation, poses are rotations
     n_correct = int((m["matches0"].cpu() == torch.arange(n_obj)).sum())
     det_ok = bool((torch.det(R.cpu()) > 0.99).all())
-    if world > 1:  # RCCL all-gather of the per-rank codes (4.1 KB each: latency-bound; outside the timed region)
+    if multi:  # RCCL all-gather of the per-rank codes (4.1 KB each: latency-bound; outside the timed region)
         allc = parallel.all_gather_codes(emb)
         assert allc["z_inv"].shape[0] == B * world
 
@@ -378,6 +384,7 @@ def main():
         ref_m = more.sequential_matcher(emb["z_inv"][:n_obj].cpu(), emb["z_inv"][n_obj:].cpu())
         oracle_check["matches_bit_exact_vs_oracle_on_hip_codes"] = bool(torch.equal(ref_m["matches0"], m["matches0"].cpu()))
 
+    line = None
     if rank == 0:
         total_objects = B * args.steps * world
         line = {
@@ -411,10 +418,18 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()  # rank 0 may still be in its profiled pass / JSON print
+    if multi:
+        dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()  # rank 0 may still be in its profiled pass
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio (flushed at exit when piped)
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

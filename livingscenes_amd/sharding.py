@@ -30,7 +30,7 @@ def shard_range(n_items, rank=None, world_size=None):
 
 def broadcast_weights(module, src=0):
     """Broadcast every parameter of `module` from rank `src` as ONE flat fp32 buffer (one collective, not 78)."""
-    if world()[1] == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     params = [p for p in module.parameters()]
     flat = torch.cat([p.detach().reshape(-1) for p in params])
@@ -68,7 +68,7 @@ def all_gather_codes(emb, counts=None):
     """All ranks receive the codes of all shards, concatenated in rank order.  `counts` = rows per rank (defaults
     to equal shards); ragged shards are padded to the largest."""
     rank, ws = world()
-    if ws == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return emb
     rows = pack_codes(emb)
     if counts is None:
