@@ -47,13 +47,24 @@ constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 // Write one wave's staged 32x64 half-tile (LDS rows of 68 floats) to out[gm0.., gn0..].  Interior tiles (the common case)
 // take the predicate-free path: all eight LDS reads in flight, then eight 16-byte stores per lane (each store = four
 // 256-byte row segments per wave); per-element branches around the LDS read -> store pairs cost 12 % on the K <= 64 GEMMs.
+// `mask` (nullable, same shape and row stride as `out`): out = mask > 0 ? value : 0 -- the ReLU derivative of the decoder's backward
+// pass fused into the store (ls_sdf_backward: dh_{l-1} = (dz_l W_l) [h_{l-1} > 0]; a separate pass cost 80 us per layer at 65 536 rows).
 __device__ __forceinline__ void store_half_tile(const float* stg, float* __restrict__ out, int ldc, int M, int N, int gm0, int gn0,
-                                                int lane, bool full_tile, bool vec_ok) {
+                                                int lane, bool full_tile, bool vec_ok, const float* __restrict__ mask) {
     if (full_tile) {
         float4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(&stg[(u * 4 + (lane >> 4)) * 68 + (lane & 15) * 4]);
-        float* op = out + (size_t)(gm0 + (lane >> 4)) * ldc + gn0 + (lane & 15) * 4;
+        const size_t o0 = (size_t)(gm0 + (lane >> 4)) * ldc + gn0 + (lane & 15) * 4;
+        if (mask) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 hm = *reinterpret_cast<const float4*>(mask + o0 + (size_t)(u * 4) * ldc);
+                v[u].x = hm.x > 0.f ? v[u].x : 0.f; v[u].y = hm.y > 0.f ? v[u].y : 0.f;
+                v[u].z = hm.z > 0.f ? v[u].z : 0.f; v[u].w = hm.w > 0.f ? v[u].w : 0.f;
+            }
+        }
+        float* op = out + o0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(op + (size_t)(u * 4) * ldc) = v[u];
         return;
@@ -64,8 +75,15 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
         const int rr = idx >> 4, c4 = (idx & 15) * 4;
         const int gm = gm0 + rr, gn = gn0 + c4;
         if (gm < M && gn < N) {
-            const float4 v = *reinterpret_cast<const float4*>(&stg[rr * 68 + c4]);
+            float4 v = *reinterpret_cast<const float4*>(&stg[rr * 68 + c4]);
             float* op = out + (size_t)gm * ldc + gn;
+            if (mask) {
+                const float* mp = mask + (size_t)gm * ldc + gn;
+                v.x = mp[0] > 0.f ? v.x : 0.f;
+                if (gn + 1 < N) v.y = mp[1] > 0.f ? v.y : 0.f;
+                if (gn + 2 < N) v.z = mp[2] > 0.f ? v.z : 0.f;
+                if (gn + 3 < N) v.w = mp[3] > 0.f ? v.w : 0.f;
+            }
             if (vec_ok && gn + 3 < N) {
                 *reinterpret_cast<float4*>(op) = v;
             } else {
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
                                                        int ldc, int M, int N, int K, int relu, int ntiles_n,
                                                        const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk,
-                                                       size_t slab_stride) {
+                                                       size_t slab_stride, const float* __restrict__ mask) {
     constexpr int STG = 32 * 68;  // epilogue staging: 32 rows x (64 + 4) floats per wave
     constexpr int BK = SPLIT ? 32 : GK;          // k depth of one staged slab
     constexpr int NST = SPLIT ? 4 : 2;           // float4 per thread per operand slab
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         // wave-local hand-off through LDS: same wave writes and reads, LDS ops of a wave complete in order
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok);
+        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const float* __restric
                 }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
-            store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok);
+            store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, nullptr);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -422,7 +440,7 @@ size_t gemm_scratch_floats(int M, int N, int K) {
 
 int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
                        int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st, bool latency_path = false,
-                       int pieces = 3) {
+                       int pieces = 3, const float* mask = nullptr) {
     LS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem (M=%d N=%d K=%d)", M, N, K);
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
@@ -449,7 +467,7 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     // conv, M = 3B), where the fp32 kernel's shorter slab (16 k, no split arithmetic before the first MFMA) wins: 44 vs 112 us
     // at M = 192, N = 1024, K = 512
     const bool split = split_on && !latency_path;
-    const int nsplit = scratch ? gemm_choose_splits(M, N, K) : 1;
+    const int nsplit = (scratch && !mask) ? gemm_choose_splits(M, N, K) : 1;
     if (nsplit > 1) {
         const int kq = split ? 32 : GK;
         int kchunk = cdiv(cdiv(K, nsplit), kq) * kq;
@@ -457,10 +475,10 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         const size_t slab = (size_t)M * N;
         if (split)
             hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
-                               a_rows, gNd, gNs, kchunk, slab);
+                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr);
         else
             hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
-                               a_rows, gNd, gNs, kchunk, slab);
+                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr);
         LS_LAUNCH_CHECK();
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv((long long)M * (N / 4), 256)), dim3(256), 0, st, scratch, slab, ns, bias, out,
                            ldc, M, N, relu);
@@ -469,13 +487,13 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     }
     if (split && pieces == 2)
         hipLaunchKernelGGL((gemm_f32_kernel<true, 2>), dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                           gNd, gNs, K, (size_t)0);
+                           gNd, gNs, K, (size_t)0, mask);
     else if (split)
         hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                           gNd, gNs, K, (size_t)0);
+                           gNd, gNs, K, (size_t)0, mask);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                           gNd, gNs, K, (size_t)0);
+                           gNd, gNs, K, (size_t)0, mask);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -495,6 +513,11 @@ int gemm_dispatch_ws(const float* A, int lda, const float* W, int ldw, const flo
 int gemm_dispatch_fast2(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
                         int K, int relu, hipStream_t st) {
     return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, nullptr, st, false, 2);
+}
+// out = (mask > 0) ? A W^T : 0 with `mask` laid out like `out` (never splits K); pieces = 3 | 2
+int gemm_dispatch_masked(const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, const float* mask, int pieces,
+                         hipStream_t st) {
+    return gemm_dispatch_full(A, lda, W, ldw, nullptr, out, ldc, M, N, K, 0, nullptr, 0, 0, nullptr, st, false, pieces, mask);
 }
 int gemm_dispatch_small(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
                         int K, int relu, float* scratch, hipStream_t st) {

@@ -33,6 +33,7 @@ int gemm_dispatch_gather(const float*, int, const float*, int, const float*, flo
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 int gemm_dispatch_fast2(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
+int gemm_dispatch_masked(const float*, int, const float*, int, float*, int, int, int, int, const float*, int, hipStream_t);
 size_t gemm_scratch_floats(int M, int N, int K);
 int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipStream_t);
 size_t prologue_scratch_floats(int B);
@@ -975,10 +976,15 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
             dq_started = true;
         }
         // dh_{l-1} [rows, kin] = dz_l [rows, out_l] . W_l [out_l][kin]  ==  dz_l . (Wt_l [kin][out_l])^T
-        rc = (m->sdf_bf16x2 && !sb.gws) ? gemm_dispatch_fast2(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, st)
-                                        : gemm_dispatch_ws(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, sb.gws, st);
-        if (rc != LS_OK) return rc;
-        rc = relu_mask_launch(other, sb.h[l - 1], rows, kin, w, st);
+        // the ReLU derivative [h_{l-1} > 0] is applied in the GEMM's store when the launch does not split K (h and dh share the row stride w)
+        const bool fuse_mask = !sb.gws && kin % 4 == 0;
+        if (fuse_mask) {
+            rc = gemm_dispatch_masked(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], other, w, (int)rows, kin, outw[l], sb.h[l - 1], m->sdf_bf16x2 ? 2 : 3, st);
+        } else {
+            rc = gemm_dispatch_ws(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, sb.gws, st);
+            if (rc != LS_OK) return rc;
+            rc = relu_mask_launch(other, sb.h[l - 1], rows, kin, w, st);
+        }
         if (rc != LS_OK) return rc;
         std::swap(dz, other);
     }

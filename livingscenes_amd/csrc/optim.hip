@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict_
 // L1 stream of the M y points per row, 16000 launches per 64-pair registration), online (max, sum) per lane and row, combined
 // by wave reductions.
 constexpr int SM_RB = 4;
+template <bool GRAD>   // the gradient accumulators are needed by 2 of the ~40 softmins of a divergence only
 __global__ __launch_bounds__(256) void softmin_batched_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ pot_y, float logw, const float* __restrict__ eps_p,
                                                               const float* __restrict__ prev, int average, int N, int M,
@@ -97,11 +98,13 @@ __global__ __launch_bounds__(256) void softmin_batched_kernel(const float* __res
             const float v = hj - 0.5f * (dx * dx + dy * dy + dz * dz) * inv;
             if (v > mx[r]) {
                 const float sc = __expf(mx[r] - v);   // exp(-inf) = 0 on the first hit
-                sum[r] *= sc; gx[r] *= sc; gy[r] *= sc; gz[r] *= sc;
+                sum[r] *= sc;
+                if constexpr (GRAD) { gx[r] *= sc; gy[r] *= sc; gz[r] *= sc; }
                 mx[r] = v;
             }
             const float e = __expf(v - mx[r]);
-            sum[r] += e; gx[r] += e * dx; gy[r] += e * dy; gz[r] += e * dz;
+            sum[r] += e;
+            if constexpr (GRAD) { gx[r] += e * dx; gy[r] += e * dy; gz[r] += e * dz; }
         }
     }
 #pragma unroll
@@ -110,13 +113,13 @@ __global__ __launch_bounds__(256) void softmin_batched_kernel(const float* __res
         const float sc = mx[r] == -INFINITY ? 0.f : __expf(mx[r] - wmx);
         const float s = wave_sum(sum[r] * sc);
         float ax = 0.f, ay = 0.f, az = 0.f;
-        if (grad) { ax = wave_sum(gx[r] * sc); ay = wave_sum(gy[r] * sc); az = wave_sum(gz[r] * sc); }
+        if constexpr (GRAD) { ax = wave_sum(gx[r] * sc); ay = wave_sum(gy[r] * sc); az = wave_sum(gz[r] * sc); }
         if (lane == 0 && i0 + r < N) {
             const size_t row = (size_t)p * N + i0 + r;
             float o = -eps * (wmx + __logf(s));
             if (average) o = 0.5f * (prev[row] + o);
             out[row] = o;
-            if (grad) { grad[row * 3] = ax / s; grad[row * 3 + 1] = ay / s; grad[row * 3 + 2] = az / s; }
+            if constexpr (GRAD) { grad[row * 3] = ax / s; grad[row * 3 + 1] = ay / s; grad[row * 3 + 2] = az / s; }
         }
     }
 }
@@ -239,8 +242,12 @@ int ls_sinkhorn_softmin_batched_f32(const float* x, const float* y, const float*
     LS_REQUIRE(P > 0 && N > 0 && M > 0 && P <= 65535, "sinkhorn_softmin_batched: bad sizes (P=%d N=%d M=%d)", P, N, M);
     LS_REQUIRE(!average || prev, "sinkhorn_softmin_batched: average needs prev");
     LS_REQUIRE(prev != out || !prev, "sinkhorn_softmin_batched: out must not alias prev (the symmetric update reads old potentials)");
-    hipLaunchKernelGGL(softmin_batched_kernel, dim3(cdiv(N, 4 * SM_RB), P), dim3(256), 0, (hipStream_t)stream, x, y, pot_y, logw, eps, prev, average, N, M,
-                       out, grad_x);
+    if (grad_x)
+        hipLaunchKernelGGL(softmin_batched_kernel<true>, dim3(cdiv(N, 4 * SM_RB), P), dim3(256), 0, (hipStream_t)stream, x, y, pot_y, logw, eps, prev,
+                           average, N, M, out, grad_x);
+    else
+        hipLaunchKernelGGL(softmin_batched_kernel<false>, dim3(cdiv(N, 4 * SM_RB), P), dim3(256), 0, (hipStream_t)stream, x, y, pot_y, logw, eps, prev,
+                           average, N, M, out, grad_x);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

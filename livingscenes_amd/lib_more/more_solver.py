@@ -112,16 +112,28 @@ class More_Solver:
             try:
                 opt = ops.Se3Adam(g0, src, stop)
                 steps_run = 0
+                # length of the Sinkhorn epsilon-schedule loop: read back once, then guessed as (largest seen + 1) and VERIFIED at the
+                # host read every 16 steps (a schedule grows by one entry when a pair's bounding-box diameter doubles; 16 steps of
+                # at most lr radians / units each cannot do that) -- no device -> host round trip inside a step
+                sched_len, needs = None, []
                 for i in range(n_steps):
                     lr = lr0 * (0.1 ** sum(i >= ms for ms in (300, 340, 380)))          # MultiStepLR([300, 340, 380], 0.1), :143
                     sdf, saved = hip.sdf_decode_train(opt.query, shared["z_so3"], shared["z_inv"], shared["s"], shared["t"])
                     loss, gsdf = ops.smooth_l1(sdf)
                     gq = hip.sdf_backward(saved, gsdf)[0]
-                    sl, sg = divergence_batch(opt.query, tgt)
+                    sl, sg, need = divergence_batch(opt.query, tgt, lmax=sched_len, return_need=True)
+                    if sched_len is None:
+                        sched_len = int(need) + 1
+                    needs.append(need)
                     opt.step(gq + sg, loss + sl, lr)
                     steps_run = i + 1
-                    if i % 16 == 15 and not bool(opt.active.any()):             # every pair stopped early: one host read per 16 steps
-                        break
+                    if i % 16 == 15:                                            # one host read per 16 steps
+                        worst = int(torch.stack(needs).max())
+                        if worst > sched_len:
+                            raise RuntimeError(f"Sinkhorn schedule grew from {sched_len} to {worst} entries within 16 steps (diverging pose?)")
+                        sched_len, needs = worst + 1, []
+                        if not bool(opt.active.any()):                          # every pair stopped early
+                            break
             finally:
                 hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 1)
                 if two_piece:

@@ -67,18 +67,23 @@ def _softmin_b(x, y, pot_y, logw, eps, prev=None, average=False, need_grad=False
     return (out, grad) if need_grad else out
 
 
-def divergence_batch(x, y, blur=0.05, scaling=0.5):
+def divergence_batch(x, y, blur=0.05, scaling=0.5, lmax=None, return_need=False):
     """Debiased Sinkhorn divergence of P cloud pairs in lock-step: x [P,N,3] (moving), y [P,M,3] -> (loss [P], d loss / d x [P,N,3]).
     Same definition as _divergence pair by pair: every pair follows ITS OWN epsilon schedule (it depends on the pair's bounding-box
     diameter, so the schedules differ in length); a pair whose schedule has ended is passed through unchanged by the kernel
-    (eps <= 0), and one host read per call (the longest schedule) sizes the loop."""
+    (eps <= 0).  The loop length is the longest schedule of the batch: read back from the device when ``lmax`` is None (one host
+    sync), or given by the caller (e.g. the value of an earlier call + 1: a schedule grows by one entry when the diameter doubles);
+    ``return_need`` also returns the exact requirement as a 0-dim DEVICE tensor so that the caller can verify its guess later without
+    stalling the launch sequence (a guess that is too small truncates the schedules that needed more)."""
     x, y = x.detach().float().contiguous(), y.detach().float().contiguous()
     P, N, _ = x.shape
     M = y.shape[1]
     both = torch.cat([x, y], 1)
     diam = (both.max(1)[0] - both.min(1)[0]).norm(dim=1).clamp_min(1e-6).double()                      # [P]
     nj = torch.ceil((math.log(blur) - diam.log()) / math.log(scaling)).clamp_min(0).long()       # len(np.arange(2 log d, 2 log blur, 2 log scaling))
-    lmax = int(nj.max()) + 2                                                                           # the one host read
+    need = nj.max() + 2
+    if lmax is None:
+        lmax = int(need)                                                                               # the one host read
     k = torch.arange(lmax, device=x.device)[None]                                                      # [1,L]
     e_mid = (2 * diam.log()[:, None] + (k - 1).clamp_min(0) * (2 * math.log(scaling))).exp()           # d^2 scaling^(2 (k - 1))
     eps_tab = torch.where(k == 0, (diam ** 2)[:, None], e_mid)
@@ -101,6 +106,8 @@ def divergence_batch(x, y, blur=0.05, scaling=0.5):
     f_aa_l, d_aa = _softmin_b(x, x, f_aa, a_log, last, need_grad=True)
     g_bb_l = _softmin_b(y, y, g_bb, b_log, last)
     loss = (f_ba_l - f_aa_l).mean(1) + (g_ab_l - g_bb_l).mean(1)
+    if return_need:
+        return loss, (d_ba - d_aa) / N, need
     return loss, (d_ba - d_aa) / N
 
 
