@@ -89,9 +89,12 @@ int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, cons
 /* pytorch3d.ops.sample_farthest_points(points, K=..., random_start_point=False) as called at
  * vec_dgcnn_atten.py:169, model_utils.py:205, lib_more/more_solver.py:107-108.
  *   pts [B, N, 3]; lengths [B] or NULL; idx_out [B, K] int32 (-1 padded when K > length);
- *   pts_out [B, K, 3] or NULL (gathered points).  Start index 0, running min, first arg-max. */
+ *   pts_out [B, K, 3] or NULL (gathered points).  Start index 0, running min, first arg-max.
+ * workspace: ls_fps_workspace_bytes(B, N, K) bytes -- non-zero only for raw clouds of more than 8 192 points, where it holds the
+ * bucketed copy of the clouds the pruned scan works on (fps.hip); NULL / too small there = the un-pruned scan (same result, ~6x slower). */
+size_t ls_fps_workspace_bytes(int B, int N, int K);
 int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out,
-               float* pts_out, void* stream);
+               float* pts_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) -- the VecLinear channel contraction
  * (vec_layers.py:121-136, F.linear at :134) on x-major rows, and the DeepSDF linears

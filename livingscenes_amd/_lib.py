@@ -77,7 +77,8 @@ SIGNATURES = {
     "ls_device_count": (_I, []),
     "ls_knn_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I, _U]),
     "ls_knn_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _P, _P, _P, _SZ, _P]),
-    "ls_fps_f32": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P]),
+    "ls_fps_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "ls_fps_f32": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _SZ, _P]),
     "ls_gemm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ls_gemm_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "ls_encode_prologue_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),

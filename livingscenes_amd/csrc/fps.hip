@@ -72,6 +72,18 @@ __device__ __forceinline__ int wave_argmax_dpp(float v, int i, bool valid) {
     return (int)~(unsigned)__builtin_amdgcn_readlane((int)lo, 63);
 }
 
+// The same reduction on ready-made keys; both halves of the winning key come back wave-uniform (SGPRs).
+__device__ __forceinline__ void wave_max_key_dpp(unsigned& hi, unsigned& lo) {
+    dpp_max_u64<0xB1, 0xF>(hi, lo);
+    dpp_max_u64<0x4E, 0xF>(hi, lo);
+    dpp_max_u64<0x141, 0xF>(hi, lo);
+    dpp_max_u64<0x140, 0xF>(hi, lo);
+    dpp_max_u64<0x142, 0xA>(hi, lo);
+    dpp_max_u64<0x143, 0xC>(hi, lo);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
 template <int PPL, bool FMA>
 __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
                                                       int N, int K, int32_t* __restrict__ idx_out,
@@ -259,6 +271,246 @@ __global__ __launch_bounds__(1024) void fps_block_kernel(const float* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Raw clouds (8 192 < N <= 65 536 points -> 1 024 samples: Shape_Prior.encode_fps, model_utils.py:199-215; more_solver.py:107-108).
+// fps_block_kernel re-reads the whole cloud every step (720 KB through one CU for 60 000 points: 17.6 us per step, 18 ms per
+// cloud).  But once a few dozen samples exist, a new sample can only lower the running minimum of points NEAR it: bucket the
+// cloud on a uniform grid (counting sort inside the workgroup), keep per bucket the bounding box of its points and its largest
+// running minimum (value, smallest original index), and per step
+//   1. test every bucket: lb = canonical distance from the new sample to the bucket's box, evaluated with the SAME fp32 formula on
+//      the per-axis gaps -- rounding is monotone, so lb <= the computed distance of every point in the box, exactly; a bucket with
+//      lb >= its largest minimum cannot change (min(md, d) = md for all its points) and is skipped;
+//   2. update the points of the remaining buckets (16 lanes per bucket, four buckets per wave step) and their maxima;
+//   3. arg-max over the bucket maxima (larger value, then smaller ORIGINAL index: the first arg-max of the un-bucketed scan).
+// Bit-identical to the full scan by construction (tests: ragged, duplicates, degenerate clouds, both rounding modes); the work per
+// step falls from N to ~N / k point updates + one test per bucket.
+constexpr int FB_MAXB = 4096;      // buckets
+constexpr int FB_CELLS = 32768;    // finest grid: 32^3
+
+__device__ __forceinline__ int fb_cell(const float* __restrict__ p, int i, const float (&lo)[3], const float (&sc)[3], int G) {
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = min(G - 1, max(0, (int)((p[(size_t)i * 3 + a] - lo[a]) * sc[a])));
+    return (c[0] * G + c[1]) * G + c[2];
+}
+
+template <bool FMA, int NT>
+__global__ __launch_bounds__(NT) void fps_bucket_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths, int N, int K,
+                                                          int32_t* __restrict__ idx_out, float* __restrict__ pts_out, char* __restrict__ ws,
+                                                          size_t ws_stride) {
+    __shared__ int s_cnt[FB_MAXB];        // bucket arg index (original index of its largest running minimum)
+    __shared__ int s_start[FB_MAXB + 1];  // first point of a bucket in the bucket-contiguous copy
+    __shared__ float s_max[FB_MAXB];      // largest running minimum of a bucket (-inf: empty bucket)
+    __shared__ unsigned short s_work[FB_MAXB];
+    __shared__ float s_red[(NT / 64) * 6];
+    __shared__ int s_redi[NT / 64];
+    __shared__ int s_nwork;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = pts + (size_t)b * N * 3;
+    const int n = lengths ? min(lengths[b], N) : N;
+    int32_t* out = idx_out + (size_t)b * K;
+    float* po = pts_out ? pts_out + (size_t)b * K * 3 : nullptr;
+    const int kk = min(K, n);
+    // per-cloud scratch
+    char* w = ws + (size_t)b * ws_stride;
+    float* ppts = (float*)w;                                  // [N][3] bucket-contiguous copy of the cloud
+    int32_t* pidx = (int32_t*)(ppts + (size_t)N * 3);         // [N] original index
+    float* md = (float*)(pidx + N);                           // [N] running minimum
+    int* hist = (int*)(md + N);                               // [FB_CELLS] points per grid cell -> running scatter offset (L2 atomics only)
+    int32_t* bstart = hist + FB_CELLS;                        // [FB_MAXB + 1]
+
+    if (n > 0) {
+        // ---- bounding box of the cloud
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = tid; i < n; i += NT)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float v = p[(size_t)i * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+            if (lane == 0) { s_red[wave * 6 + a] = lo[a]; s_red[wave * 6 + 3 + a] = hi[a]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int ww = 0; ww < NT / 64; ++ww) { lo[a] = fminf(lo[a], s_red[ww * 6 + a]); hi[a] = fmaxf(hi[a], s_red[ww * 6 + 3 + a]); }
+        // ---- counting sort on a uniform grid; the buckets are its NON-EMPTY cells.  Scanner clouds are surfaces: a 32^3 grid has a few
+        //      thousand occupied cells of ~15-40 points; a cloud that fills the volume (more than FB_MAXB occupied cells) drops to 16^3.
+        int G = 32, NB = 0;
+        float sc[3];
+        for (;; G = 16) {
+            const int NC = G * G * G, per = NC / NT;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) sc[a] = (float)G / fmaxf(hi[a] - lo[a], 1e-30f);
+            for (int c = tid; c < NC; c += NT) __hip_atomic_store(&hist[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            for (int i = tid; i < n; i += NT) atomicAdd(&hist[fb_cell(p, i, lo, sc, G)], 1);
+            __syncthreads();
+            // exclusive scans over the cells (per consecutive cells per thread): point offset, and bucket id = rank among non-empty cells
+            const int c0 = tid * per;
+            int sum = 0, nz = 0;
+            for (int e = 0; e < per; ++e) {
+                const int h = __hip_atomic_load(&hist[c0 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sum += h; nz += h > 0;
+            }
+            int isum = sum, inz = nz;   // inclusive wave scans
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t1 = __shfl_up(isum, o, 64), t2 = __shfl_up(inz, o, 64);
+                if (lane >= o) { isum += t1; inz += t2; }
+            }
+            if (lane == 63) { s_redi[wave] = isum; s_cnt[wave] = inz; }
+            __syncthreads();
+            int run = isum - sum, bk = inz - nz, tot = 0;
+            for (int ww = 0; ww < NT / 64; ++ww) { if (ww < wave) { run += s_redi[ww]; bk += s_cnt[ww]; } tot += s_cnt[ww]; }
+            NB = tot;
+            __syncthreads();            // s_redi / s_cnt are free again
+            if (NB > FB_MAXB && G == 32) continue;
+            for (int e = 0; e < per; ++e) {
+                const int h = __hip_atomic_load(&hist[c0 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (h > 0) bstart[bk++] = run;
+                __hip_atomic_store(&hist[c0 + e], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run += h;
+            }
+            if (tid == 0) bstart[NB] = n;
+            break;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            const int pos = atomicAdd(&hist[fb_cell(p, i, lo, sc, G)], 1);   // order inside a bucket is arbitrary: nothing depends on it
+            ppts[(size_t)pos * 3] = p[(size_t)i * 3]; ppts[(size_t)pos * 3 + 1] = p[(size_t)i * 3 + 1]; ppts[(size_t)pos * 3 + 2] = p[(size_t)i * 3 + 2];
+            pidx[pos] = i;
+            md[pos] = INFINITY;
+        }
+        for (int c = tid; c <= NB; c += NT) s_start[c] = bstart[c];
+        __syncthreads();
+        // thread t owns buckets t, t + 1024, ...: their exact boxes live in its registers for the whole run
+        constexpr int E = FB_MAXB / NT, NW = NT / 64;   // buckets per thread, waves
+        float bx[E][6];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = tid + NT * e;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { bx[e][a] = INFINITY; bx[e][3 + a] = -INFINITY; }
+            if (c < NB) {
+                const int s0 = s_start[c], e0 = s_start[c + 1];
+                for (int j = s0; j < e0; ++j)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { const float v = ppts[(size_t)j * 3 + a]; bx[e][a] = fminf(bx[e][a], v); bx[e][3 + a] = fmaxf(bx[e][3 + a], v); }
+                s_max[c] = e0 > s0 ? INFINITY : -INFINITY;    // +inf: the first step visits every non-empty bucket
+                s_cnt[c] = INT_MAX;                           // from here on: the bucket's arg index
+            }
+        }
+        if (tid == 0) { s_nwork = 0; out[0] = 0; if (po) { po[0] = p[0]; po[1] = p[1]; po[2] = p[2]; } }
+        __syncthreads();
+
+        // ---- the K - 1 dependent steps
+        int last = 0;
+        const int sub = lane >> 4, sl = lane & 15;
+        for (int k = 1; k < kk; ++k) {
+            const float lx = p[(size_t)last * 3], ly = p[(size_t)last * 3 + 1], lz = p[(size_t)last * 3 + 2];
+            // 1. which buckets can change?  per-axis gap to the box, then the canonical formula on the gaps: a lower bound of every
+            //    point's COMPUTED distance
+            bool hit[E];
+            int cnt = 0;
+            unsigned long long mask[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int c = tid + NT * e;
+                hit[e] = false;
+                if (c < NB) {
+                    const float bm = s_max[c];
+                    const float gx = lx > bx[e][3] ? lx - bx[e][3] : (lx < bx[e][0] ? bx[e][0] - lx : 0.f);
+                    const float gy = ly > bx[e][4] ? ly - bx[e][4] : (ly < bx[e][1] ? bx[e][1] - ly : 0.f);
+                    const float gz = lz > bx[e][5] ? lz - bx[e][5] : (lz < bx[e][2] ? bx[e][2] - lz : 0.f);
+                    hit[e] = dist3<FMA>(gx, gy, gz, 0.f, 0.f, 0.f) < bm;   // empty bucket: bm = -inf, never
+                }
+                mask[e] = __ballot(hit[e]);
+                cnt += __popcll(mask[e]);
+            }
+            if (cnt) {   // wave-uniform: one LDS atomic per wave
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nwork, cnt);
+                base = __shfl(base, 0, 64);
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (hit[e]) s_work[base + __popcll(mask[e] & below)] = (unsigned short)(tid + NT * e);
+                    base += __popcll(mask[e]);
+                }
+            }
+            __syncthreads();
+            // 2. update them: 16 lanes per bucket
+            const int nw = s_nwork;
+            for (int it0 = wave * 4; it0 < nw; it0 += NW * 4) {   // wave-uniform bound: the four 16-lane groups stay in the loop together
+                const int it = it0 + sub;
+                float v = -INFINITY;
+                int bi = INT_MAX, c = -1;
+                if (it < nw) {
+                    c = s_work[it];
+                    const int s0 = s_start[c], e0 = s_start[c + 1];
+                    for (int j = s0 + sl; j < e0; j += 16) {
+                        const float d = dist3<FMA>(lx, ly, lz, ppts[(size_t)j * 3], ppts[(size_t)j * 3 + 1], ppts[(size_t)j * 3 + 2]);
+                        const float mm = fminf(md[j], d);
+                        md[j] = mm;
+                        const int oi = pidx[j];
+                        if (mm > v || (mm == v && oi < bi)) { v = mm; bi = oi; }
+                    }
+                }
+                // 16-lane arg-max on the DPP network (keys as below; every lane of the row ends up with the row's maximum)
+                unsigned gh = bi != INT_MAX ? __float_as_uint(v) + 1u : 0u, gl = bi != INT_MAX ? ~(unsigned)bi : 0u;
+                dpp_max_u64<0xB1, 0xF>(gh, gl);
+                dpp_max_u64<0x4E, 0xF>(gh, gl);
+                dpp_max_u64<0x141, 0xF>(gh, gl);
+                dpp_max_u64<0x140, 0xF>(gh, gl);
+                if (c >= 0 && sl == 0) { s_max[c] = __uint_as_float(gh - 1u); s_cnt[c] = (int)~gl; }
+            }
+            __syncthreads();
+            // 3. arg-max over the bucket maxima
+            if (tid == 0) s_nwork = 0;
+            float bv = -INFINITY;
+            int bi = INT_MAX;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int c = tid + NT * e;
+                if (c < NB) {
+                    const float v = s_max[c];
+                    const int oi = s_cnt[c];
+                    if (v > bv || (v == bv && oi < bi)) { bv = v; bi = oi; }
+                }
+            }
+            // (value >= 0, index) as one 64-bit key (see wave_argmax_dpp): larger value, then smaller index = unsigned max; key 0 = nothing
+            unsigned khi = bi != INT_MAX ? __float_as_uint(bv) + 1u : 0u, klo = bi != INT_MAX ? ~(unsigned)bi : 0u;
+            wave_max_key_dpp(khi, klo);
+            if (lane == 0) { s_red[wave] = __uint_as_float(khi); s_redi[wave] = (int)klo; }
+            __syncthreads();
+            {   // every wave reduces the 16 partial results itself: no second barrier for a broadcast, and `last` is wave-uniform
+                khi = lane < NW ? __float_as_uint(s_red[lane]) : 0u;
+                klo = lane < NW ? (unsigned)s_redi[lane] : 0u;
+                wave_max_key_dpp(khi, klo);
+                last = (int)~klo;
+            }
+            if (tid == 0) {
+                out[k] = last;
+                if (po) { po[k * 3] = p[(size_t)last * 3]; po[k * 3 + 1] = p[(size_t)last * 3 + 1]; po[k * 3 + 2] = p[(size_t)last * 3 + 2]; }
+            }
+            // s_red / s_redi are rewritten after the next step's second barrier, s_nwork was reset before this step's third one
+        }
+    }
+    for (int k = max(kk, 0) + tid; k < K; k += NT) {
+        out[k] = -1;
+        if (po) { po[k * 3 + 0] = 0.f; po[k * 3 + 1] = 0.f; po[k * 3 + 2] = 0.f; }
+    }
+}
+
+size_t fps_scratch_bytes_per_cloud(int N) {
+    if (N <= 8192) return 0;
+    size_t b = (size_t)N * (12 + 4 + 4) + (size_t)(FB_CELLS + FB_MAXB + 1) * 4;
+    return (b + 255) & ~(size_t)255;
+}
+
 template <int PPL, bool FMA>
 static int launch_wave(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
     hipLaunchKernelGGL((fps_wave_kernel<PPL, FMA>), dim3(B), dim3(64), (size_t)N * 3 * sizeof(float), st, pts, lengths, N, K, idx, po);
@@ -279,7 +531,8 @@ static int launch_block(const float* pts, const int32_t* lengths, int B, int N, 
 }
 
 template <bool FMA>
-static int fps_mode(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, hipStream_t st) {
+static int fps_mode(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, void* ws, size_t ws_bytes,
+                    hipStream_t st) {
     static const bool one_wave = getenv("LS_FPS_ONE_WAVE") && atoi(getenv("LS_FPS_ONE_WAVE")) != 0;   // A/B: the one-wave kernel
     if (N <= 128) return launch_wave<2, FMA>(pts, lengths, B, N, K, idx, po, st);
     if (!one_wave) {
@@ -292,16 +545,28 @@ static int fps_mode(const float* pts, const int32_t* lengths, int B, int N, int 
     if (N <= 1024) return launch_wave<16, FMA>(pts, lengths, B, N, K, idx, po, st);
     if (N <= 2048) return launch_wave<32, FMA>(pts, lengths, B, N, K, idx, po, st);
     if (N <= 8192) return launch_block<8, FMA>(pts, lengths, B, N, K, idx, po, st);
-    if (N <= 65536) return launch_block<64, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 65536) {
+        static const bool full_scan = getenv("LS_FPS_FULL_SCAN") && atoi(getenv("LS_FPS_FULL_SCAN")) != 0;   // A/B: the un-bucketed block kernel
+        const size_t per = fps_scratch_bytes_per_cloud(N);
+        if (ws && ws_bytes >= per * (size_t)B && !full_scan) {
+            static const int nt = getenv("LS_FPS_BUCKET_THREADS") ? atoi(getenv("LS_FPS_BUCKET_THREADS")) : 1024;   // A/B
+            if (nt == 256) hipLaunchKernelGGL((fps_bucket_kernel<FMA, 256>), dim3(B), dim3(256), 0, st, pts, lengths, N, K, idx, po, (char*)ws, per);
+            else if (nt == 512) hipLaunchKernelGGL((fps_bucket_kernel<FMA, 512>), dim3(B), dim3(512), 0, st, pts, lengths, N, K, idx, po, (char*)ws, per);
+            else hipLaunchKernelGGL((fps_bucket_kernel<FMA, 1024>), dim3(B), dim3(1024), 0, st, pts, lengths, N, K, idx, po, (char*)ws, per);
+            LS_LAUNCH_CHECK();
+            return LS_OK;
+        }
+        return launch_block<64, FMA>(pts, lengths, B, N, K, idx, po, st);   // no scratch handed in: the full scan per step (same result)
+    }
     set_error("fps: N=%d too large (max 65536)", N);
     return LS_ERR_INVALID;
 }
 
 int fps_dispatch(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out,
-                 float* pts_out, hipStream_t st) {
+                 float* pts_out, void* ws, size_t ws_bytes, hipStream_t st) {
     LS_REQUIRE(B > 0 && N > 0 && K > 0, "fps: empty problem (B=%d N=%d K=%d)", B, N, K);
-    return (flags & LS_FLAG_CONTRACT_FMA) ? fps_mode<true>(pts, lengths, B, N, K, idx_out, pts_out, st)
-                                          : fps_mode<false>(pts, lengths, B, N, K, idx_out, pts_out, st);
+    return (flags & LS_FLAG_CONTRACT_FMA) ? fps_mode<true>(pts, lengths, B, N, K, idx_out, pts_out, ws, ws_bytes, st)
+                                          : fps_mode<false>(pts, lengths, B, N, K, idx_out, pts_out, ws, ws_bytes, st);
 }
 
 }  // namespace ls

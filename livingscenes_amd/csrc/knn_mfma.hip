@@ -817,7 +817,8 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
                            epsE, seedkeys, surv_cnt, surv);
     }
     LS_LAUNCH_CHECK();
-    if constexpr (CC == 32) {
+    static const bool finish_wave32 = getenv("LS_KNN_FINISH_WAVE32") && atoi(getenv("LS_KNN_FINISH_WAVE32")) != 0;   // A/B
+    if (CC == 32 && !finish_wave32) {
         if (fma)
             hipLaunchKernelGGL((knn_finish_kernel<CC, true>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seedkeys,
                                surv_cnt, surv, idx_out, dist_out, groups, B * groups);

@@ -24,7 +24,8 @@ int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int,
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags);
 int knn_compose_hints_launch(const int32_t* prev_knn, const int32_t* prev_rows, int B, int Nd, int Ns, int32_t* inv, int32_t* hints, hipStream_t st);
 bool knn_would_sweep(int C, int Ns, unsigned flags);
-int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, hipStream_t);
+int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, void*, size_t, hipStream_t);
+size_t fps_scratch_bytes_per_cloud(int N);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
 int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
@@ -328,9 +329,13 @@ int ls_knn_f32(const float* dst, const float* src, const int32_t* dst_rows, cons
     }
     return knn_dispatch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, flags, idx_out, dist_out, workspace, seed_idx, Nd, 0, (hipStream_t)stream);
 }
+size_t ls_fps_workspace_bytes(int B, int N, int K) {
+    (void)K;
+    return (B > 0 && N > 0) ? fps_scratch_bytes_per_cloud(N) * (size_t)B : 0;
+}
 int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, unsigned flags, int32_t* idx_out, float* pts_out,
-               void* stream) {
-    return fps_dispatch(pts, lengths, B, N, K, flags, idx_out, pts_out, (hipStream_t)stream);
+               void* workspace, size_t workspace_bytes, void* stream) {
+    return fps_dispatch(pts, lengths, B, N, K, flags, idx_out, pts_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 size_t ls_gemm_workspace_bytes(int M, int N, int K) {
     return (M > 0 && N > 0 && K > 0 && K % 4 == 0) ? gemm_scratch_floats(M, N, K) * sizeof(float) : 0;
@@ -483,7 +488,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             toff += (size_t)B * p.levelN[l + 1];
             {
                 PROF(LS_K_FPS, l, fs);
-                rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), fs);
+                rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), nullptr, 0, fs);
             }
             if (rc != LS_OK) return rc;
         }

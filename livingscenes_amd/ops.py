@@ -45,7 +45,9 @@ def fps(pts, K, lengths=None, flags=DEFAULT_FLAGS, return_points=False):
     out = torch.empty(B, K, 3, dtype=torch.float32, device=pts.device) if return_points else None
     if lengths is not None:
         lengths = lengths.to(device=pts.device, dtype=torch.int32).contiguous()
-    call(pts.device, "ls_fps_f32", ptr(pts), ptr(lengths), B, N, K, flags, ptr(idx), ptr(out), stream_ptr(pts.device))
+    ws = _scratch(load().ls_fps_workspace_bytes(B, N, K), pts.device)
+    call(pts.device, "ls_fps_f32", ptr(pts), ptr(lengths), B, N, K, flags, ptr(idx), ptr(out), ptr(ws), 0 if ws is None else ws.numel(),
+         stream_ptr(pts.device))
     return (idx, out) if return_points else idx
 
 

@@ -221,6 +221,38 @@ def test_fps_bit_exact(N, K, contract):
     assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(p, ref[..., None].astype(np.int64), 1))
 
 
+@pytest.mark.parametrize("contract", [0, 1])
+def test_fps_raw_cloud_bucketed_scan_bit_exact(contract):
+    """Clouds above 8 192 points take the bucketed, pruned scan (fps.hip: fps_bucket_kernel): same indices as the full scan of the
+    oracle on scanner-like clouds (surfaces, not blobs), ragged lengths on both sides of the 8^3 / 16^3 grid switch, duplicated
+    points (tie -> smallest original index), a planar and a fully degenerate cloud."""
+    from livingscenes_amd import ops
+    from oracle import canon
+    rng = np.random.default_rng(77 + contract)
+    N = 60000
+    p = np.zeros((7, N, 3), np.float32)
+    u = rng.random((N, 2)).astype(np.float32)
+    p[0] = np.stack([u[:, 0] * 3, u[:, 1] * 2, 0.2 * np.sin(4 * u[:, 0]) + 0.01 * rng.standard_normal(N)], 1)    # a bumpy sheet
+    d = rng.standard_normal((N, 3)).astype(np.float32)
+    p[1] = d / np.linalg.norm(d, axis=1, keepdims=True) * np.float32(0.7) + np.float32(5.0)                         # a sphere shell, off-centre
+    p[2] = rng.standard_normal((N, 3)).astype(np.float32)
+    p[2, 30000:] = p[2, :30000]                                                                                   # every point twice
+    p[3] = rng.standard_normal((N, 3)).astype(np.float32); p[3, :, 2] = 1.5                                        # planar: one axis has no extent
+    p[4] = 0.25                                                                                                   # all points identical
+    p[5] = rng.standard_normal((N, 3)).astype(np.float32) * np.float32(1e-3)
+    p[6] = rng.standard_normal((N, 3)).astype(np.float32)
+    lens = np.array([60000, 60000, 60000, 20000, 9000, 12000, 700], np.int32)
+    ref = canon.fps_c(p, 1024, lengths=lens, contract=contract)
+    idx, pts = ops.fps(torch.from_numpy(p).to(_dev()), 1024, lengths=torch.from_numpy(lens), flags=contract, return_points=True)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    sel = np.take_along_axis(p, np.maximum(ref, 0)[..., None].astype(np.int64), 1) * (ref >= 0)[..., None]
+    assert np.array_equal(pts.cpu().numpy(), sel)
+    q = rng.standard_normal((2, 8200, 3)).astype(np.float32)                                                       # just above the switch, K > n on one
+    lq = np.array([8200, 100], np.int32)
+    assert np.array_equal(ops.fps(torch.from_numpy(q).to(_dev()), 300, lengths=torch.from_numpy(lq)).cpu().numpy(),
+                          canon.fps_c(q, 300, lengths=lq))
+
+
 def test_fps_one_wave_switch():
     """LS_FPS_ONE_WAVE=1 keeps the one-wave kernel for 256..2048-point clouds (A/B): same indices."""
     import os, subprocess, sys

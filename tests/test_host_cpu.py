@@ -63,7 +63,7 @@ def test_argument_validation_without_device(lib):
     assert gneed > 0 and lib.ls_gemm_f32(P(16), 512, P(16), 512, None, P(16), 1024, 192, 1024, 512, 0, None, 0, None) == -3
     assert lib.ls_cosine_scores_workspace_bytes(32, 32) == 64 * 4
     assert lib.ls_cosine_scores_f32(P(16), P(16), 32, 32, 256, P(16), None, 0, None) == -3
-    assert lib.ls_fps_f32(P(16), None, 1, 100000, 8, 0, P(16), None, None) == -1
+    assert lib.ls_fps_f32(P(16), None, 1, 100000, 8, 0, P(16), None, None, 0, None) == -1
     assert b"too large" in lib.ls_last_error()
 
 
