@@ -14,6 +14,7 @@
 // that every lane fetches its four k-values with ONE ds_read_b128; A and B use the same permutation, so the
 // product is unchanged.  Next-tile global loads are issued before the MFMA block (register double buffer).
 #include "ls_common.h"
+#include <string.h>
 
 namespace ls {
 
@@ -40,6 +41,31 @@ __device__ __forceinline__ void split3_bf16(const float4& v, uint2& p1, uint2& p
     p2.x = cvt2_bf16(r1l); p2.y = cvt2_bf16(r1h);
     const f32x2_t r2l = r1l - expand2_bf16(p2.x), r2h = r1h - expand2_bf16(p2.y);
     p3.x = cvt2_bf16(r2l); p3.y = cvt2_bf16(r2h);
+}
+
+
+// ---- fp32 GEMM on the f16 matrix cores ("2 x f16 split, scaled residual", PIECES = 22).  a = h + l / 1024 with h = f16(a) (11
+// significant bits) and l = f16((a - h) * 1024) (the residual is exact in fp32; scaled, it keeps 11 more bits and stays clear of
+// the f16 subnormal range for |a| >= 2^-13): |a - (h + l/1024)| <= 2^-22 |a|.  The matrix core takes f16 subnormals as they are
+// (scripts/ubench/f16_denorm.hip), so small |a| degrade gracefully: the absolute error never exceeds 2^-35.
+// a b = h_a h_b + (h_a l_b + l_a h_b) / 1024 + O(2^-21 |a b|): THREE v_mfma_f32_32x32x16_f16 per 16 k, the main term and the two
+// cross terms in separate fp32 accumulators that meet in the epilogue.  Against fp64 the result is as close as with the
+// three-piece bf16 split (scripts/gemm_microbench.py --check: 6.5 - 7.3 vs 5.9 - 8.4 units of 2^-24 sum|a||w| at K = 32 .. 768 --
+// both are the fp32 accumulation error any fp32 GEMM carries; the split error itself is 8e-8 of the largest output) at half the
+// matrix-pipe time and three VALU instructions per split value (v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add, v_pk_mul,
+// v_cvt_pk_f16_f32 per PAIR) instead of 5.5.  Precondition: |a| < 65 504 (f16 range); the encoder's normalised features and the
+// decoder's activations are O(1 - 100).  LS_GEMM_MODE=bf16x3 keeps the six-MFMA split (any fp32 range).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2_f16_pair(f32x2_t v, unsigned& h, unsigned& l) {
+    const f16x2_t hv = __builtin_convertvector(v, f16x2_t);
+    const f16x2_t lv = __builtin_convertvector((v - __builtin_convertvector(hv, f32x2_t)) * 1024.f, f16x2_t);
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, lv);
+}
+__device__ __forceinline__ void split2_f16(const float4& v, uint2& h, uint2& l) {
+    split2_f16_pair(f32x2_t{v.x, v.y}, h.x, l.x);
+    split2_f16_pair(f32x2_t{v.z, v.w}, h.y, l.y);
 }
 
 constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
@@ -104,7 +130,7 @@ __device__ unsigned long long ls_gemm_prof[8];
 // PIECES = 2 (opt-in, LS_SDF_BF16X2): a = a1 + a2 only, three MFMAs per 16 k (a1b1 + a1b2 + a2b1); products carry a 2^-16
 // relative error instead of 2^-24 -- a decode mode for throughput, never the default.
 template <bool SPLIT, int PIECES = 3>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
                                                        int ldc, int M, int N, int K, int relu, int ntiles_n,
                                                        const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk,
@@ -127,13 +153,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
     out += (size_t)blockIdx.y * slab_stride;
 
-    f32x16 acc[2][2];
+    constexpr bool H2 = PIECES == 22;   // two f16 pieces, scaled residual (see split2_f16)
+    f32x16 acc[2][2], acx[H2 ? 2 : 1][H2 ? 2 : 1];   // acx: the cross terms (x 1024) of the f16 split
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; if constexpr (H2) acx[i][j][r] = 0.0f; }
 
     // staging map.  fp32 path: 128 rows x 4 float4 per operand slab, two per thread (rows sr0, sr0 + 64).  SPLIT: 128 rows x 8
     // float4 (32 k), four per thread (rows sr0 + 32 u)
@@ -172,6 +199,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             if constexpr (SPLIT) {
                 const int swz = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
                 uint2 p1, p2, p3;
+                if constexpr (H2) {
+                    split2_f16(ra[h], p1, p2);
+                    *reinterpret_cast<uint2*>(Ap + swz) = p1;
+                    *reinterpret_cast<uint2*>(Ap + PLANE + swz) = p2;
+                    split2_f16(rb[h], p1, p2);
+                    *reinterpret_cast<uint2*>(Bp + swz) = p1;
+                    *reinterpret_cast<uint2*>(Bp + PLANE + swz) = p2;
+                    continue;
+                }
                 split3_bf16(ra[h], p1, p2, p3);
                 *reinterpret_cast<uint2*>(Ap + swz) = p1;
                 *reinterpret_cast<uint2*>(Ap + PLANE + swz) = p2;
@@ -206,13 +242,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         if constexpr (SPLIT) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {   // the slab's two 16-k halves; lane (row lr, lane>>5) holds k = 16 s2 + 8 (lane>>5) .. +7
-                bf16x8_t a[2][3], b[2][3];
                 const int q = s2 * 2 + (lane >> 5);
+                if constexpr (H2) {
+                    f16x8_t a[2][2], b[2][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int rowa = wm * 64 + i * 32 + lr, rowb = wn * 64 + i * 32 + lr;
+#pragma unroll
+                        for (int pc = 0; pc < 2; ++pc) {
+                            a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ap + pc * PLANE + rowa * 64 + ((q ^ ((rowa >> 2) & 3)) << 4)));
+                            b[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bp + pc * PLANE + rowb * 64 + ((q ^ ((rowb >> 2) & 3)) << 4)));
+                        }
+                    }
+                    // term-major: eight independent accumulator chains
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+                    continue;
+                }
+                bf16x8_t a[2][3], b[2][3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int rowa = wm * 64 + i * 32 + lr, rowb = wn * 64 + i * 32 + lr;
 #pragma unroll
-                    for (int p3 = 0; p3 < PIECES; ++p3) {
+                    for (int p3 = 0; p3 < (H2 ? 2 : PIECES); ++p3) {
                         a[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ap + p3 * PLANE + rowa * 64 + ((q ^ ((rowa >> 2) & 3)) << 4)));
                         b[i][p3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bp + p3 * PLANE + rowb * 64 + ((q ^ ((rowb >> 2) & 3)) << 4)));
                     }
@@ -265,12 +327,171 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r];
+                if constexpr (H2) v = fmaf(acx[i][j][r], 0.0009765625f, v);
+                v += bv;
                 if (relu) v = fmaxf(v, 0.0f);
                 stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
             }
         }
         // wave-local hand-off through LDS: same wave writes and reads, LDS ops of a wave complete in order
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The f16-split GEMM as a software pipeline.  In gemm_f32_kernel a slab goes barrier -> split + LDS store -> barrier -> LDS reads +
+// MFMAs, one after the other (measured at M = 262 144, N = K = 512: 39 % / 44 % of a wave's time in the two halves, the matrix pipe
+// 30 % busy with two workgroups per CU).  Here the LDS operand area is double-buffered: while the 24 MFMAs of slab t run out of
+// buffer t & 1, the same wave splits the global data of slab t+1 (already in registers) into buffer (t+1) & 1 and issues the loads
+// of slab t+2 -- VALU, LDS stores and global loads interleaved with the matrix instructions in one basic block, one barrier per slab.
+// Same arithmetic as gemm_f32_kernel<true, 22> (same products, same accumulation order per accumulator): bit-identical results.
+template <bool KAL>   // K range of this launch is a whole number of 32-k slabs
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_h2_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc,
+    int M, int N, int K, int relu, int ntiles_n, const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk, size_t slab_stride,
+    const float* __restrict__ mask) {
+    constexpr int STG = 32 * 68;
+    constexpr int PLANE = GM * 64;         // one f16 plane: 128 rows x 32 k
+    constexpr int BUF = 4 * PLANE;         // A hi, A lo, B hi, B lo
+    static_assert(2 * BUF >= 4 * STG * 4, "epilogue staging aliases the operand buffers");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = logical / ntiles_n, tn = logical % ntiles_n;
+    const int m0 = tm * GM, n0 = tn * GN;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+    out += (size_t)blockIdx.y * slab_stride;
+
+    f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+
+    // staging map: 128 rows x 8 float4 (32 k) per operand slab, four per thread (rows sr0 + 32 h).  Rows past M / N are clamped
+    // (computed, never stored) and so is k past the end (KAL: whole slabs, the data is never used; otherwise per float4, zeroed by
+    // a select) -- no predicated load, so that the k-loop stays one basic block the scheduler can interleave.
+    const int sr0 = tid >> 3, sk = (tid & 7) * 4;
+    float4 ra[4], rb[4];
+    const float* arow[4];
+    const float* brow[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int gm = min(m0 + sr0 + h * 32, M - 1), gn = min(n0 + sr0 + h * 32, N - 1);
+        size_t r = (size_t)gm;
+        if (a_rows) {
+            const int pt = gm / 3, x = gm - pt * 3;
+            const int bb = pt / gNd;
+            r = ((size_t)bb * gNs + a_rows[pt]) * 3 + x;
+        }
+        arow[h] = A + r * lda;
+        brow[h] = W + (size_t)gn * ldw;
+    }
+    auto kof = [&](int k0) { return KAL ? min(k0, kend - 32) + sk : min(k0 + sk, kend - 4); };
+    auto gload_a = [&](int k0) {
+        const int ko = kof(k0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            ra[h] = *reinterpret_cast<const float4*>(arow[h] + ko);
+            if (!KAL && k0 + sk >= kend) ra[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto gload_b = [&](int k0) {
+        const int ko = kof(k0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            rb[h] = *reinterpret_cast<const float4*>(brow[h] + ko);
+            if (!KAL && k0 + sk >= kend) rb[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // plane = 128 rows x 64 bytes; the 16-byte slot index (k / 8) is XOR-ed with bits 2-3 of the row (conflict-free b128 reads)
+    int swz[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = sr0 + h * 32;
+        swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
+    }
+    auto lstore2 = [&](char* plane_hi, const float4& v, int off) {
+        uint2 ph, pl;
+        split2_f16(v, ph, pl);
+        *reinterpret_cast<uint2*>(plane_hi + off) = ph;
+        *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
+    };
+    const int lr = lane & 31;
+    int offa[2], offb[2];   // byte offset of this lane's operand row inside a plane, per 32-row MFMA tile (slot XOR applied per half)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { offa[i] = (wm * 64 + i * 32 + lr) * 64; offb[i] = (wn * 64 + i * 32 + lr) * 64; }
+    const int xa[2] = {((wm * 64 + lr) >> 2) & 3, ((wm * 64 + 32 + lr) >> 2) & 3}, xb[2] = {((wn * 64 + lr) >> 2) & 3, ((wn * 64 + 32 + lr) >> 2) & 3};
+
+    gload_a(kbeg); gload_b(kbeg);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], swz[h]); }
+    gload_a(kbeg + 32); gload_b(kbeg + 32);
+    __syncthreads();
+
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 32, cur ^= 1) {
+        const char* Ac = smem + cur * BUF;
+        const char* Bc = Ac + 2 * PLANE;
+        char* An = smem + (cur ^ 1) * BUF;
+        char* Bn = An + 2 * PLANE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {   // the slab's two 16-k halves; lane (row lr, lane >> 5) holds k = 16 s2 + 8 (lane >> 5) .. +7
+            const int q = s2 * 2 + (lane >> 5);
+            f16x8_t a[2][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
+                    b[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + offb[i] + ((q ^ xb[i]) << 4)));
+                }
+            // term-major, eight independent accumulator chains; between the three groups of four MFMAs: the split of the NEXT slab
+            // (first half: the A rows, second half: the W rows), then the loads of the slab after it
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+            if (s2 == 0) { lstore2(An, ra[0], swz[0]); lstore2(An, ra[1], swz[1]); } else { lstore2(Bn, rb[0], swz[0]); lstore2(Bn, rb[1], swz[1]); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            if (s2 == 0) { lstore2(An, ra[2], swz[2]); lstore2(An, ra[3], swz[3]); gload_a(k0 + 64); }
+            else { lstore2(Bn, rb[2], swz[2]); lstore2(Bn, rb[3], swz[3]); gload_b(k0 + 64); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
+    }
+
+    // epilogue: as gemm_f32_kernel (each wave transposes its 64x64 sub-tile through LDS in two 32-row halves)
+    float* stg = reinterpret_cast<float*>(smem) + wave * STG;
+    const int col_l = lane & 31, rowh = (lane >> 5) * 4;
+    const bool vec_ok = (ldc % 4 == 0) && (((uintptr_t)out & 15) == 0);
+    const bool full_tile = vec_ok && (m0 + GM <= M) && (n0 + GN <= N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + wn * 64 + j * 32 + col_l;
+            const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) + bv;
+                if (relu) v = fmaxf(v, 0.0f);
+                stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask);
@@ -467,13 +688,22 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     // conv, M = 3B), where the fp32 kernel's shorter slab (16 k, no split arithmetic before the first MFMA) wins: 44 vs 112 us
     // at M = 192, N = 1024, K = 512
     const bool split = split_on && !latency_path;
+    // how an fp32 product is formed on the 16-bit matrix cores: 22 = two f16 pieces with a scaled residual (three MFMAs per 16 k, the
+    // default), 3 = three bf16 pieces (six MFMAs, any fp32 range: LS_GEMM_MODE=bf16x3), 2 = two bf16 pieces (opt-in decode mode)
+    static const bool h2_unpipelined = getenv("LS_GEMM_H2_SIMPLE") && atoi(getenv("LS_GEMM_H2_SIMPLE")) != 0;   // A/B: the two-barrier kernel
+#define LS_H2_KERNEL ((h2_unpipelined || K <= 64) ? gemm_f32_kernel<true, 22> : (K % 32 == 0 ? gemm_h2_kernel<true> : gemm_h2_kernel<false>))
+    static const int default_pieces = (getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) ? 3 : 22;
+    if (pieces == 3) pieces = default_pieces;
     const int nsplit = (scratch && !mask) ? gemm_choose_splits(M, N, K) : 1;
     if (nsplit > 1) {
         const int kq = split ? 32 : GK;
         int kchunk = cdiv(cdiv(K, nsplit), kq) * kq;
         const int ns = cdiv(K, kchunk);
         const size_t slab = (size_t)M * N;
-        if (split)
+        if (split && pieces == 22)
+            hipLaunchKernelGGL(LS_H2_KERNEL, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
+                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr);
+        else if (split)
             hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
                                a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr);
         else
@@ -485,7 +715,10 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         LS_LAUNCH_CHECK();
         return LS_OK;
     }
-    if (split && pieces == 2)
+    if (split && pieces == 22)
+        hipLaunchKernelGGL(LS_H2_KERNEL, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
+                           gNd, gNs, K, (size_t)0, mask);
+    else if (split && pieces == 2)
         hipLaunchKernelGGL((gemm_f32_kernel<true, 2>), dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
                            gNd, gNs, K, (size_t)0, mask);
     else if (split)

@@ -66,14 +66,18 @@ def _to_rows(f):
     return f.permute(0, 3, 2, 1).contiguous().numpy()
 
 
-def knn_points(dst_flat, src_flat, K, C):
+def knn_points(dst_flat, src_flat, K, C, idx=None):
     """pytorch3d.ops.knn_points(dst [B,Nd,3C], src [B,Ns,3C], K, return_nn=True) as called at
-    vec_dgcnn_atten.py:139-141; feature index j = c*3+x (reshape of [B,C,3,N] at :138)."""
+    vec_dgcnn_atten.py:139-141; feature index j = c*3+x (reshape of [B,C,3,N] at :138).
+    ``idx`` (tests only): neighbour lists to use instead of searching -- see encoder_forward(graph=...)."""
     B, Nd, D = dst_flat.shape
     Ns = src_flat.shape[1]
-    d = dst_flat.reshape(B, Nd, C, 3).permute(0, 1, 3, 2).contiguous().numpy()
-    s = src_flat.reshape(B, Ns, C, 3).permute(0, 1, 3, 2).contiguous().numpy()
-    idx = torch.from_numpy(canon.knn_c(d, s, K, contract=KNN_CONTRACT).astype(np.int64))
+    if idx is None:
+        d = dst_flat.reshape(B, Nd, C, 3).permute(0, 1, 3, 2).contiguous().numpy()
+        s = src_flat.reshape(B, Ns, C, 3).permute(0, 1, 3, 2).contiguous().numpy()
+        idx = torch.from_numpy(canon.knn_c(d, s, K, contract=KNN_CONTRACT).astype(np.int64))
+    else:
+        idx = torch.as_tensor(idx).to(torch.int64).reshape(B, Nd, K)
     nn = torch.gather(src_flat[:, None].expand(-1, Nd, -1, -1), 2, idx[..., None].expand(-1, -1, -1, D))
     return None, idx, nn
 
@@ -87,14 +91,14 @@ def sample_farthest_points(points, K, lengths=None):
 
 
 # ----------------------------------------------------------------------------- encoder
-def get_graph_feature(src_f, dst_f, k, cross):
+def get_graph_feature(src_f, dst_f, k, cross, idx=None):
     """VecDGCNN_att.get_graph_feature, use_dg branch: vec_dgcnn_atten.py:124-161.
     Conscious divergence: the reference calls torch.cross WITHOUT dim (:157), which crosses over the
     batch axis when B == 3; the restatement (and the HIP path) always cross over xyz (dim=2)."""
     B, C, _, N_src = src_f.shape
     N_dst = dst_f.shape[-1]
     _dst, _src = dst_f.reshape(B, -1, N_dst), src_f.reshape(B, -1, N_src)
-    _, knn_idx, nn = knn_points(_dst.transpose(2, 1), _src.transpose(2, 1), k, C)
+    _, knn_idx, nn = knn_points(_dst.transpose(2, 1), _src.transpose(2, 1), k, C, idx=idx)
     nn = nn.reshape(B, N_dst, k, C, 3).permute(0, -2, -1, 1, 2)
     dst_pad = dst_f[..., None].expand_as(nn)
     if cross:
@@ -125,9 +129,14 @@ def as_params(w):
 
 
 @torch.no_grad()
-def encoder_forward(w, cfg, x, trace=None):
+def encoder_forward(w, cfg, x, trace=None, graph=None):
     """VecDGCNN_att.forward: vec_dgcnn_atten.py:177-252.  x [B,3,N] -> (center, scale, z_so3, z_inv).
-    If ``trace`` is a dict it receives per-layer fps idx / knn idx / layer inputs / outputs."""
+    If ``trace`` is a dict it receives per-layer fps idx / knn idx / layer inputs / outputs.
+    ``graph`` (tests only): {layer: neighbour lists [B,Nd,K]} to use instead of the k-NN search of that layer.  The deeper layers
+    search in FEATURE space, where two candidates can be equidistant to within fp32 round-off; which of them enters the list then
+    depends on the summation order of the GEMMs that produced the features, on any implementation (the reference's own CPU and CUDA
+    paths differ the same way).  A test that finds such a flip re-runs the restatement on the device's lists and compares the codes
+    at full tolerance, after checking that every flipped pair IS a near-tie."""
     w = as_params(w)
     ns = cfg.get("leak_neg_slope", 0.2)
     L = cfg["num_layers"]
@@ -145,7 +154,7 @@ def encoder_forward(w, cfg, x, trace=None):
             dst_xyz, dst_f = src_xyz, src_f
         if trace is not None:
             trace[f"src_f_{i}"], trace[f"dst_f_in_{i}"] = src_f, dst_f
-        y, knn_idx = get_graph_feature(src_f, dst_f, K, cross=(i == 0))
+        y, knn_idx = get_graph_feature(src_f, dst_f, K, cross=(i == 0), idx=None if graph is None else graph.get(i))
         if trace is not None:
             trace[f"knn_idx_{i}"] = knn_idx
         Wv, Wvd = w[f"V_list.{i}.lin.weight"], w[f"V_list.{i}.act.lin_dir.weight"]

@@ -4,11 +4,13 @@
 //   hipcc --offload-arch=gfx950 -O3 -w -DLS_GEMM_PROF -Iinclude -Ilivingscenes_amd/csrc scripts/ubench/gemm_phases.hip -o scripts/ubench/gemm_phases
 #include "../../livingscenes_amd/csrc/gemm.hip"
 #include <cstdio>
+#include <cstring>
 #include <cstdarg>
 #include <vector>
 namespace ls { void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc(10, stderr); } }
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 262144, N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 768;
+    const int lda = argc > 4 ? atoi(argv[4]) : K;   // 0: every A row is row 0 (an L1/L2-resident A operand: separates the cache path from the rest)
     float *A, *W, *O;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&O, (size_t)M * N * 4);
     std::vector<float> h((size_t)M * K);
@@ -21,7 +23,7 @@ int main(int argc, char** argv) {
         hipMemcpyToSymbol(HIP_SYMBOL(ls::ls_gemm_prof), z, sizeof z);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        ls::gemm_dispatch(A, K, W, K, nullptr, O, N, M, N, K, 0, 0);
+        ls::gemm_dispatch(A, lda, W, K, nullptr, O, N, M, N, K, 0, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpyFromSymbol(z, HIP_SYMBOL(ls::ls_gemm_prof), sizeof z);
