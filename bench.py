@@ -38,7 +38,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32 MFMA peak
-BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (the GEMMs run fp32 products as six bf16 MFMAs: gemm.hip)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (the GEMMs run an fp32 product as three f16 MFMAs -- six bf16 ones under LS_GEMM_MODE=bf16x3: gemm.hip)
 
 
 def layer_plan(cfg, N):
@@ -73,8 +73,12 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     L = pl[min(layer, len(pl) - 1)]
     Ns, Nd, Cin, Co = L["Ns"], L["Nd"], L["Cin"], L["Co"]
     f4 = 4
-    mm_peak, mm_what, mm_mult = (BF16_PEAK_TFLOPS, "bf16 MFMA flops as executed (fp32 products = 6 bf16 MFMAs)", 6.0) if bf16x3 else \
-                                (FP32_PEAK_TFLOPS, "fp32 MFMA flops", 1.0)
+    if not bf16x3:
+        mm_peak, mm_what, mm_mult = FP32_PEAK_TFLOPS, "fp32 MFMA flops", 1.0
+    elif os.environ.get("LS_GEMM_MODE") == "bf16x3":
+        mm_peak, mm_what, mm_mult = BF16_PEAK_TFLOPS, "bf16 MFMA flops as executed (fp32 products = 6 bf16 MFMAs)", 6.0
+    else:
+        mm_peak, mm_what, mm_mult = BF16_PEAK_TFLOPS, "f16 MFMA flops as executed (an fp32 product = 3 f16 MFMAs: two-piece split with a scaled residual)", 3.0
     nc = (10 if L["attn"] else 4) * Co
     pc = (4 if L["attn"] else 2) * Co
     down = Nd != Ns   # neighbour-side columns on the Ns source points, destination-side columns on the Nd selected points
@@ -398,7 +402,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" + (" (GEMM products as three-piece bf16 splits on the bf16 matrix cores, fp32 accumulate: as accurate as an fp32 FMA chain)" if bf16x3 else ""),
+            "dtype": "f32" + ((" (GEMM products as three-piece bf16 splits on the bf16 matrix cores, fp32 accumulate: as accurate as an fp32 FMA chain)"
+                              if os.environ.get("LS_GEMM_MODE") == "bf16x3" else
+                              " (GEMM products as two-piece f16 splits with a scaled residual on the f16 matrix cores, fp32 accumulate: as accurate against fp64 as an fp32 FMA chain)")
+                             if bf16x3 else ""),
             "data": "synthetic (seeded chair-like clouds; deterministic random-init weights of the released architecture)",
             "config": {"workload": f"BASELINE configs[1]+[2]: batch={B} instances x N={N} pts per GPU = {n_obj}-object scene + rescan; "
                                    f"VN-DGCNN encode, {n_obj}x{n_obj} sequential matching, {n_obj} Kabsch poses",
