@@ -98,11 +98,13 @@ int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, un
 
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) -- the VecLinear channel contraction
  * (vec_layers.py:121-136, F.linear at :134) on x-major rows, and the DeepSDF linears
- * (lib_shape_prior/core/lib/implicit_func/deepsdf_decoder.py:98-121).  fp32 in, fp32 out; the products run on the bf16
- * matrix cores as THREE-PIECE splits (a = a1 + a2 + a3 exactly up to 2^-24, six v_mfma_f32_32x32x16_bf16 per 16 k, fp32
- * accumulate): measured against fp64 this is as accurate as -- slightly better than -- an fp32 FMA chain, and exact on
- * integer-valued operands.  LS_GEMM_BF16X3=0 in the environment selects the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact
- * fp32 FMA chains) instead.  A row's result does not depend on the other rows of the call.
+ * (lib_shape_prior/core/lib/implicit_func/deepsdf_decoder.py:98-121).  fp32 in, fp32 out; the products run on the f16
+ * matrix cores as TWO-PIECE splits with a scaled residual (a = h + l/1024, h = f16(a), l = f16((a - h) * 1024): 2^-22 |a|; three
+ * v_mfma_f32_32x32x16_f16 per 16 k, main and cross terms in separate fp32 accumulators): measured against fp64 this is as accurate
+ * as an fp32 FMA chain (the fp32 accumulation error dominates both) and exact on integer-valued operands below 2^22.
+ * PRECONDITION |a|, |w| < 65 504 (f16 range).  LS_GEMM_MODE=bf16x3 in the environment selects three-piece bf16 splits instead
+ * (six v_mfma_f32_32x32x16_bf16 per 16 k, any fp32 range, ~1.5x the time); LS_GEMM_BF16X3=0 the fp32-MFMA kernel
+ * (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains).  A row's result does not depend on the other rows of the call.
  * K % 4 == 0, lda/ldw/ldc % 4 == 0; bias may be NULL; relu in {0,1}.  workspace: ls_gemm_workspace_bytes(M, N, K) bytes
  * (split-K slabs of under-filled long-K problems; 0 -> may be NULL). */
 size_t ls_gemm_workspace_bytes(int M, int N, int K);
