@@ -389,7 +389,8 @@ static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int
                           const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float isd, float* out,
                           hipStream_t st) {
     const int total = B * Nd, ppb = 4 * (64 / LPP);
-    hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn,
+    static const int lds_pad = getenv("LS_EDGE_LDS_PAD") ? atoi(getenv("LS_EDGE_LDS_PAD")) : 0;   // A/B: unused dynamic LDS = fewer workgroups per CU
+    hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), lds_pad, st, T, ldt, Tq, ldq, NQ, qvr, knn,
                        dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total);
     LS_LAUNCH_CHECK();
     return LS_OK;
