@@ -293,8 +293,9 @@ def test_gemm(M, N, K):
     assert torch.equal(ops.gemm(Ai.to(_dev()), Wi.to(_dev())).cpu(), Ai @ Wi.T)
 
 
-def test_gemm_bf16x3_is_as_accurate_as_the_fp32_chain_and_row_invariant():
-    """The default GEMM forms every fp32 product from three bf16 pieces on the bf16 matrix cores.  Componentwise error against
+def test_gemm_split_is_as_accurate_as_the_fp32_chain_and_row_invariant():
+    """The default GEMM forms every fp32 product from two f16 pieces with a scaled residual on the f16 matrix cores (gemm.hip;
+    LS_GEMM_MODE=bf16x3: three bf16 pieces -- test_gemm_mode_switches).  Componentwise error against
     fp64 must stay within the fp32 FMA chain's own bound (in units of 2^-24 sum|a||w|: measured 6-9 vs 11-13 for the chain) on
     badly scaled operands, and the kernel's arithmetic must not depend on M: a row's result is the same whatever other rows the call
     carries (checked here where ls_gemm_f32 does not split K, K < 128; the decoder path, which never splits K, is covered by
@@ -311,6 +312,27 @@ def test_gemm_bf16x3_is_as_accurate_as_the_fp32_chain_and_row_invariant():
         if K < 128:
             part = ops.gemm(A[100:137].contiguous().to(_dev()), W.to(_dev())).cpu()
             assert torch.equal(part.double(), out[100:137]), K
+
+
+def test_gemm_mode_switches():
+    """LS_GEMM_MODE=bf16x3 (six-MFMA split, any fp32 range -- here with operands far outside the f16 range) keeps the tolerance;
+    the pipelined kernel (K >= 128, default) and the two-barrier kernel (LS_GEMM_H2_SIMPLE=1) compute the same products in the same
+    order: bit-identical outputs, also on ragged shapes."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch; from livingscenes_amd import ops; g = torch.Generator().manual_seed(1);"
+            "A = torch.randn(700, 256, generator=g) * 3e6; W = torch.randn(200, 256, generator=g) * 1e-7;"
+            "o = ops.gemm(A.cuda(), W.cuda()).cpu().double(); r = A.double() @ W.double().T;"
+            "assert torch.isfinite(o).all() and ((o - r).abs().max() / r.abs().max()) < 2e-6")
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_GEMM_MODE="bf16x3"), cwd=root)
+    code = ("import hashlib, torch; from livingscenes_amd import ops\n"
+            "for (M, N, K) in ((4099, 500, 136), (20000, 512, 512), (333, 130, 128), (9000, 1024, 256)):\n"
+            "    g = torch.Generator().manual_seed(M + K)\n"
+            "    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.05; b = torch.randn(N, generator=g)\n"
+            "    print(hashlib.sha1(ops.gemm(A.cuda(), W.cuda(), b.cuda(), relu=True).cpu().numpy().tobytes()).hexdigest())\n")
+    outs = [subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root, capture_output=True, text=True).stdout.split()
+            for env in ({}, {"LS_GEMM_H2_SIMPLE": "1"})]
+    assert len(outs[0]) == 4 and outs[0] == outs[1]
 
 
 def test_gemm_fp32_chain_switch():
