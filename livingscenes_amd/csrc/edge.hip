@@ -390,6 +390,7 @@ static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int
                           hipStream_t st) {
     const int total = B * Nd, ppb = 4 * (64 / LPP);
     static const int lds_pad = getenv("LS_EDGE_LDS_PAD") ? atoi(getenv("LS_EDGE_LDS_PAD")) : 0;   // A/B: unused dynamic LDS = fewer workgroups per CU
+    if (lds_pad > 30000) (void)hipFuncSetAttribute((const void*)edge_attn_v4_kernel<LPP, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
     hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), lds_pad, st, T, ldt, Tq, ldq, NQ, qvr, knn,
                        dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total);
     LS_LAUNCH_CHECK();
