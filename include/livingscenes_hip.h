@@ -303,6 +303,18 @@ int ls_se3_transform_f32(const float* g, const float* src, int P, int N, float* 
 int ls_smooth_l1_f32(const float* sdf, int P, int N, int accumulate, float* loss, float* grad_sdf, void* stream);
 int ls_sinkhorn_softmin_batched_f32(const float* x, const float* y, const float* pot_y, float logw, const float* eps, const float* prev,
                                     int average, int P, int N, int M, float* out, float* grad_x, void* stream);
+/* Up to four independent batched softmins in one launch (the four potentials of one symmetric Sinkhorn iteration): the same
+ * arithmetic as ls_sinkhorn_softmin_batched_f32 without the gradient, problem i on x [P,N,3], y [P,M,3], pot_y [P,M] or NULL. */
+typedef struct ls_softmin_problem {
+    const float* x;
+    const float* y;
+    const float* pot_y;
+    const float* prev;
+    float* out;
+    float logw;
+    int N, M;
+} ls_softmin_problem;
+int ls_sinkhorn_softmin_multi_f32(const ls_softmin_problem* problems, int count, const float* eps, int average, int P, void* stream);
 int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float* loss, int P, int N, float lr, float beta1, float beta2,
                          float adam_eps, int step, float stop_angle, float* g, float* m1, float* m2, float* min_loss, float* best_g,
                          const float* init_R, int32_t* active, float* query, void* stream);

@@ -71,6 +71,12 @@ _F = ctypes.c_float
 _SZ = ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/livingscenes_hip.h declares
+class SoftminProblem(ctypes.Structure):
+    """ls_softmin_problem (include/livingscenes_hip.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("pot_y", ctypes.c_void_p), ("prev", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("logw", ctypes.c_float), ("N", ctypes.c_int), ("M", ctypes.c_int)]
+
+
 SIGNATURES = {
     "ls_version": (_I, []),
     "ls_last_error": (ctypes.c_char_p, []),
@@ -95,6 +101,7 @@ SIGNATURES = {
     "ls_se3_transform_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "ls_smooth_l1_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "ls_sinkhorn_softmin_batched_f32": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "ls_sinkhorn_softmin_multi_f32": (_I, [_P, _I, _P, _I, _I, _P]),
     "ls_se3_adam_step_f32": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ls_encoder_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -13,6 +13,7 @@
 // this build's documented definitions -- PARITY UNPINNED for them; the decoder gradients are pinned (sdf.hip).
 // Every reduction runs in a fixed order (no atomics): a pair's trajectory does not depend on which other pairs share the launch.
 #include "ls_common.h"
+#include <algorithm>
 
 namespace ls {
 
@@ -61,67 +62,114 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict_
 //   out[i] = -eps_p log sum_j exp(v_j)          (averaged with prev[i] when `average`: the symmetric Sinkhorn update)
 //   grad[i] = sum_j softmax_j(v) (x_i - y_j)    (optional)
 // eps_p <= 0 marks a pair whose epsilon schedule has ended (shorter schedule than the batch maximum): out = prev, untouched.
-// One wave per FOUR rows of one pair (a y point and its potential are loaded once for four x rows: the kernel is bound by the
+// One wave per RB rows of one pair (a y point and its potential are loaded once for RB x rows: the kernel is bound by the
 // L1 stream of the M y points per row, 16000 launches per 64-pair registration), online (max, sum) per lane and row, combined
 // by wave reductions.
-constexpr int SM_RB = 4;
-template <bool GRAD>   // the gradient accumulators are needed by 2 of the ~40 softmins of a divergence only
-__global__ __launch_bounds__(256) void softmin_batched_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                              const float* __restrict__ pot_y, float logw, const float* __restrict__ eps_p,
-                                                              const float* __restrict__ prev, int average, int N, int M,
-                                                              float* __restrict__ out, float* __restrict__ grad) {
+// Arithmetic per (row, j): three subtractions, |d|^2 (mul + 2 fma), ONE fma that forms the exponent already in base 2
+// (v' = hj' + c |d|^2 with hj' = (logw + pot / eps) log2 e and c = -log2 e / (2 eps) folded per j / per pair), a compare, a subtraction,
+// v_exp_f32, an add: 11 VALU slots + the quarter-rate exponential.  RB rows per wave share the y point and hj' (8 without the
+// gradient accumulators, 4 with them).
+template <bool GRAD, int RB, int CHK = 4>   // the gradient accumulators are needed by 2 of the ~40 softmins of a divergence only
+__device__ __forceinline__ void softmin_rows(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ pot_y, float logw,
+                                             const float* __restrict__ eps_p, const float* __restrict__ prev, int average, int N, int M,
+                                             float* __restrict__ out, float* __restrict__ grad) {
     const int p = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_RB;
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RB;
     if (i0 >= N) return;
     const float eps = eps_p[p];
     if (!(eps > 0.f)) {
-        if (prev && lane < SM_RB && i0 + lane < N) out[(size_t)p * N + i0 + lane] = prev[(size_t)p * N + i0 + lane];
+        if (prev && lane < RB && i0 + lane < N) out[(size_t)p * N + i0 + lane] = prev[(size_t)p * N + i0 + lane];
         return;
     }
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     const float* yp = y + (size_t)p * M * 3;
     const float* hp = pot_y ? pot_y + (size_t)p * M : nullptr;
-    const float inv = 1.0f / eps;
-    float xi[SM_RB], yi[SM_RB], zi[SM_RB], mx[SM_RB], sum[SM_RB], gx[SM_RB], gy[SM_RB], gz[SM_RB];
+    const float inv2 = LOG2E / eps, c2 = -0.5f * inv2, logw2 = logw * LOG2E;
+    float xi[RB], yi[RB], zi[RB], mx[RB], sum[RB], gx[GRAD ? RB : 1], gy[GRAD ? RB : 1], gz[GRAD ? RB : 1];
 #pragma unroll
-    for (int r = 0; r < SM_RB; ++r) {
+    for (int r = 0; r < RB; ++r) {
         const float* xp = x + ((size_t)p * N + min(i0 + r, N - 1)) * 3;   // rows past N: clamped, computed, never stored
         xi[r] = xp[0]; yi[r] = xp[1]; zi[r] = xp[2];
-        mx[r] = -INFINITY; sum[r] = gx[r] = gy[r] = gz[r] = 0.f;
+        mx[r] = -INFINITY; sum[r] = 0.f;
+        if constexpr (GRAD) gx[r] = gy[r] = gz[r] = 0.f;
     }
+    if constexpr (!GRAD) {
+        // chunks of eight y points per lane: the running maximum moves at most once per chunk and row (with a per-element update some
+        // lane of the wave sees a new maximum in nearly every one of the M / 64 iterations, i.e. the rescaling path always runs)
+        constexpr int CH = CHK;
+        for (int j0 = lane; j0 < M; j0 += 64 * CH) {
+            float yx[CH], yy[CH], yz[CH], hj[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = j0 + 64 * u, jc = min(j, M - 1);
+                yx[u] = yp[jc * 3]; yy[u] = yp[jc * 3 + 1]; yz[u] = yp[jc * 3 + 2];
+                hj[u] = j < M ? (hp ? fmaf(hp[jc], inv2, logw2) : logw2) : -INFINITY;   // past M: exponent -inf, contributes exactly 0
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                float v[CH], cm = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float dx = xi[r] - yx[u], dy = yi[r] - yy[u], dz = zi[r] - yz[u];
+                    v[u] = fmaf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), c2, hj[u]);
+                    cm = fmaxf(cm, v[u]);
+                }
+                if (cm > mx[r]) { sum[r] *= __builtin_amdgcn_exp2f(mx[r] - cm); mx[r] = cm; }   // 2^(-inf) = 0 on the first hit
+#pragma unroll
+                for (int u = 0; u < CH; ++u) sum[r] += __builtin_amdgcn_exp2f(v[u] - mx[r]);
+            }
+        }
+    } else
     for (int j = lane; j < M; j += 64) {
         const float yx = yp[j * 3], yy = yp[j * 3 + 1], yz = yp[j * 3 + 2];
-        const float hj = logw + (hp ? hp[j] * inv : 0.f);
+        const float hj = hp ? fmaf(hp[j], inv2, logw2) : logw2;
 #pragma unroll
-        for (int r = 0; r < SM_RB; ++r) {
+        for (int r = 0; r < RB; ++r) {
             const float dx = xi[r] - yx, dy = yi[r] - yy, dz = zi[r] - yz;
-            const float v = hj - 0.5f * (dx * dx + dy * dy + dz * dz) * inv;
+            const float v = fmaf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), c2, hj);
             if (v > mx[r]) {
-                const float sc = __expf(mx[r] - v);   // exp(-inf) = 0 on the first hit
+                const float sc = __builtin_amdgcn_exp2f(mx[r] - v);   // 2^(-inf) = 0 on the first hit
                 sum[r] *= sc;
-                if constexpr (GRAD) { gx[r] *= sc; gy[r] *= sc; gz[r] *= sc; }
+                gx[r] *= sc; gy[r] *= sc; gz[r] *= sc;
                 mx[r] = v;
             }
-            const float e = __expf(v - mx[r]);
+            const float e = __builtin_amdgcn_exp2f(v - mx[r]);
             sum[r] += e;
-            if constexpr (GRAD) { gx[r] += e * dx; gy[r] += e * dy; gz[r] += e * dz; }
+            gx[r] += e * dx; gy[r] += e * dy; gz[r] += e * dz;
         }
     }
 #pragma unroll
-    for (int r = 0; r < SM_RB; ++r) {
+    for (int r = 0; r < RB; ++r) {
         const float wmx = wave_max(mx[r]);
-        const float sc = mx[r] == -INFINITY ? 0.f : __expf(mx[r] - wmx);
+        const float sc = mx[r] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mx[r] - wmx);
         const float s = wave_sum(sum[r] * sc);
         float ax = 0.f, ay = 0.f, az = 0.f;
         if constexpr (GRAD) { ax = wave_sum(gx[r] * sc); ay = wave_sum(gy[r] * sc); az = wave_sum(gz[r] * sc); }
         if (lane == 0 && i0 + r < N) {
             const size_t row = (size_t)p * N + i0 + r;
-            float o = -eps * (wmx + __logf(s));
+            float o = -eps * LN2 * (wmx + __log2f(s));
             if (average) o = 0.5f * (prev[row] + o);
             out[row] = o;
             if constexpr (GRAD) { grad[row * 3] = ax / s; grad[row * 3 + 1] = ay / s; grad[row * 3 + 2] = az / s; }
         }
     }
+}
+
+template <bool GRAD, int RB, int CHK = 4>
+__global__ __launch_bounds__(256) void softmin_batched_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ pot_y, float logw, const float* __restrict__ eps_p,
+                                                              const float* __restrict__ prev, int average, int N, int M,
+                                                              float* __restrict__ out, float* __restrict__ grad) {
+    softmin_rows<GRAD, RB, CHK>(x, y, pot_y, logw, eps_p, prev, average, N, M, out, grad);
+}
+// Up to four INDEPENDENT softmins in one launch (blockIdx.z): the four potentials of one symmetric Sinkhorn iteration
+// (f_ba, g_ab, f_aa, g_bb each read only the previous iteration's potentials).  At P = 64 a single softmin is a 29 us kernel behind
+// ~30 us of Python + ctypes per call: the 400-step registration loop was bound by the host, not by the device.
+struct SoftminSet { ls_softmin_problem q[4]; };
+__global__ __launch_bounds__(256) void softmin_multi_kernel(SoftminSet s, const float* __restrict__ eps_p, int average) {
+    const ls_softmin_problem& q = s.q[blockIdx.z];
+    softmin_rows<false, 8, 4>(q.x, q.y, q.pot_y, q.logw, eps_p, q.prev, average, q.N, q.M, q.out, nullptr);
 }
 
 struct AdamCfg { float lr, b1, b2, eps, bc1, bc2, stop_angle; };   // bc = 1 - beta^(step + 1)
@@ -243,11 +291,29 @@ int ls_sinkhorn_softmin_batched_f32(const float* x, const float* y, const float*
     LS_REQUIRE(!average || prev, "sinkhorn_softmin_batched: average needs prev");
     LS_REQUIRE(prev != out || !prev, "sinkhorn_softmin_batched: out must not alias prev (the symmetric update reads old potentials)");
     if (grad_x)
-        hipLaunchKernelGGL(softmin_batched_kernel<true>, dim3(cdiv(N, 4 * SM_RB), P), dim3(256), 0, (hipStream_t)stream, x, y, pot_y, logw, eps, prev,
+        hipLaunchKernelGGL((softmin_batched_kernel<true, 4>), dim3(cdiv(N, 4 * 4), P), dim3(256), 0, (hipStream_t)stream, x, y, pot_y, logw, eps, prev,
                            average, N, M, out, grad_x);
     else
-        hipLaunchKernelGGL(softmin_batched_kernel<false>, dim3(cdiv(N, 4 * SM_RB), P), dim3(256), 0, (hipStream_t)stream, x, y, pot_y, logw, eps, prev,
+        hipLaunchKernelGGL((softmin_batched_kernel<false, 8>), dim3(cdiv(N, 4 * 8), P), dim3(256), 0, (hipStream_t)stream, x, y, pot_y, logw, eps, prev,
                            average, N, M, out, grad_x);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+int ls_sinkhorn_softmin_multi_f32(const ls_softmin_problem* problems, int count, const float* eps, int average, int P, void* stream) {
+    LS_REQUIRE(problems && eps && count >= 1 && count <= 4 && P > 0 && P <= 65535, "sinkhorn_softmin_multi: bad arguments (count=%d P=%d)", count, P);
+    SoftminSet s;
+    int nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const ls_softmin_problem& q = problems[i];
+        LS_REQUIRE(q.x && q.y && q.out && q.N > 0 && q.M > 0, "sinkhorn_softmin_multi: problem %d: null argument or empty cloud", i);
+        LS_REQUIRE(!average || q.prev, "sinkhorn_softmin_multi: problem %d: average needs prev", i);
+        LS_REQUIRE(q.prev != q.out || !q.prev, "sinkhorn_softmin_multi: problem %d: out must not alias prev", i);
+        s.q[i] = q;
+        nmax = std::max(nmax, q.N);
+    }
+    for (int i = count; i < 4; ++i) s.q[i] = s.q[0];
+    hipLaunchKernelGGL(softmin_multi_kernel, dim3(cdiv(nmax, 4 * 8), P, count), dim3(256), 0, (hipStream_t)stream, s, eps, average);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

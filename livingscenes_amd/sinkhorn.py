@@ -67,6 +67,22 @@ def _softmin_b(x, y, pot_y, logw, eps, prev=None, average=False, need_grad=False
     return (out, grad) if need_grad else out
 
 
+def _softmin_multi(problems, eps, average):
+    """Up to four independent batched softmins in ONE launch: problems = [(x, y, pot_y | None, logw, prev | None), ...] -> [out, ...]."""
+    from ._lib import SoftminProblem
+    import ctypes
+    P = problems[0][0].shape[0]
+    arr = (SoftminProblem * len(problems))()
+    outs = []
+    for i, (x, y, pot, logw, prev) in enumerate(problems):
+        out = torch.empty(P, x.shape[1], dtype=torch.float32, device=x.device)
+        outs.append(out)
+        arr[i] = SoftminProblem(ptr(x), ptr(y), ptr(pot), ptr(prev), ptr(out), float(logw), x.shape[1], y.shape[1])
+    call(problems[0][0].device, "ls_sinkhorn_softmin_multi_f32", ctypes.addressof(arr), len(problems), ptr(eps), int(average), P,
+         stream_ptr(problems[0][0].device))
+    return outs
+
+
 def divergence_batch(x, y, blur=0.05, scaling=0.5, lmax=None, return_need=False):
     """Debiased Sinkhorn divergence of P cloud pairs in lock-step: x [P,N,3] (moving), y [P,M,3] -> (loss [P], d loss / d x [P,N,3]).
     Same definition as _divergence pair by pair: every pair follows ITS OWN epsilon schedule (it depends on the pair's bounding-box
@@ -91,15 +107,12 @@ def divergence_batch(x, y, blur=0.05, scaling=0.5, lmax=None, return_need=False)
     eps_tab = torch.where(k > (nj + 1)[:, None], torch.zeros_like(eps_tab), eps_tab).float().t().contiguous()   # [L,P]; 0 = schedule ended
     a_log, b_log = -math.log(N), -math.log(M)
     e0 = eps_tab[0]
-    g_ab, f_ba = _softmin_b(y, x, None, a_log, e0), _softmin_b(x, y, None, b_log, e0)
-    f_aa, g_bb = _softmin_b(x, x, None, a_log, e0), _softmin_b(y, y, None, b_log, e0)
+    # the four potentials of an iteration read only the previous iteration's: one launch for the four (csrc/optim.hip)
+    g_ab, f_ba, f_aa, g_bb = _softmin_multi([(y, x, None, a_log, None), (x, y, None, b_log, None), (x, x, None, a_log, None), (y, y, None, b_log, None)],
+                                            e0, False)
     for i in range(lmax):
-        e = eps_tab[i]
-        f_ba_n = _softmin_b(x, y, g_ab, b_log, e, prev=f_ba, average=True)
-        g_ab_n = _softmin_b(y, x, f_ba, a_log, e, prev=g_ab, average=True)
-        f_aa_n = _softmin_b(x, x, f_aa, a_log, e, prev=f_aa, average=True)
-        g_bb_n = _softmin_b(y, y, g_bb, b_log, e, prev=g_bb, average=True)
-        f_ba, g_ab, f_aa, g_bb = f_ba_n, g_ab_n, f_aa_n, g_bb_n
+        f_ba, g_ab, f_aa, g_bb = _softmin_multi([(x, y, g_ab, b_log, f_ba), (y, x, f_ba, a_log, g_ab), (x, x, f_aa, a_log, f_aa), (y, y, g_bb, b_log, g_bb)],
+                                                eps_tab[i], True)
     last = torch.full((P,), blur ** 2, dtype=torch.float32, device=x.device)    # every schedule ends at blur^2
     f_ba_l, d_ba = _softmin_b(x, y, g_ab, b_log, last, need_grad=True)
     g_ab_l = _softmin_b(y, x, f_ba, a_log, last)

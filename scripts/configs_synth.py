@@ -20,7 +20,7 @@ ap.add_argument("--scenes", type=int, default=16)
 ap.add_argument("--dense-instances", type=int, default=256)
 ap.add_argument("--skip-dense", action="store_true")
 ap.add_argument("--optim-pairs", type=int, default=-1, help="matched pairs put through the optim=True refinement (-1 = all, 0 = skip)")
-ap.add_argument("--optim-chunk", type=int, default=64, help="pairs advanced in lock-step per call")
+ap.add_argument("--optim-chunk", type=int, default=128, help="pairs advanced in lock-step per call")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
