@@ -272,7 +272,8 @@ int ls_sdf_decode_rows(ls_model_t* m, const float* query, const int32_t* row_ins
  * (lib_more/more_solver.py:191-228) through FieldWrapper.forward (model_utils.py:230-263) and DeepSDF_Decoder.forward
  * (deepsdf_decoder.py:78-123).  ls_sdf_decode_train = ls_sdf_decode keeping every layer's activations in `workspace`
  * (ls_sdf_train_workspace_bytes); ls_sdf_backward, called with the SAME arguments and workspace, returns the gradients of
- * sum(grad_sdf * sdf):  grad_query [B,M,3] (nullable), grad_z_so3 [B,c,3], grad_z_inv [B,c], grad_s [B], grad_t [B,3]. */
+ * sum(grad_sdf * sdf):  grad_query [B,M,3] (nullable), grad_z_so3 [B,c,3], grad_z_inv [B,c] (nullable TOGETHER: a pose refinement
+ * with a fixed code -- more_solver.py:137-173 -- skips the code-gradient reductions), grad_s [B], grad_t [B,3]. */
 size_t ls_sdf_train_workspace_bytes(const ls_model_t* m, int B, int M);
 int ls_sdf_decode_train(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s,
                         const float* t, int B, int M, float* sdf, void* workspace, size_t workspace_bytes, void* stream);

@@ -53,7 +53,7 @@ int sdf_affine_rows_launch(const float*, const int32_t*, const float*, const flo
 int sdf_out_bwd_launch(const float*, const float*, const float*, const float*, int, int, long long, float*, hipStream_t);
 int relu_mask_launch(float*, const float*, long long, int, int, hipStream_t);
 int sdf_affine_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*, float*,
-                          float*, hipStream_t);
+                          float*, bool, hipStream_t);
 int sdf_code_grad_launch(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                          int, int, int, float*, float*, hipStream_t);
 int sdf_query_grad_launch(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
@@ -946,12 +946,13 @@ static int build_dec_wt(ls_model_t* m, hipStream_t st) {   // transposed main we
 }
 
 // Gradients of sum(grad_sdf * sdf) w.r.t. the code and the query points, after ls_sdf_decode_train on the SAME arguments and
-// workspace.  grad_query is optional; the others are required.
+// workspace.  grad_query is optional; grad_z_so3 / grad_z_inv may be omitted TOGETHER (pose refinement with a fixed code).
 int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const float* z_inv, const float* s, const float* t, int B,
                     int M, const float* sdf, const float* grad_sdf, void* workspace, size_t workspace_bytes, float* grad_query,
                     float* grad_z_so3, float* grad_z_inv, float* grad_s, float* grad_t, void* stream) {
-    LS_REQUIRE(m && query && z_so3 && z_inv && s && t && sdf && grad_sdf && workspace && grad_z_so3 && grad_z_inv && grad_s && grad_t,
-               "sdf_backward: null argument");
+    LS_REQUIRE(m && query && z_so3 && z_inv && s && t && sdf && grad_sdf && workspace && grad_s && grad_t, "sdf_backward: null argument");
+    LS_REQUIRE((grad_z_so3 != nullptr) == (grad_z_inv != nullptr), "sdf_backward: grad_z_so3 and grad_z_inv are given or omitted together");
+    const bool need_code = grad_z_so3 != nullptr;   // a pose refinement with a fixed code skips the code-gradient reductions
     const ls_model_desc& d = m->d;
     LS_REQUIRE(d.dec_num_linear >= 3, "sdf_backward: model has no decoder packed");
     LS_REQUIRE(B > 0 && M > 0, "sdf_backward: empty problem");
@@ -976,7 +977,7 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
     for (int l = nl - 2; l >= 1; --l) {
         const int kin = outw[l - 1];          // input width of layer l (= padded output width of layer l-1)
         if (l == li) {
-            rc = sdf_affine_bwd_launch(query, s, t, dz, sb.A4, B, M, w, w, dq_started ? 1 : 0, sb.dA4, sb.db4, sb.dQ, st);
+            rc = sdf_affine_bwd_launch(query, s, t, dz, sb.A4, B, M, w, w, dq_started ? 1 : 0, sb.dA4, sb.db4, sb.dQ, need_code, st);
             if (rc != LS_OK) return rc;
             dq_started = true;
         }
@@ -993,9 +994,9 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
         if (rc != LS_OK) return rc;
         std::swap(dz, other);
     }
-    rc = sdf_affine_bwd_launch(query, s, t, dz, sb.A0, B, M, w, w, dq_started ? 1 : 0, sb.dA0, sb.db0, sb.dQ, st);
+    rc = sdf_affine_bwd_launch(query, s, t, dz, sb.A0, B, M, w, w, dq_started ? 1 : 0, sb.dA0, sb.db0, sb.dQ, need_code, st);
     if (rc != LS_OK) return rc;
-    rc = sdf_code_grad_launch(W + d.off_dec_so3_t[0], W + d.off_dec_inv_t[0], sb.dA0, sb.db0, li >= 0 ? W + d.off_dec_so3_t[li] : nullptr,
+    if (need_code) rc = sdf_code_grad_launch(W + d.off_dec_so3_t[0], W + d.off_dec_inv_t[0], sb.dA0, sb.db0, li >= 0 ? W + d.off_dec_so3_t[li] : nullptr,
                               li >= 0 ? W + d.off_dec_inv_t[li] : nullptr, sb.dA4, sb.db4, B, L, w, grad_z_so3, grad_z_inv, st);
     if (rc != LS_OK) return rc;
     return sdf_query_grad_launch(query, s, t, sb.dQ, B, M, grad_query, grad_t, grad_s, st);

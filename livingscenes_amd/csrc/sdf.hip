@@ -289,8 +289,10 @@ int relu_mask_launch(float* dh, const float* h, long long rows, int cols, int ld
     return LS_OK;
 }
 int sdf_affine_bwd_launch(const float* query, const float* s, const float* t, const float* dz, const float* A, int B, int M, int out_dim,
-                          int ldh, int accumulate, float* dA, float* dbeff, float* dQ, hipStream_t st) {
-    hipLaunchKernelGGL(sdf_affine_bwd_cols_kernel, dim3(cdiv(out_dim, 64), B), dim3(256), 0, st, query, s, t, dz, M, out_dim, ldh, dA, dbeff);
+                          int ldh, int accumulate, float* dA, float* dbeff, float* dQ, bool need_code, hipStream_t st) {
+    // the reductions over the queries feed only the CODE gradient (a pose refinement with a fixed code does not need them)
+    if (need_code)
+        hipLaunchKernelGGL(sdf_affine_bwd_cols_kernel, dim3(cdiv(out_dim, 64), B), dim3(256), 0, st, query, s, t, dz, M, out_dim, ldh, dA, dbeff);
     hipLaunchKernelGGL(sdf_affine_bwd_rows_kernel, dim3(cdiv((long long)B * M, 4)), dim3(256), 0, st, dz, A, M, out_dim, ldh, accumulate,
                        (long long)B * M, dQ);
     LS_LAUNCH_CHECK();

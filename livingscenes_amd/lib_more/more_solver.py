@@ -120,7 +120,7 @@ class More_Solver:
                     lr = lr0 * (0.1 ** sum(i >= ms for ms in (300, 340, 380)))          # MultiStepLR([300, 340, 380], 0.1), :143
                     sdf, saved = hip.sdf_decode_train(opt.query, shared["z_so3"], shared["z_inv"], shared["s"], shared["t"])
                     loss, gsdf = ops.smooth_l1(sdf)
-                    gq = hip.sdf_backward(saved, gsdf)[0]
+                    gq = hip.sdf_backward(saved, gsdf, need_code_grad=False)[0]              # the code is fixed here (:137-141)
                     sl, sg, need = divergence_batch(opt.query, tgt, lmax=sched_len, return_need=True)
                     if sched_len is None:
                         sched_len = int(need) + 1

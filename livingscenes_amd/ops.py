@@ -368,14 +368,14 @@ class HipModel:
                                          ws.numel(), stream_ptr(query.device))
         return sdf, (query, z_so3, z_inv, s, t, sdf, ws)
 
-    def sdf_backward(self, saved, grad_sdf, need_query_grad=True):
-        """-> (grad_query [B,M,3] or None, grad_z_so3 [B,c,3], grad_z_inv [B,c], grad_s [B], grad_t [B,3])."""
+    def sdf_backward(self, saved, grad_sdf, need_query_grad=True, need_code_grad=True):
+        """-> (grad_query [B,M,3] or None, grad_z_so3 [B,c,3] or None, grad_z_inv [B,c] or None, grad_s [B], grad_t [B,3])."""
         query, z_so3, z_inv, s, t, sdf, ws = saved
         B, M, _ = query.shape
         dev = query.device
         g = _f32(grad_sdf).reshape(B, M)
         gq = torch.empty(B, M, 3, dtype=torch.float32, device=dev) if need_query_grad else None
-        gso3, ginv = torch.empty_like(z_so3), torch.empty_like(z_inv)
+        gso3, ginv = (torch.empty_like(z_so3), torch.empty_like(z_inv)) if need_code_grad else (None, None)
         gs, gt = torch.empty_like(s), torch.empty_like(t)
         call(dev, "ls_sdf_backward", self._h, ptr(query), ptr(z_so3), ptr(z_inv), ptr(s), ptr(t), B, M, ptr(sdf), ptr(g), ptr(ws),
                                      ws.numel(), ptr(gq), ptr(gso3), ptr(ginv), ptr(gs), ptr(gt), stream_ptr(dev))
