@@ -568,6 +568,25 @@ def test_optim_registration_batch_equals_per_pair(small_prior):
 
 
 @pytest.mark.gpu
+def test_softmin_multi_equals_single_launches():
+    """ls_sinkhorn_softmin_multi_f32 (four independent softmins behind one launch) == four ls_sinkhorn_softmin_batched_f32 calls, bit
+    for bit, with ragged sizes, a finished pair (eps <= 0 -> prev) and without potentials / prev."""
+    from livingscenes_amd.sinkhorn import _softmin_b, _softmin_multi
+    g = torch.Generator().manual_seed(3)
+    P = 5
+    x, y = (torch.randn(P, 300, 3, generator=g) * 0.4).to(_dev()), (torch.randn(P, 173, 3, generator=g) * 0.4).to(_dev())
+    f, h = (torch.randn(P, 300, generator=g) * 0.1).to(_dev()), (torch.randn(P, 173, generator=g) * 0.1).to(_dev())
+    eps = torch.tensor([0.5, 0.01, 0.0, 0.0025, 2.0]).to(_dev())
+    probs = [(x, y, h, -5.1, f), (y, x, f, -5.7, h), (x, x, f, -5.7, f), (y, y, h, -5.1, h)]
+    multi = _softmin_multi(probs, eps, True)
+    for (a, b, pot, lw, prev), out in zip(probs, multi):
+        assert torch.equal(out, _softmin_b(a, b, pot, lw, eps, prev=prev, average=True))
+    e1 = torch.full((P,), 0.3).to(_dev())
+    multi = _softmin_multi([(x, y, None, -5.1, None), (y, x, None, -5.7, None)], e1, False)
+    assert torch.equal(multi[0], _softmin_b(x, y, None, -5.1, e1)) and torch.equal(multi[1], _softmin_b(y, x, None, -5.7, e1))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("P,N,M", [(3, 256, 300), (2, 1024, 1024)])
 def test_sinkhorn_divergence_batch_vs_oracle(P, N, M):
     """sinkhorn.divergence_batch (per-pair epsilon schedules inside one launch sequence) against the torch-CPU restatement pair by
