@@ -384,6 +384,215 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------- attention layers, destination side fused
+// edge_attn_v4_kernel with the SIX destination-side column groups (v_lin, v_dir, k_lin, k_dir of the destination point and q_lin,
+// q_dir: 60 % of an attention layer's table) computed IN the kernel instead of being written by the table GEMM and read back once:
+// -151 MB of writes and -151 MB of reads per pass at layers 2 and 3 (B = 64), -75 + 75 MB at layer 4.  A workgroup owns PW = 16 (Co = 64)
+// or 8 (Co = 128) destination points = 48 / 24 feature rows [x, Cin]; before each of the three phases (q | k | v) it multiplies them
+// by the 2 Co weight rows that phase needs -- a [64 | 32] x Cin x [128 | 256] product on the f16 matrix cores with the same two-piece
+// split as gemm.hip (a = h + l / 1024, three MFMAs per product, main and cross terms in separate accumulators), 8 output tiles of
+// 32 x 32, two per wave -- into an LDS slab the phase then reads where the v4 kernel read Tq.  Cost: 144 - 288 MFMAs per workgroup
+// (4 - 8 us per launch chip-wide) and 33 KB of LDS (two workgroups per CU instead of five; measured neutral for the gather itself,
+// DESIGN.md 9).  The neighbour-side tables (P) are unchanged.
+typedef _Float16 eh8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 eh2_t __attribute__((ext_vector_type(2)));
+typedef float ef2_t __attribute__((ext_vector_type(2)));
+typedef float ef16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void esplit_pair(ef2_t v, unsigned& h, unsigned& l) {
+    const eh2_t hv = __builtin_convertvector(v, eh2_t);
+    const eh2_t lv = __builtin_convertvector((v - __builtin_convertvector(hv, ef2_t)) * 1024.f, eh2_t);
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, lv);
+}
+// eight consecutive-k fp32 values -> the (hi, lo) MFMA operand fragments of this lane
+__device__ __forceinline__ void esplit8(const float* p, eh8_t& h, eh8_t& l) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    uint4 hh, ll;
+    esplit_pair(ef2_t{a.x, a.y}, hh.x, ll.x); esplit_pair(ef2_t{a.z, a.w}, hh.y, ll.y);
+    esplit_pair(ef2_t{b.x, b.y}, hh.z, ll.z); esplit_pair(ef2_t{b.z, b.w}, hh.w, ll.w);
+    h = __builtin_bit_cast(eh8_t, hh);
+    l = __builtin_bit_cast(eh8_t, ll);
+}
+
+// Wq [rows = 6 Co][Cin] fp32 -> (hi, lo) f16 pieces in MFMA-fragment-major order: [rows / 32 tiles][Cin / 16 steps][hi, lo][64 lanes] x 16 B,
+// lane = (row & 31) + 32 (k / 8 & 1), eight consecutive k: a wave fetches an operand fragment with ONE contiguous 1 KB load.  (Fetching
+// the fragments straight from the row-major fp32 weights -- 32 rows x 32 bytes per load instruction -- made the fused kernel 2x
+// slower than the un-fused one: every load instruction touched 32 cache lines.)  Built once per model (ls_model_create).
+__global__ __launch_bounds__(64) void edge_presplit_wq_kernel(const float* __restrict__ W, int rows, int Cin, int KS, uint4* __restrict__ planes) {
+    const int tile = blockIdx.x / KS, ks = blockIdx.x % KS, lane = threadIdx.x;
+    const int n = tile * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5);
+    eh8_t h, l;
+    esplit8(W + (size_t)min(n, rows - 1) * Cin + k, h, l);
+    planes[((size_t)blockIdx.x * 2) * 64 + lane] = __builtin_bit_cast(uint4, h);
+    planes[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, l);
+}
+size_t edge_wq_planes_bytes(int Co, int Cin) { return (size_t)(6 * Co / 32) * (Cin / 16) * 2 * 64 * sizeof(uint4); }
+int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipStream_t st) {
+    hipLaunchKernelGGL(edge_presplit_wq_kernel, dim3((6 * Co / 32) * (Cin / 16)), dim3(64), 0, st, Wq, 6 * Co, Cin, Cin / 16, (uint4*)planes);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+template <int LPP, int CIN>
+__global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
+                                                           const uint4* __restrict__ Wp, const int32_t* __restrict__ knn,
+                                                           const int32_t* __restrict__ dst_rows, int Nd, int Ns, float oms, float inv_sqrt_dk,
+                                                           float* __restrict__ out, int total) {
+    constexpr int PPW = 64 / LPP, PW = 4 * PPW, ROWS = 3 * PW, MT = (ROWS + 31) / 32, Co = LPP * 4, SC = 2 * Co, NT = SC / 32, SLD = SC + 4,
+                  KS = CIN / 16, ASTR = CIN * 2 + 16;   // A plane row stride in bytes (+16: conflict-free 16-byte fragment reads)
+    static_assert(MT * NT == 8, "two output tiles per wave");
+    __shared__ float l_score[EK][256];
+    __shared__ __attribute__((aligned(16))) float slab[ROWS * SLD];
+    __shared__ __attribute__((aligned(16))) char a_pl[2][MT * 32 * ASTR];   // the workgroup's feature rows as (hi, lo) f16 planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / LPP, ll = lane % LPP;
+    const int pid0 = xcd_remap(blockIdx.x, gridDim.x) * PW;
+    const int pwl = wave * PPW + sub;              // this lane's point inside the workgroup
+    int pid = pid0 + pwl;
+    const bool live = pid < total;
+    if (!live) pid = total - 1;
+    const int b = pid / Nd;
+    const float* Tb = T + (size_t)b * Ns * 3 * ldt;
+    const int32_t* ki = knn + (size_t)pid * EK;
+    const int c4 = ll * 4;
+
+    // ---- stage the destination points' feature rows (coalesced: a row is CIN * 4 contiguous bytes), split once for the three products
+    for (int c = tid; c < MT * 32 * (CIN / 4); c += 256) {
+        const int r = c / (CIN / 4), kq = c - r * (CIN / 4);
+        uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+        if (r < ROWS) {
+            const int pw = r / 3, x = r - 3 * pw;
+            const int pa = min(pid0 + pw, total - 1), ba = pa / Nd;
+            const int sp = dst_rows ? dst_rows[pa] : pa - ba * Nd;
+            const float4 v = *reinterpret_cast<const float4*>(cur + (((size_t)ba * Ns + sp) * 3 + x) * CIN + kq * 4);
+            esplit_pair(ef2_t{v.x, v.y}, h.x, l.x);
+            esplit_pair(ef2_t{v.z, v.w}, h.y, l.y);
+        }
+        *reinterpret_cast<uint2*>(&a_pl[0][r * ASTR + kq * 8]) = h;
+        *reinterpret_cast<uint2*>(&a_pl[1][r * ASTR + kq * 8]) = l;
+    }
+    __syncthreads();
+
+    // ---- destination-side product for one phase: slab[row][0 .. 2 Co) = x_rows . Wq[cb .. cb + 2 Co)^T
+    auto qgemm = [&](int cb) {
+        const uint4* wt = Wp + (size_t)(cb / 32) * KS * 128 + lane;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int mt = MT == 2 ? u : 0, nt = MT == 2 ? wave : wave + 4 * u;
+            const int aoff = (32 * mt + (lane & 31)) * ASTR + (lane >> 5) * 16;
+            ef16_t acc, acx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const eh8_t ah = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(&a_pl[0][aoff + ks * 32]));
+                const eh8_t al = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(&a_pl[1][aoff + ks * 32]));
+                const eh8_t bh = __builtin_bit_cast(eh8_t, wt[((size_t)(nt * KS + ks) * 2) * 64]);
+                const eh8_t bl = __builtin_bit_cast(eh8_t, wt[((size_t)(nt * KS + ks) * 2 + 1) * 64]);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acx, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acx, 0, 0, 0);
+            }
+            // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); rows past the workgroup's points: dropped
+            const int row0 = 32 * mt + 4 * (lane >> 5);
+            float* sp = slab + row0 * SLD + 32 * nt + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (row0 + dr < ROWS) sp[dr * SLD] = fmaf(acx[r], 0.0009765625f, acc[r]);
+            }
+        }
+    };
+    const float* srow = slab + 3 * pwl * SLD + c4;   // this lane's destination-side values: rows x, y, z of its point, its four channels
+    auto lds43 = [&](int col) {
+        F43 r;
+        r.x = *reinterpret_cast<const float4*>(srow + col);
+        r.y = *reinterpret_cast<const float4*>(srow + SLD + col);
+        r.z = *reinterpret_cast<const float4*>(srow + 2 * SLD + col);
+        return r;
+    };
+
+    // ---- A: q = cevn(VecLNA_Q(dst_f[n]))
+    qgemm(4 * Co);
+    __syncthreads();
+    F43 qf = lds43(0);
+    {
+        const F43 kd = lds43(Co);
+        act43(qf, kd, oms);
+    }
+    const float inv_q = 1.0f / fmaxf(sqrtf(group_sum<LPP>(dot43(qf, qf))), 1e-12f);
+    __syncthreads();   // every wave has its q: the slab may be overwritten
+
+    // ---- B: K branch -> per-head scores for the 16 neighbours, normalised by the Frobenius norm of k
+    qgemm(2 * Co);
+    __syncthreads();
+    {
+        const F43 ql = lds43(0), qd = lds43(Co);
+#pragma unroll 2
+        for (int k = 0; k < EK; ++k) {
+            const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
+            F43 y = add43(ld43(Tr + 2 * Co + c4, ldt), ql);
+            const F43 kd = add43(ld43(Tr + 3 * Co + c4, ldt), qd);
+            act43(y, kd, oms);
+            const float invk = 1.0f / fmaxf(sqrtf(group_sum<LPP>(dot43(y, y))), 1e-12f);
+            l_score[k][tid] = quad_sum(dot43(y, qf)) * inv_q * invk * inv_sqrt_dk;
+        }
+    }
+    __syncthreads();   // done with the k slab
+    qgemm(0);
+    float mx = -INFINITY, sum = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < EK; ++k) mx = fmaxf(mx, l_score[k][tid]);
+#pragma unroll 4
+    for (int k = 0; k < EK; ++k) {  // soft-max numerators (the 1/sum is applied to the weighted sum below)
+        const float ex = expf(l_score[k][tid] - mx);
+        l_score[k][tid] = ex;
+        sum += ex;
+    }
+    __syncthreads();
+
+    // ---- C: V branch, weighted sum
+    {
+        const F43 ql = lds43(0), qd = lds43(Co);
+        F43 acc;
+        acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+        for (int k = 0; k < EK; ++k) {
+            const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
+            F43 y = add43(ld43(Tr + c4, ldt), ql);
+            const F43 kd = add43(ld43(Tr + Co + c4, ldt), qd);
+            act43(y, kd, oms);
+            const float w = l_score[k][tid];
+            acc.x.x += w * y.x.x; acc.x.y += w * y.x.y; acc.x.z += w * y.x.z; acc.x.w += w * y.x.w;
+            acc.y.x += w * y.y.x; acc.y.y += w * y.y.y; acc.y.z += w * y.y.z; acc.y.w += w * y.y.w;
+            acc.z.x += w * y.z.x; acc.z.y += w * y.z.y; acc.z.z += w * y.z.z; acc.z.w += w * y.z.w;
+        }
+        if (live) {
+            const float inv = 1.0f / sum;
+            float* op = out + (size_t)pid * 3 * Co + c4;
+            *reinterpret_cast<float4*>(op) = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
+            *reinterpret_cast<float4*>(op + Co) = make_float4(acc.y.x * inv, acc.y.y * inv, acc.y.z * inv, acc.y.w * inv);
+            *reinterpret_cast<float4*>(op + 2 * Co) = make_float4(acc.z.x * inv, acc.z.y * inv, acc.z.z * inv, acc.z.w * inv);
+        }
+    }
+}
+
+// can this layer shape take the fused kernel?
+bool edge_attn_fq_supported(int Co, int Cin) { return (Co == 64 && (Cin == 32 || Cin == 64)) || (Co == 128 && Cin == 64); }
+int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, const void* wq_planes, const int32_t* knn, const int32_t* dst_rows, int B,
+                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st) {
+    LS_REQUIRE(head_c == 16 && edge_attn_fq_supported(Co, Cin) && ldt % 4 == 0 && wq_planes, "edge_attn_fq: unsupported shape (Co=%d Cin=%d ldt=%d)", Co, Cin, ldt);
+    const float isd = 1.0f / sqrtf(3.0f * head_c), oms = 1.0f - neg_slope;
+    const int total = B * Nd;
+#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total)
+    if (Co == 64 && Cin == 32) LS_FQ(16, 32);
+    else if (Co == 64) LS_FQ(16, 64);
+    else LS_FQ(32, 64);
+#undef LS_FQ
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
 template <int LPP, int NCH>
 static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
                           const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float isd, float* out,

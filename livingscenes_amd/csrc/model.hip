@@ -30,6 +30,10 @@ int gemm_dispatch(const float*, int, const float*, int, const float*, float*, in
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
 int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
 int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
+bool edge_attn_fq_supported(int Co, int Cin);
+int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
+size_t edge_wq_planes_bytes(int Co, int Cin);
+int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipStream_t st);
 int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t);
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
@@ -74,6 +78,7 @@ struct ProfRec { int kind, layer; hipEvent_t a, b; };
 struct ls_model {
     ls_model_desc d;
     float* blob = nullptr;
+    void* wq_planes[LS_MAX_LAYERS] = {};   // attention layers 2 - 4: destination-side weights as f16 MFMA fragments (edge.hip, edge_attn_fq_kernel)
     float* dec_wt = nullptr;            // transposed decoder weights [kin_l][out_l], built by the first backward call
     size_t dec_wt_off[12] = {};
     hipStream_t side = nullptr;    // FPS chain
@@ -231,27 +236,37 @@ static size_t edge_table_floats(const ls_model_desc& d, int i, int B, int Ns, in
     const int nc = layer_ncols(d, i), pc = layer_pcols(d, i);
     return rows ? (size_t)B * 3 * ((size_t)Ns * pc + (size_t)Nd * (nc - pc)) : (size_t)B * Ns * 3 * nc;
 }
-struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; };
+struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; const float* cur = nullptr; const void* Wq = nullptr; int Cin = 0; };   // cur != null: destination side fused into the edge kernel
 
+// where the table(s) of layer i live in T and how the edge kernel reads them (no launch)
+static bool edge_fused(const ls_model* m, int i) {
+    static const bool fuse_q = !(getenv("LS_EDGE_FUSE_Q") && atoi(getenv("LS_EDGE_FUSE_Q")) == 0);   // A/B: destination side as table columns
+    return fuse_q && m->wq_planes[i];
+}
+static EdgeTables edge_tables_layout(const ls_model* m, int i, const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, float* T) {
+    const ls_model_desc& d = m->d;
+    const int Cin = layer_cin(d, i), nc = layer_ncols(d, i), pc = layer_pcols(d, i);
+    if (edge_fused(m, i)) return EdgeTables{nullptr, pc, 0, 0, 0, cur, m->wq_planes[i], Cin};
+    if (dst_rows) return EdgeTables{T + (size_t)B * Ns * 3 * pc, pc, nc - pc, Nd, 0};
+    return EdgeTables{T + pc, nc, nc, Ns, 1};
+}
 // the folded VN-Linear contraction of layer i >= 1 (edge.hip header): cur [B,Ns,3,Cin] -> table(s) in T
 static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, float* T, hipStream_t gs,
                        EdgeTables& et) {
     const ls_model_desc& d = m->d;
     const int Cin = layer_cin(d, i), nc = layer_ncols(d, i), pc = layer_pcols(d, i), qc = nc - pc;
     const float* W = m->blob + d.off_edge[i];
-    int rc;
+    et = edge_tables_layout(m, i, cur, dst_rows, B, Ns, Nd, T);
     PROF(LS_K_GEMM_EDGE, i, gs);
+    // attention layers 2 - 4 (fused): only the neighbour-side table; the destination side is computed inside the edge kernel (edge.hip)
+    if (et.cur) return gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
     if (dst_rows) {
         // down-sampled layer: P table on all source points, Q table only on the FPS-selected destination points
-        float* Tq_w = T + (size_t)B * Ns * 3 * pc;
-        rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
-        if (rc == LS_OK) rc = gemm_dispatch_gather(cur, Cin, W + (size_t)pc * Cin, Cin, nullptr, Tq_w, qc, B * Nd * 3, qc, Cin, 0, dst_rows, Nd, Ns, gs);
-        et = EdgeTables{Tq_w, pc, qc, Nd, 0};
-    } else {
-        rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, gs);
-        et = EdgeTables{T + pc, nc, nc, Ns, 1};
+        int rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
+        if (rc == LS_OK) rc = gemm_dispatch_gather(cur, Cin, W + (size_t)pc * Cin, Cin, nullptr, const_cast<float*>(et.Tq), qc, B * Nd * 3, qc, Cin, 0, dst_rows, Nd, Ns, gs);
+        return rc;
     }
-    return rc;
+    return gemm_dispatch(cur, Cin, W, Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, gs);
 }
 // gather + VN activation + mean-pool | attention of layer i >= 1 over the tables
 static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, const int32_t* knn, const int32_t* dst_rows, int B, int Nd,
@@ -260,6 +275,7 @@ static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, 
     const int Co = d.feat_dim[i];
     if (i >= d.atten_start_layer) {
         PROF(LS_K_EDGE_ATTN, i, st);
+        if (et.cur) return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st);
         return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st);
     }
     PROF(LS_K_EDGE_POOL, i, st);
@@ -414,6 +430,14 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
+    for (int i = desc->atten_start_layer; i < desc->num_layers && i >= 1; ++i) {
+        const int Co = desc->feat_dim[i], Cin = layer_cin(*desc, i);
+        if (desc->atten_head_c != 16 || !edge_attn_fq_supported(Co, Cin)) continue;
+        e = hipMalloc(&m->wq_planes[i], edge_wq_planes_bytes(Co, Cin));
+        if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
+        const int rc = edge_presplit_wq_launch(m->blob + desc->off_edge[i] + (size_t)layer_pcols(*desc, i) * Cin, Co, Cin, m->wq_planes[i], nullptr);
+        if (rc != LS_OK || hipDeviceSynchronize() != hipSuccess) { ls_model_destroy(m); return LS_ERR_HIP; }
+    }
     *out = m;
     return LS_OK;
 }
@@ -422,6 +446,8 @@ void ls_model_destroy(ls_model_t* m) {
     if (!m) return;
     if (m->blob) (void)hipFree(m->blob);
     if (m->dec_wt) (void)hipFree(m->dec_wt);
+    for (int i = 0; i < LS_MAX_LAYERS; ++i)
+        if (m->wq_planes[i]) (void)hipFree(m->wq_planes[i]);
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->side2) (void)hipStreamDestroy(m->side2);
     for (int i = 0; i < LS_MAX_LAYERS; ++i) {
@@ -672,9 +698,7 @@ static int edgeconv_export(ls_model_t* m, int layer, const float* src_f, const i
     int rc = LS_OK;
     const char* dbg = getenv("LS_DEBUG_EDGE");   // race hunting: "notab" = tables already in the workspace, "tabonly" = stop after them
     if (dbg && !strcmp(dbg, "notab")) {
-        const int nc = layer_ncols(m->d, layer), pc = layer_pcols(m->d, layer);
-        float* T = (float*)workspace;
-        et = dst_rows ? EdgeTables{T + (size_t)B * Ns * 3 * pc, pc, nc - pc, Nd, 0} : EdgeTables{T + pc, nc, nc, Ns, 1};
+        et = edge_tables_layout(m, layer, src_f, dst_rows, B, Ns, Nd, (float*)workspace);
     } else {
         rc = edge_tables(m, layer, src_f, dst_rows, B, Ns, Nd, (float*)workspace, st, et);
     }

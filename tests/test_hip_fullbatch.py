@@ -112,3 +112,31 @@ def test_encode_graph_replay_is_bit_identical():
                     for k in ("z_so3", "z_inv", "s", "t"):
                         assert torch.equal(got[k], want[k]), (rep, k)
         sp.hip_model().set_option(_lib.OPT_ENCODE_GRAPH, 0)
+
+
+def test_fused_destination_side_equals_table_path_bit_for_bit():
+    """Attention layers 2 - 4 compute the destination-side column groups inside the edge kernel (edge_attn_fq_kernel: f16-split MFMA
+    product per workgroup) instead of reading them from the table the GEMM wrote (LS_EDGE_FUSE_Q=0).  Same products, same
+    accumulation order, same additions afterwards: the codes of the released-width encoder must be IDENTICAL, ragged batch included."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import hashlib, torch\n"
+            "from livingscenes_amd import synth\n"
+            "from livingscenes_amd.model_utils import Shape_Prior\n"
+            "dev = torch.device('cuda:0')\n"
+            "ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()\n"
+            "sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=dev)\n"
+            "for B, seed in ((7, 3), (64, 1000)):\n"
+            "    x = synth.make_instances(B, 1024, seed=seed)\n"
+            "    x = (x if isinstance(x, torch.Tensor) else x[0]).to(dev)\n"
+            "    with torch.no_grad():\n"
+            "        c = sp.encode(x)\n"
+            "    print(hashlib.sha1(b''.join(c[k].cpu().numpy().tobytes() for k in ('z_so3', 'z_inv', 's', 't'))).hexdigest())\n")
+    outs = []
+    for env in ({}, {"LS_EDGE_FUSE_Q": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        outs.append([l for l in r.stdout.split() if len(l) == 40])
+    assert len(outs[0]) == 2 and outs[0] == outs[1]
