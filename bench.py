@@ -82,17 +82,23 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     nc = (10 if L["attn"] else 4) * Co
     pc = (4 if L["attn"] else 2) * Co
     down = Nd != Ns   # neighbour-side columns on the Ns source points, destination-side columns on the Nd selected points
-    table_floats = B * 3 * (Ns * pc + Nd * (nc - pc)) if down else B * Ns * 3 * nc
+    # attention layers with C_out in {64, 128} compute the destination side inside the edge kernel (edge.hip, edge_attn_fq_kernel): the
+    # table holds the neighbour-side columns only; the edge kernel reads the destination points' feature rows + the weights instead
+    fused = L["attn"] and os.environ.get("LS_EDGE_FUSE_Q", "1") != "0" and ((Co == 64 and Cin in (32, 64)) or (Co == 128 and Cin == 64))
+    table_floats = B * Ns * 3 * pc if fused else (B * 3 * (Ns * pc + Nd * (nc - pc)) if down else B * Ns * 3 * nc)
+    q_side_in = (B * Nd * 3 * Cin + (nc - pc) * Cin) if fused else 0          # floats the fused edge kernel reads instead of Q columns
+    q_side_flops = mm_mult * 2.0 * B * Nd * 3 * Cin * (nc - pc) if fused else 0.0
     if kind == "knn":
         D = 3 * Cin
         return (B * ((Nd + Ns) * D * f4 + Nd * 16 * 4), 3.0 * B * Nd * Ns * D, FP32_PEAK_TFLOPS,
                 "direct-difference-EQUIVALENT fp32 flops (3 per pair and dimension): the kernels execute fewer -- a bf16-MFMA safe filter "
                 "over all pairs plus exact canonical distances on the ~40 survivors per query")
     if kind == "gemm_edge":
-        return (B * Ns * 3 * Cin * f4 + table_floats * f4 + nc * Cin * f4, mm_mult * 2.0 * table_floats * Cin, mm_peak, mm_what)
+        return (B * Ns * 3 * Cin * f4 + table_floats * f4 + (pc if fused else nc) * Cin * f4, mm_mult * 2.0 * table_floats * Cin, mm_peak, mm_what)
     if kind in ("edge_attn", "edge_pool"):
-        return (table_floats * f4 + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * (60 if L["attn"] else 30), FP32_PEAK_TFLOPS,
-                "fp32 VALU flops (VN activation, scores, soft-max, weighted sum)")
+        return ((table_floats + q_side_in) * f4 + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * (60 if L["attn"] else 30),
+                FP32_PEAK_TFLOPS, "fp32 VALU flops (VN activation, scores, soft-max, weighted sum)" +
+                (f"; the fused destination-side product adds {q_side_flops / 1e9:.1f} GFLOP of f16 MFMA (microseconds at the matrix peak), not counted here" if fused else ""))
     if kind == "edge_l0":
         return B * Ns * 12 + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * 40, FP32_PEAK_TFLOPS, "fp32 VALU flops"
     if kind == "gemm_glob":
