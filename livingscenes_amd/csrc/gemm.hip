@@ -500,6 +500,166 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The residual global conv (vec_dgcnn_atten.py:222-225) as ONE launch: out[p][x][c] = VN-act(lin, dir) with
+//   lin = f[p][x] . W[c] + G[b][x][2C + c],   dir = f[p][x] . W[C + c] + G[b][x][3C + c]
+// -- gemm_h2_kernel (same pipeline, same products, same accumulation order) with the point-wise VN activation as its epilogue instead
+// of a [rows, 2C] table that vn_act_rows_kernel read back.  Two re-mappings make the activation local to a wave:
+//   rows   a 32-row MFMA tile carries 30 rows = TEN whole points (the last two rows of each M-tile are duplicates, never stored), so a
+//          workgroup tile is 120 rows of f: the xyz triple of a point never straddles tiles;
+//   cols   the 128 tile columns are [lin c0..c0+31 | dir c0..c0+31 | lin c0+32..c0+63 | dir c0+32..c0+63] of 64 channels, so wave
+//          (wm, wn) holds lin AND dir of its 32 channels.
+template <bool KAL>   // K is a whole number of 32-k slabs
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_vn_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ G, int ldg, float* __restrict__ out,
+    int M, int C, int K, int npts, float oms, int ntiles_n) {
+    constexpr int TR = 30;                 // useful rows per 32-row MFMA tile
+    constexpr int STG = 32 * 68;
+    constexpr int PLANE = GM * 64;         // one f16 plane: 128 rows x 32 k
+    constexpr int BUF = 4 * PLANE;         // A hi, A lo, B hi, B lo
+    static_assert(2 * BUF >= 4 * STG * 4, "epilogue staging aliases the operand buffers");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = logical / ntiles_n, tn = logical % ntiles_n;
+    const int m0 = tm * 4 * TR, c0 = tn * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kbeg = 0, kend = K;
+
+    f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+
+    // staging map: 128 rows x 8 float4 (32 k) per operand slab, four per thread (rows sr0 + 32 h).  Rows past M / N are clamped
+    // (computed, never stored) and so is k past the end (KAL: whole slabs, the data is never used; otherwise per float4, zeroed by
+    // a select) -- no predicated load, so that the k-loop stays one basic block the scheduler can interleave.
+    const int sr0 = tid >> 3, sk = (tid & 7) * 4;
+    float4 ra[4], rb[4];
+    const float* arow[4];
+    const float* brow[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        // staged row sr0 + 32 h = row sr0 of M-tile h; staged W row = tile column sr0 + 32 h = (wn = h >> 1, lin | dir = h & 1, channel sr0)
+        const int gm = min(m0 + h * TR + min(sr0, TR - 1), M - 1);
+        arow[h] = A + (size_t)gm * lda;
+        brow[h] = W + (size_t)((h & 1) * C + c0 + 32 * (h >> 1) + sr0) * ldw;
+    }
+    auto kof = [&](int k0) { return KAL ? min(k0, kend - 32) + sk : min(k0 + sk, kend - 4); };
+    auto gload_a = [&](int k0) {
+        const int ko = kof(k0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            ra[h] = *reinterpret_cast<const float4*>(arow[h] + ko);
+            if (!KAL && k0 + sk >= kend) ra[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto gload_b = [&](int k0) {
+        const int ko = kof(k0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            rb[h] = *reinterpret_cast<const float4*>(brow[h] + ko);
+            if (!KAL && k0 + sk >= kend) rb[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // plane = 128 rows x 64 bytes; the 16-byte slot index (k / 8) is XOR-ed with bits 2-3 of the row (conflict-free b128 reads)
+    int swz[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = sr0 + h * 32;
+        swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
+    }
+    auto lstore2 = [&](char* plane_hi, const float4& v, int off) {
+        uint2 ph, pl;
+        split2_f16(v, ph, pl);
+        *reinterpret_cast<uint2*>(plane_hi + off) = ph;
+        *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
+    };
+    const int lr = lane & 31;
+    int offa[2], offb[2];   // byte offset of this lane's operand row inside a plane, per 32-row MFMA tile (slot XOR applied per half)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { offa[i] = (wm * 64 + i * 32 + lr) * 64; offb[i] = (wn * 64 + i * 32 + lr) * 64; }
+    const int xa[2] = {((wm * 64 + lr) >> 2) & 3, ((wm * 64 + 32 + lr) >> 2) & 3}, xb[2] = {((wn * 64 + lr) >> 2) & 3, ((wn * 64 + 32 + lr) >> 2) & 3};
+
+    gload_a(kbeg); gload_b(kbeg);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], swz[h]); }
+    gload_a(kbeg + 32); gload_b(kbeg + 32);
+    __syncthreads();
+
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 32, cur ^= 1) {
+        const char* Ac = smem + cur * BUF;
+        const char* Bc = Ac + 2 * PLANE;
+        char* An = smem + (cur ^ 1) * BUF;
+        char* Bn = An + 2 * PLANE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {   // the slab's two 16-k halves; lane (row lr, lane >> 5) holds k = 16 s2 + 8 (lane >> 5) .. +7
+            const int q = s2 * 2 + (lane >> 5);
+            f16x8_t a[2][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
+                    b[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + offb[i] + ((q ^ xb[i]) << 4)));
+                }
+            // term-major, eight independent accumulator chains; between the three groups of four MFMAs: the split of the NEXT slab
+            // (first half: the A rows, second half: the W rows), then the loads of the slab after it
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+            if (s2 == 0) { lstore2(An, ra[0], swz[0]); lstore2(An, ra[1], swz[1]); } else { lstore2(Bn, rb[0], swz[0]); lstore2(Bn, rb[1], swz[1]); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            if (s2 == 0) { lstore2(An, ra[2], swz[2]); lstore2(An, ra[3], swz[3]); gload_a(k0 + 64); }
+            else { lstore2(Bn, rb[2], swz[2]); lstore2(Bn, rb[3], swz[3]); gload_b(k0 + 64); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
+    }
+
+    // epilogue: each wave stages a 32-row M-tile x its 64 columns (lin 32 | dir 32) in LDS, then activates ten points x 32 channels
+    float* stg = reinterpret_cast<float*>(smem) + wave * STG;
+    const int col_l = lane & 31, rowh = (lane >> 5) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const int row0 = m0 + (wm * 2 + i) * TR;       // first row of this M-tile
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int item = it * 64 + lane, pl = item >> 5, c = item & 31;   // point 0..9 of the tile, channel
+            const int grow = row0 + 3 * pl;
+            if (grow < M) {
+                const int ch = c0 + 32 * wn + c;
+                const float* g = G + (size_t)((grow / 3) / npts) * 3 * ldg + 2 * C + ch;
+                const float* sp = stg + 3 * pl * 68 + c;
+                float y0 = sp[0] + g[0], y1 = sp[68] + g[ldg], y2 = sp[136] + g[2 * ldg];
+                const float k0 = sp[32] + g[C], k1 = sp[68 + 32] + g[ldg + C], k2 = sp[136 + 32] + g[2 * ldg + C];
+                vn_act(y0, y1, y2, k0, k1, k2, oms);
+                float* op = out + (size_t)grow * C + ch;
+                op[0] = y0; op[C] = y1; op[2 * C] = y2;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K = 32: the per-point table GEMMs of encoder layers 1-2 (M = B*N*3 up to 196 608 rows, N = 128..384 columns).
 // With two to four k-steps per 128x128 tile the kernel above is all prologue and epilogue: measured per workgroup (K = 64)
 // 6.6 k cycles waiting for the first operand tile + 21.6 k in the k-loop (8.2 k of MFMA) + 21 k issuing the stores, with
@@ -751,6 +911,22 @@ int gemm_dispatch_fast2(const float* A, int lda, const float* W, int ldw, const 
 int gemm_dispatch_masked(const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, const float* mask, int pieces,
                          hipStream_t st) {
     return gemm_dispatch_full(A, lda, W, ldw, nullptr, out, ldc, M, N, K, 0, nullptr, 0, 0, nullptr, st, false, pieces, mask);
+}
+// out [M = B * npts * 3, C] = VN-act(A W[0:C]^T + G lin part, A W[C:2C]^T + G dir part): see gemm_vn_kernel.  false = shape / mode not
+// supported (the caller runs GEMM + vn_act_rows instead)
+bool gemm_vn_supported(int M, int C, int K) {
+    static const bool on = !(getenv("LS_GLOB_FUSE") && atoi(getenv("LS_GLOB_FUSE")) == 0);
+    static const bool h2 = !(getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) && !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
+    return on && h2 && C % 64 == 0 && K % 4 == 0 && K >= 32 && M % 3 == 0;
+}
+int gemm_vn_dispatch(const float* A, int lda, const float* W, int ldw, const float* G, int ldg, float* out, int M, int C, int K, int npts, float oms,
+                     hipStream_t st) {
+    LS_REQUIRE(gemm_vn_supported(M, C, K) && lda % 4 == 0 && ldw % 4 == 0, "gemm_vn: unsupported shape (M=%d C=%d K=%d)", M, C, K);
+    const int tm = cdiv(M, 120), tn = C / 64;
+    if (K % 32 == 0) hipLaunchKernelGGL(gemm_vn_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn);
+    else hipLaunchKernelGGL(gemm_vn_kernel<false>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
 }
 int gemm_dispatch_small(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
                         int K, int relu, float* scratch, hipStream_t st) {

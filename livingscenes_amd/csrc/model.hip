@@ -37,6 +37,8 @@ int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipS
 int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t);
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
+bool gemm_vn_supported(int M, int C, int K);
+int gemm_vn_dispatch(const float*, int, const float*, int, const float*, int, float*, int, int, int, int, float, hipStream_t);
 int gemm_dispatch_fast2(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int gemm_dispatch_masked(const float*, int, const float*, int, float*, int, int, int, int, const float*, int, hipStream_t);
 size_t gemm_scratch_floats(int M, int N, int K);
@@ -293,6 +295,13 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
     int rc;
     { PROF(LS_K_MEAN, i, st); rc = mean_points_launch(msg, B, Nd, Co, g, st); }
     if (rc != LS_OK) return rc;
+    if (gemm_vn_supported(B * Nd * 3, Co, Co)) {
+        // per-instance part first, then ONE launch for the per-point contraction + the VN activation (gemm.hip: gemm_vn_kernel)
+        PROF(LS_K_GEMM_GLOB, i, st);
+        rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, gws, st);
+        if (rc != LS_OK) return rc;
+        return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st);
+    }
     {
         PROF(LS_K_GEMM_GLOB, i, st);
         rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, gws, st);

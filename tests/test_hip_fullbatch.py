@@ -140,3 +140,33 @@ def test_fused_destination_side_equals_table_path_bit_for_bit():
         r = subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
         outs.append([l for l in r.stdout.split() if len(l) == 40])
     assert len(outs[0]) == 2 and outs[0] == outs[1]
+
+
+def test_fused_global_conv_matches_the_two_launch_path():
+    """The residual global conv as one launch (gemm_vn_kernel: the per-point GEMM with the VN activation as its epilogue) against
+    GEMM -> table -> vn_act_rows (LS_GLOB_FUSE=0): same products in the same order, same activation formula.  Compared through the
+    operator export on released widths (layers 2, 4, 6), ragged point counts included."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import hashlib, torch, numpy as np\n"
+            "from livingscenes_amd import synth\n"
+            "from livingscenes_amd.model_utils import Shape_Prior\n"
+            "dev = torch.device('cuda:0')\n"
+            "ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()\n"
+            "sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=dev)\n"
+            "hip = sp.hip_model()\n"
+            "g = torch.Generator().manual_seed(5)\n"
+            "for layer, B, N in ((2, 3, 512), (2, 2, 333), (4, 5, 128), (6, 7, 32), (6, 1, 11)):\n"
+            "    C = ecfg['feat_dim'][layer]\n"
+            "    msg = torch.randn(B, N, 3, C, generator=g).to(dev)\n"
+            "    out = hip.vn_lna_global(layer, msg)\n"
+            "    np.save(f'/tmp/_ls_glob_{os.environ.get(\"LS_GLOB_FUSE\", \"1\")}_{layer}_{B}_{N}.npy', out.cpu().numpy())\n")
+    code = "import os\n" + code
+    for env in ({"LS_GLOB_FUSE": "1"}, {"LS_GLOB_FUSE": "0"}):
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root)
+    for layer, B, N in ((2, 3, 512), (2, 2, 333), (4, 5, 128), (6, 7, 32), (6, 1, 11)):
+        a, b = np.load(f"/tmp/_ls_glob_1_{layer}_{B}_{N}.npy"), np.load(f"/tmp/_ls_glob_0_{layer}_{B}_{N}.npy")
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), (layer, B, N, np.abs(a - b).max())
