@@ -102,7 +102,10 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     if kind == "edge_l0":
         return B * Ns * 12 + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * 40, FP32_PEAK_TFLOPS, "fp32 VALU flops"
     if kind == "gemm_glob":
-        return B * Nd * 3 * 3 * Co * f4 + 4 * Co * Co * f4, mm_mult * 2.0 * B * Nd * 3 * Co * 2 * Co, mm_peak, mm_what
+        # fused with the VN activation (gemm.hip: gemm_vn_kernel) where C_out % 64 == 0: reads f, writes the activated f' (no [rows, 2C] table)
+        glob_fused = Co % 64 == 0 and bf16x3 and os.environ.get("LS_GEMM_MODE") != "bf16x3" and os.environ.get("LS_GLOB_FUSE", "1") != "0"
+        return (B * Nd * 3 * (2 if glob_fused else 3) * Co * f4 + 4 * Co * Co * f4, mm_mult * 2.0 * B * Nd * 3 * Co * 2 * Co, mm_peak,
+                mm_what + (" (+ the VN activation in the epilogue)" if glob_fused else ""))
     if kind == "vn_act":
         return B * Nd * 3 * 3 * Co * f4, 30.0 * B * Nd * Co, FP32_PEAK_TFLOPS, "fp32 VALU flops"
     if kind == "mean":
