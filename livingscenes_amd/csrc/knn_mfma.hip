@@ -473,7 +473,10 @@ __global__ __launch_bounds__(1024) void knn_mean_rows_kernel(const float* __rest
 // one wave per 32-row tile: lane (h, j) walks row j in 16-dim steps (dims kk*16 + h*8 .. +7: two float4 in, one 16-byte store
 // into the step's 1 KB fragment block), accumulating the centred row's squared norm on the way
 __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restrict__ f, const float* __restrict__ mu, int N, int Npad, int D,
-                                                            int tiles_total, unsigned short* __restrict__ out, float* __restrict__ norms) {
+                                                            int tiles_total, unsigned short* __restrict__ out, float* __restrict__ norms,
+                                                            int32_t* __restrict__ zero_buf, long long zero_n) {
+    // the sweep's per-query survivor counters are cleared here (a separate memset launch cost 5 - 7 us per layer)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_buf[i] = 0;
     const int tg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tg >= tiles_total) return;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -756,14 +759,13 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         hipLaunchKernelGGL(knn_mean_rows_kernel, dim3(B, cdiv(D, 64)), dim3(1024), 0, st, src, Ns, D, mu);
         LS_LAUNCH_CHECK();
         hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, mu, Ns, ns_pad, D,
-                           B * (ns_pad / 32), sq, nsrc);
+                           B * (ns_pad / 32), sq, nsrc, surv_cnt, (long long)nq);
         LS_LAUNCH_CHECK();
         if (dst != src) {   // same centre for both sets
             hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, mu, dst_n, dst_npad, D,
-                               B * (dst_npad / 32), dq, ndst);
+                               B * (dst_npad / 32), dq, ndst, (int32_t*)nullptr, 0LL);
             LS_LAUNCH_CHECK();
         }
-        LS_HIP_CHECK(hipMemsetAsync(surv_cnt, 0, nq * sizeof(int32_t), st));
         if (!seed_idx) {   // un-seeded call: hints from a first sweep (class winners -> 16 best)
             unsigned short* img_end = dq + (size_t)B * dst_npad * D;
             float* win_val = (float*)(((uintptr_t)img_end + 255) & ~(uintptr_t)255);
