@@ -242,7 +242,12 @@ struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; const float* cur = n
 
 // where the table(s) of layer i live in T and how the edge kernel reads them (no launch)
 static bool edge_fused(const ls_model* m, int i) {
-    static const bool fuse_q = !(getenv("LS_EDGE_FUSE_Q") && atoi(getenv("LS_EDGE_FUSE_Q")) == 0);   // A/B: destination side as table columns
+    // LS_EDGE_FUSE_Q=0: destination side as table columns (A/B).  The fused kernel forms its products from f16 pieces like the default
+    // GEMM mode; under LS_GEMM_MODE=bf16x3 / LS_GEMM_BF16X3=0 (any fp32 range, or the fp32-MFMA kernels) the table path is kept so that
+    // every product of the layer is formed the same way
+    static const bool fuse_q = !(getenv("LS_EDGE_FUSE_Q") && atoi(getenv("LS_EDGE_FUSE_Q")) == 0) &&
+                               !(getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) &&
+                               !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
     return fuse_q && m->wq_planes[i];
 }
 static EdgeTables edge_tables_layout(const ls_model* m, int i, const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, float* T) {

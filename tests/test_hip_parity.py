@@ -3,6 +3,8 @@ seeded inputs, and against the golden fixtures generated from the imported refer
 
 Bars (BASELINE.json north_star): integer outputs (k-NN / FPS indices, match assignments) BIT-EXACT on identical
 inputs; fp32 outputs within 1e-4 of the tensor max-norm (TOL below; most are ~1e-6)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -301,6 +303,8 @@ def test_gemm_split_is_as_accurate_as_the_fp32_chain_and_row_invariant():
     carries (checked here where ls_gemm_f32 does not split K, K < 128; the decoder path, which never splits K, is covered by
     test_ragged_decode_and_batched_mise_equal_per_instance)."""
     from livingscenes_amd import ops
+    if os.environ.get("LS_GEMM_BF16X3") == "0":
+        pytest.skip("the fp32-MFMA A/B mode is an fp32 FMA chain itself (11 - 16 units on these operands)")
     for K in (32, 64, 256, 768):
         g = torch.Generator().manual_seed(K)
         A = torch.randn(3000, K, generator=g) * torch.exp(2 * torch.randn(3000, K, generator=g))
