@@ -785,6 +785,144 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K = 32 / 64 with the f16 split, PERSISTENT over the M-tiles of one N-tile (the per-point table GEMMs of encoder layers 1 - 4: 24 or
+// 48 MFMAs against a 64 KB store per tile -- all prologue and epilogue in the tiled kernel).  The W tile is split once per workgroup; the
+// whole-K A tile of M-tile t+1 is in flight (registers) under the MFMAs and the stores of tile t.  Same products and accumulation
+// order as gemm_f32_kernel<true, 22>: bit-identical.
+template <int KK, bool GATHER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_h2_smallk_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc, int M,
+    int N, int relu, int ntiles_m, int per_n, const int32_t* __restrict__ a_rows, int gNd, int gNs) {
+    constexpr int STG = 32 * 68;
+    constexpr int NSL = KK / 32;                    // 32-k slabs
+    constexpr int PLANE = GM * 64;                  // one f16 plane of one slab: 128 rows x 32 k
+    constexpr int OPER = 2 * NSL * PLANE;           // hi + lo planes of all slabs of one operand
+    constexpr int ABYTES = (OPER > 4 * STG * 4) ? OPER : 4 * STG * 4;   // the A planes double as the epilogue staging area
+    __shared__ __attribute__((aligned(16))) char smem[ABYTES + OPER];
+    char* Ap = smem;
+    char* Bp = smem + ABYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tn = blockIdx.x / per_n, slot = blockIdx.x % per_n;
+    const int n0 = tn * GN;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int sr0 = tid >> 3, sk = (tid & 7) * 4;   // staging: rows sr0 + 32 h, 16 bytes at column sk of a 32-k slab
+    const bool vec_ok = (ldc % 4 == 0) && (((uintptr_t)out & 15) == 0);
+    int swz[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = sr0 + h * 32;
+        swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
+    }
+    auto lstore2 = [&](char* base, int slab, const float4& v, int off) {
+        uint2 ph, pl;
+        split2_f16(v, ph, pl);
+        *reinterpret_cast<uint2*>(base + (2 * slab) * PLANE + off) = ph;
+        *reinterpret_cast<uint2*>(base + (2 * slab + 1) * PLANE + off) = pl;
+    };
+    // W tile, once (columns past N: clamped row, computed and never stored)
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int gn = min(n0 + sr0 + h * 32, N - 1);
+            lstore2(Bp, sl, *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + sl * 32 + sk), swz[h]);
+        }
+    float bv[2] = {0.f, 0.f};
+    const int lr = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gn = n0 + wn * 64 + j * 32 + lr;
+        bv[j] = (bias && gn < N) ? bias[gn] : 0.0f;
+    }
+    int offa[2], offb[2], xa[2], xb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra_ = wm * 64 + i * 32 + lr, rb_ = wn * 64 + i * 32 + lr;
+        offa[i] = ra_ * 64; offb[i] = rb_ * 64; xa[i] = (ra_ >> 2) & 3; xb[i] = (rb_ >> 2) & 3;
+    }
+
+    float4 ra[NSL][4];
+    auto load_tile = [&](int tmx) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int gm = min(tmx * GM + sr0 + h * 32, M - 1);
+            size_t r_ = (size_t)gm;
+            if constexpr (GATHER) {
+                const int pt = gm / 3, x = gm - pt * 3, bb = pt / gNd;
+                r_ = ((size_t)bb * gNs + a_rows[pt]) * 3 + x;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) ra[sl][h] = *reinterpret_cast<const float4*>(A + r_ * lda + sl * 32 + sk);
+        }
+    };
+    int tm = slot;
+    load_tile(min(tm, ntiles_m - 1));
+    for (; tm < ntiles_m; tm += per_n) {
+        const int m0 = tm * GM;
+        __syncthreads();                               // previous tile's staging reads are done (and the W planes are written)
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) lstore2(Ap, sl, ra[sl][h], swz[h]);
+        __syncthreads();
+        load_tile(min(tm + per_n, ntiles_m - 1));      // next A tile in flight under the MFMAs and the stores (last iteration: re-reads its own)
+
+        f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int q = s2 * 2 + (lane >> 5);
+                f16x8_t a[2][2], b[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ap + (2 * sl + pc) * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
+                        b[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bp + (2 * sl + pc) * PLANE + offb[i] + ((q ^ xb[i]) << 4)));
+                    }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+            }
+        __syncthreads();                               // every wave is done with the A planes: they become the staging area
+        float* stg = reinterpret_cast<float*>(Ap) + wave * STG;
+        const int col_l = lane & 31, rowh = (lane >> 5) * 4;
+        const bool full_tile = vec_ok && (m0 + GM <= M) && (n0 + GN <= N);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) + bv[j];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, nullptr);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // split-K combine: out[m][n] = act(sum_s slab[s][m][n] + bias[n]), slices summed in ascending order (deterministic)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ out, int ldc,
@@ -875,7 +1013,15 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         LS_LAUNCH_CHECK();
         return LS_OK;
     }
-    if (split && pieces == 22)
+    static const bool persist = !(getenv("LS_GEMM_PERSIST") && atoi(getenv("LS_GEMM_PERSIST")) == 0);   // A/B: K = 32 / 64 on the tiled kernel
+    if (split && pieces == 22 && persist && !mask && (K == 32 || K == 64) && tm >= 16 && !h2_unpipelined) {
+        int per_n = cdiv(512, tn);   // two resident workgroups per CU (registers), spread evenly over the N-tiles
+        if (per_n > tm) per_n = tm;
+#define LS_H2SK(KK, G) hipLaunchKernelGGL((gemm_h2_smallk_kernel<KK, G>), dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, relu, tm, per_n, a_rows, gNd, gNs)
+        if (K == 32) { if (a_rows) LS_H2SK(32, true); else LS_H2SK(32, false); }
+        else { if (a_rows) LS_H2SK(64, true); else LS_H2SK(64, false); }
+#undef LS_H2SK
+    } else if (split && pieces == 22)
         hipLaunchKernelGGL(LS_H2_KERNEL, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
                            gNd, gNs, K, (size_t)0, mask);
     else if (split && pieces == 2)
