@@ -102,8 +102,10 @@ class Generator3D:
                 outs.append(self.implicit_F(pi.unsqueeze(0), z, c, **kwargs).logits.squeeze(0))
         return torch.cat(outs, 0) if outs else p.new_zeros(0)
 
-    def eval_grid(self, c, F, stats_dict=None, **kwargs):
-        """-> value grid float64 [(R+1)^3] as numpy (what the reference hands to marching cubes), R = resolution0 << steps."""
+    def eval_grid(self, c, F, stats_dict=None, on_device=False, **kwargs):
+        """-> value grid float64 [(R+1)^3] as numpy (what the reference hands to marching cubes), R = resolution0 << steps.
+        on_device=True (used by generate_from_latent): the same values as a float64 DEVICE tensor -- the 129^3 grid (17 MB) does not
+        travel to the host and back between the octree and the marching cubes kernels."""
         self.implicit_F = F
         z = torch.zeros(1, 0, device=self.device)
         threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
@@ -112,7 +114,8 @@ class Generator3D:
             nx = self.resolution0
             lin = torch.linspace(-0.5, 0.5, nx, device=self.device)
             g = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)   # make_3d_grid, common.py:157
-            return self.eval_points(box_size * g, z, c, **kwargs).reshape(nx, nx, nx).cpu().numpy().astype(np.float64)
+            dense = self.eval_points(box_size * g, z, c, **kwargs).reshape(nx, nx, nx)
+            return dense.to(torch.float64) if on_device else dense.cpu().numpy().astype(np.float64)
         mise = MISE(self.resolution0, self.upsampling_steps, threshold, device=self.device)
         rounds = []
         idx, pts = mise.query_device(box_size)
@@ -122,9 +125,9 @@ class Generator3D:
             idx, pts = mise.query_device(box_size)
         if stats_dict is not None:
             stats_dict["mise rounds"] = rounds
-        return mise.to_dense()
+        return mise.to_dense_device().to(torch.float64) if on_device else mise.to_dense()
 
-    def eval_grid_batch(self, codes, F):
+    def eval_grid_batch(self, codes, F, on_device=False):
         """Value grids of SEVERAL instances at once (an extension: the reference extracts one mesh at a time).  codes: dict of
         [B,...] tensors.  All MISE octrees advance in lock-step; each round the unknown points of every instance are packed into
         ONE ragged decoder call (ls_sdf_decode_rows), so the small late rounds and the per-round host round trip are shared.
@@ -162,15 +165,15 @@ class Generator3D:
                 mises[b].update_device(mises[b]._idx[:n], logits[o:o + n])
                 o += n
             active = [b for b, _ in live]
-        return [m.to_dense() for m in mises]
+        return [m.to_dense_device().to(torch.float64) if on_device else m.to_dense() for m in mises]
 
     def generate_from_latent_batch(self, codes, F):
         """Meshes of B codes (batched MISE rounds, then marching cubes per instance)."""
-        return [self.extract_mesh(g, None, None) for g in self.eval_grid_batch(codes, F)]
+        return [self.extract_mesh(g, None, None) for g in self.eval_grid_batch(codes, F, on_device=True)]
 
     def generate_from_latent(self, c, F, **kwargs):
         """mesh_extractor2.py:60-74."""
-        return self.extract_mesh(self.eval_grid(c, F, **kwargs), None, c)
+        return self.extract_mesh(self.eval_grid(c, F, on_device=True, **kwargs), None, c)
 
     def extract_mesh(self, occ_hat, z, c=None, stats_dict=None):
         """mesh_extractor2.py:161-214: pad with -1e6 (watertight), marching cubes at the logit threshold, undo the library's 0.5
@@ -181,7 +184,10 @@ class Generator3D:
         n_x, n_y, n_z = occ_hat.shape
         box_size = 1 + self.padding
         threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
-        vol = torch.as_tensor(np.asarray(occ_hat, np.float64), device=self.device)
+        if torch.is_tensor(occ_hat) and occ_hat.is_cuda:
+            vol = occ_hat.to(torch.float64)              # grid still on the device (generate_from_latent)
+        else:
+            vol = torch.as_tensor(np.asarray(occ_hat, np.float64), device=self.device)
         vol = torch.nn.functional.pad(vol, (1, 1, 1, 1, 1, 1), value=-1e6)
         vertices, triangles = marching_cubes(vol, threshold)
         vertices = vertices.cpu().numpy()
