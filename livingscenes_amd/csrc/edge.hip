@@ -17,6 +17,9 @@
 //
 // Table columns (Co = layer width):  pool layers  [PV_lin | PV_dir | QV_lin | QV_dir]
 //                                    attn layers  [PV_lin | PV_dir | PK_lin | PK_dir | QV_lin | QV_dir | QK_lin | QK_dir | Qq_lin | Qq_dir]
+// Attention layers with C_out = 64 / 128 (released encoder: layers 2 - 4) do NOT materialise the Q* column groups: edge_attn_fq_kernel
+// computes them per workgroup on the f16 matrix cores from the destination points' feature rows (see there); their table holds the
+// four P* groups only.
 // Thread mapping: one wave per destination point, lanes = channels (coalesced 256-B row segments per
 // neighbour and xyz component), channel chunks of 64; attention heads are 16 consecutive channels = one
 // 16-lane DPP row, so head sums / soft-max reductions are 4-step row shuffles.

@@ -1,4 +1,14 @@
-// gemm.hip -- out[M,N] = act(A[M,K] * W[N,K]^T + bias), exact fp32 on the CDNA4 matrix cores.
+// gemm.hip -- out[M,N] = act(A[M,K] * W[N,K]^T + bias), fp32 in / fp32 out on the CDNA4 matrix cores.
+//
+// Kernels in this file (all 128 x 128 workgroup tiles, four waves as 2 x 2, 32 x 32 MFMA tiles):
+//   gemm_f32_kernel<false>          v_mfma_f32_32x32x2_f32, exact fp32 FMA chains (LS_GEMM_BF16X3=0, and the caller-designated latency GEMMs)
+//   gemm_f32_kernel<true, 3 | 2>    fp32 products as three (two) bf16 pieces, six (three) v_mfma_f32_32x32x16_bf16 per 16 k (LS_GEMM_MODE=bf16x3)
+//   gemm_f32_kernel<true, 22>       fp32 products as two f16 pieces with a scaled residual, three v_mfma_f32_32x32x16_f16: the DEFAULT arithmetic
+//   gemm_h2_kernel                  the same arithmetic as a double-buffered software pipeline (K >= 128)
+//   gemm_h2_smallk_kernel           the same arithmetic, persistent over the M-tiles of an N-tile (K = 32 / 64 table GEMMs)
+//   gemm_vn_kernel                  gemm_h2_kernel with the VN activation of the residual global conv as its epilogue
+//   gemm_smallk_kernel              fp32-MFMA persistent small-K kernel (fp32 mode only)
+// The paragraph below describes the fp32-MFMA kernel the others grew from (tile shape, LDS layout, k permutation).
 //
 // This is the ONLY MFMA-shaped work on the path: the VecLinear channel contraction
 // (/root/reference/lib_shape_prior/core/lib/vec_sim3/vec_layers.py:121-136, F.linear at :134) applied to
