@@ -213,14 +213,15 @@ def main():
     else:  # other ranks start from zeros and receive rank 0's weights over RCCL
         ew = {k: torch.zeros(s) for k, s in synth.encoder_param_shapes(ecfg).items()}
         dw = {k: torch.zeros_like(v) for k, v in synth.make_decoder_weights(dcfg, 0).items()}
-    sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=dev)
-    if multi:
-        parallel.broadcast_weights(sp, src=0)
     nfl = max(1, args.inflight)
     if nfl > 1:
         # A/B on MI355X (scripts in DESIGN.md 6): intra-step GEMM||k-NN stream overlap is +5 % for a single in-flight step but
-        # -3.5 % once two whole steps already overlap; the library default stays on, the bench turns it off.
+        # -3.5 % once two whole steps already overlap; the library default stays on, the bench turns it off (before ANY handle is
+        # created: the option is read at ls_model_create).
         os.environ.setdefault("LS_GEMM_OVERLAP", "0")
+    sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=dev)
+    if multi:
+        parallel.broadcast_weights(sp, src=0)
     # one model handle (packed weights + side stream + workspace) per in-flight step; weights are shared tensors
     sps = [sp] + [Shape_Prior.from_state(ecfg, dcfg, sp.encoder.state_dict(), sp.decoder.F.state_dict(), device=dev) for _ in range(nfl - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
