@@ -421,17 +421,42 @@ __device__ __forceinline__ void esplit8(const float* p, eh8_t& h, eh8_t& l) {
 // lane = (row & 31) + 32 (k / 8 & 1), eight consecutive k: a wave fetches an operand fragment with ONE contiguous 1 KB load.  (Fetching
 // the fragments straight from the row-major fp32 weights -- 32 rows x 32 bytes per load instruction -- made the fused kernel 2x
 // slower than the un-fused one: every load instruction touched 32 cache lines.)  Built once per model (ls_model_create).
-__global__ __launch_bounds__(64) void edge_presplit_wq_kernel(const float* __restrict__ W, int rows, int Cin, int KS, uint4* __restrict__ planes) {
+// Operand range (gemm.hip, "operand range of the f16 split"): every weight row is multiplied by its own power of two before the split;
+// the inverse scales [rows] follow the planes.  The kernel scales its feature rows the same way and multiplies the accumulators by the
+// product of the two inverses -- the same exact scaling the table GEMM applies, so the two paths stay bit-identical.
+__device__ __forceinline__ void epow2_scale(float amax, float& s, float& inv) {
+    unsigned be = (__float_as_uint(amax) >> 23) & 0xffu;
+    be = be < 15u ? 15u : be;
+    s = __uint_as_float((268u - be) << 23);
+    inv = __uint_as_float((be - 14u) << 23);
+}
+template <int CTRL>
+__device__ __forceinline__ float edpp_fmax(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
+__global__ __launch_bounds__(64) void edge_presplit_wq_kernel(const float* __restrict__ W, int rows, int Cin, int KS, uint4* __restrict__ planes,
+                                                               float* __restrict__ winv) {
     const int tile = blockIdx.x / KS, ks = blockIdx.x % KS, lane = threadIdx.x;
     const int n = tile * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5);
+    const float* wr = W + (size_t)min(n, rows - 1) * Cin;
+    float am = 0.f;
+    for (int c = 0; c < Cin; ++c) am = fmaxf(am, fabsf(wr[c]));
+    float sc, inv;
+    epow2_scale(am, sc, inv);
+    if (ks == 0 && lane < 32 && n < rows) winv[n] = inv;
+    __attribute__((aligned(16))) float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = wr[k + c] * sc;
     eh8_t h, l;
-    esplit8(W + (size_t)min(n, rows - 1) * Cin + k, h, l);
+    esplit8(v, h, l);
     planes[((size_t)blockIdx.x * 2) * 64 + lane] = __builtin_bit_cast(uint4, h);
     planes[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, l);
 }
-size_t edge_wq_planes_bytes(int Co, int Cin) { return (size_t)(6 * Co / 32) * (Cin / 16) * 2 * 64 * sizeof(uint4); }
+static size_t edge_wq_plane_count(int Co, int Cin) { return (size_t)(6 * Co / 32) * (Cin / 16) * 2 * 64; }
+size_t edge_wq_planes_bytes(int Co, int Cin) { return edge_wq_plane_count(Co, Cin) * sizeof(uint4) + (size_t)6 * Co * sizeof(float); }
 int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipStream_t st) {
-    hipLaunchKernelGGL(edge_presplit_wq_kernel, dim3((6 * Co / 32) * (Cin / 16)), dim3(64), 0, st, Wq, 6 * Co, Cin, Cin / 16, (uint4*)planes);
+    hipLaunchKernelGGL(edge_presplit_wq_kernel, dim3((6 * Co / 32) * (Cin / 16)), dim3(64), 0, st, Wq, 6 * Co, Cin, Cin / 16, (uint4*)planes,
+                       (float*)((uint4*)planes + edge_wq_plane_count(Co, Cin)));
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -447,6 +472,8 @@ __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restri
     __shared__ float l_score[EK][256];
     __shared__ __attribute__((aligned(16))) float slab[ROWS * SLD];
     __shared__ __attribute__((aligned(16))) char a_pl[2][MT * 32 * ASTR];   // the workgroup's feature rows as (hi, lo) f16 planes
+    __shared__ float a_inv[MT * 32];                                        // inverse power-of-two scale of each staged row
+    const float* __restrict__ winv = reinterpret_cast<const float*>(Wp + (size_t)(6 * Co / 32) * KS * 128);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / LPP, ll = lane % LPP;
     const int pid0 = xcd_remap(blockIdx.x, gridDim.x) * PW;
@@ -463,13 +490,22 @@ __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restri
     for (int c = tid; c < MT * 32 * (CIN / 4); c += 256) {
         const int r = c / (CIN / 4), kq = c - r * (CIN / 4);
         uint2 h = make_uint2(0u, 0u), l = make_uint2(0u, 0u);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < ROWS) {
             const int pw = r / 3, x = r - 3 * pw;
             const int pa = min(pid0 + pw, total - 1), ba = pa / Nd;
             const int sp = dst_rows ? dst_rows[pa] : pa - ba * Nd;
-            const float4 v = *reinterpret_cast<const float4*>(cur + (((size_t)ba * Ns + sp) * 3 + x) * CIN + kq * 4);
-            esplit_pair(ef2_t{v.x, v.y}, h.x, l.x);
-            esplit_pair(ef2_t{v.z, v.w}, h.y, l.y);
+            v = *reinterpret_cast<const float4*>(cur + (((size_t)ba * Ns + sp) * 3 + x) * CIN + kq * 4);
+        }
+        {   // the CIN / 4 = 8 | 16 threads of a row are an aligned lane group: row maximum by DPP, then the row's power of two
+            float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            am = edpp_fmax<0x141>(edpp_fmax<0x4E>(edpp_fmax<0xB1>(am)));
+            if constexpr (CIN == 64) am = edpp_fmax<0x140>(am);
+            float sc, inv;
+            epow2_scale(am, sc, inv);
+            if (kq == 0) a_inv[r] = inv;
+            esplit_pair(ef2_t{v.x * sc, v.y * sc}, h.x, l.x);
+            esplit_pair(ef2_t{v.z * sc, v.w * sc}, h.y, l.y);
         }
         *reinterpret_cast<uint2*>(&a_pl[0][r * ASTR + kq * 8]) = h;
         *reinterpret_cast<uint2*>(&a_pl[1][r * ASTR + kq * 8]) = l;
@@ -499,10 +535,11 @@ __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restri
             // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); rows past the workgroup's points: dropped
             const int row0 = 32 * mt + 4 * (lane >> 5);
             float* sp = slab + row0 * SLD + 32 * nt + (lane & 31);
+            const float cs = winv[cb + 32 * nt + (lane & 31)];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
-                if (row0 + dr < ROWS) sp[dr * SLD] = fmaf(acx[r], 0.0009765625f, acc[r]);
+                if (row0 + dr < ROWS) sp[dr * SLD] = fmaf(acx[r], 0.0009765625f, acc[r]) * (a_inv[row0 + dr] * cs);
             }
         }
     };

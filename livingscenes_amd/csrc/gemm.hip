@@ -77,6 +77,35 @@ __device__ __forceinline__ void split2_f16(const float4& v, uint2& h, uint2& l) 
     split2_f16_pair(f32x2_t{v.x, v.y}, h.x, l.x);
     split2_f16_pair(f32x2_t{v.z, v.w}, h.y, l.y);
 }
+// ---- operand range of the f16 split.  f16 covers 2^-14 .. 65504, fp32 features and gradients do not stay there (a trained encoder's
+// conv_c outputs sit at ~1.5e-5 because the heads multiply by scale_factor = 64000, vec_dgcnn_atten.py:234-250; the gradients of the
+// pose refinement at 1e-6 .. 1e-8).  So every ROW of A and every row of W is multiplied by its own exact power of two before the split --
+// s = 2^(14 - floor(log2 max|row|)): the row's largest element lands in [2^14, 2^15), elements down to 2^-27 of it keep the full 22
+// bits, the absolute floor is 2^-49 of the row maximum -- and the product of the two inverse scales multiplies the fp32 accumulators in
+// the epilogue.  Powers of two commute with every rounding in between, so for data that was in range before the result is
+// BIT-IDENTICAL to the unscaled split, any finite fp32 input is handled, and a row's result depends on that row's data only.
+// The row maxima come from (a) a pre-pass of the kernel over its own operand rows (default), or (b) caller-supplied arrays
+// (GemmAux: the decoder chains them from the previous layer's epilogue, weights carry theirs from ls_model_create), which may be
+// any upper bound: each factor of two of slack costs one bit at the bottom of the 27-binade window.
+// (struct GemmAux: ls_common.h)
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// exact powers of two: s * amax in [2^14, 2^15), inv = 1 / s.  amax = 0 (or fp32-subnormal) -> s = 2^126; Inf / NaN rows stay non-finite.
+__device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
+    unsigned be = (__float_as_uint(amax) >> 23) & 0xffu;
+    be = be < 15u ? 15u : be;
+    s = __uint_as_float((268u - be) << 23);
+    inv = __uint_as_float((be - 14u) << 23);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_fmax(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
+// max over aligned groups of 8 lanes (the 8 staging threads of one operand row) / 16 lanes, in every lane of the group
+__device__ __forceinline__ float max8(float v) { return dpp_fmax<0x141>(dpp_fmax<0x4E>(dpp_fmax<0xB1>(v))); }
+__device__ __forceinline__ float max16(float v) { return dpp_fmax<0x140>(max8(v)); }
+__device__ __forceinline__ float4 scale4(const float4& v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
 
 constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 
@@ -85,8 +114,11 @@ constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 // 256-byte row segments per wave); per-element branches around the LDS read -> store pairs cost 12 % on the K <= 64 GEMMs.
 // `mask` (nullable, same shape and row stride as `out`): out = mask > 0 ? value : 0 -- the ReLU derivative of the decoder's backward
 // pass fused into the store (ls_sdf_backward: dh_{l-1} = (dz_l W_l) [h_{l-1} > 0]; a separate pass cost 80 us per layer at 65 536 rows).
+// `rowmax` (nullable): rowmax[gm * rm_parts + rm_part] = max|value| of row gm over this wave's 64 columns (after the mask) -- the next
+// GEMM's operand range, see GemmAux.
 __device__ __forceinline__ void store_half_tile(const float* stg, float* __restrict__ out, int ldc, int M, int N, int gm0, int gn0,
-                                                int lane, bool full_tile, bool vec_ok, const float* __restrict__ mask) {
+                                                int lane, bool full_tile, bool vec_ok, const float* __restrict__ mask,
+                                                float* __restrict__ rowmax = nullptr, int rm_parts = 0, int rm_part = 0) {
     if (full_tile) {
         float4 v[8];
 #pragma unroll
@@ -103,6 +135,13 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
         float* op = out + o0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(op + (size_t)(u * 4) * ldc) = v[u];
+        if (rowmax) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float rm = max16(amax4(0.f, v[u]));
+                if ((lane & 15) == 0) rowmax[(size_t)(gm0 + u * 4 + (lane >> 4)) * rm_parts + rm_part] = rm;
+            }
+        }
         return;
     }
 #pragma unroll
@@ -110,6 +149,7 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
         const int idx = u * 64 + lane;           // 32 rows x 16 float4
         const int rr = idx >> 4, c4 = (idx & 15) * 4;
         const int gm = gm0 + rr, gn = gn0 + c4;
+        float rm = 0.f;
         if (gm < M && gn < N) {
             float4 v = *reinterpret_cast<const float4*>(&stg[rr * 68 + c4]);
             float* op = out + (size_t)gm * ldc + gn;
@@ -122,12 +162,17 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
             }
             if (vec_ok && gn + 3 < N) {
                 *reinterpret_cast<float4*>(op) = v;
+                rm = amax4(0.f, v);
             } else {
-                op[0] = v.x;
-                if (gn + 1 < N) op[1] = v.y;
-                if (gn + 2 < N) op[2] = v.z;
-                if (gn + 3 < N) op[3] = v.w;
+                op[0] = v.x; rm = fabsf(v.x);
+                if (gn + 1 < N) { op[1] = v.y; rm = fmaxf(rm, fabsf(v.y)); }
+                if (gn + 2 < N) { op[2] = v.z; rm = fmaxf(rm, fabsf(v.z)); }
+                if (gn + 3 < N) { op[3] = v.w; rm = fmaxf(rm, fabsf(v.w)); }
             }
+        }
+        if (rowmax) {   // wave-uniform
+            rm = max16(rm);
+            if ((lane & 15) == 0 && gm < M) rowmax[(size_t)gm * rm_parts + rm_part] = rm;
         }
     }
 }
@@ -144,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                                                        int ldw, const float* __restrict__ bias, float* __restrict__ out,
                                                        int ldc, int M, int N, int K, int relu, int ntiles_n,
                                                        const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk,
-                                                       size_t slab_stride, const float* __restrict__ mask) {
+                                                       size_t slab_stride, const float* __restrict__ mask, GemmAux aux) {
     constexpr int STG = 32 * 68;  // epilogue staging: 32 rows x (64 + 4) floats per wave
     constexpr int BK = SPLIT ? 32 : GK;          // k depth of one staged slab
     constexpr int NST = SPLIT ? 4 : 2;           // float4 per thread per operand slab
@@ -177,6 +222,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int sr0 = SPLIT ? (tid >> 3) : (tid >> 2), sk = SPLIT ? (tid & 7) * 4 : (tid & 3) * 4;
     constexpr int RSTEP = SPLIT ? 32 : 64;
     float4 ra[NST], rb[NST];
+    float sa[NST], sw[NST];   // f16 split: power-of-two scale of this thread's staged A / W rows (GemmAux)
+#pragma unroll
+    for (int h = 0; h < NST; ++h) { sa[h] = 1.f; sw[h] = 1.f; }
+    __shared__ float rsc[H2 ? GM + GN : 1];   // inverse scales of the tile's 128 A rows, then of its 128 W rows
+    if constexpr (H2) { if (aux.noscale) rsc[tid] = 1.f; }   // (256 threads = GM + GN entries; otherwise the range block below writes every entry)
     long long arow[NST];  // source row of A for this thread's staged rows (-1 = out of range)
 #pragma unroll
     for (int h = 0; h < NST; ++h) {
@@ -210,10 +260,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 const int swz = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
                 uint2 p1, p2, p3;
                 if constexpr (H2) {
-                    split2_f16(ra[h], p1, p2);
+                    split2_f16(scale4(ra[h], sa[h]), p1, p2);
                     *reinterpret_cast<uint2*>(Ap + swz) = p1;
                     *reinterpret_cast<uint2*>(Ap + PLANE + swz) = p2;
-                    split2_f16(rb[h], p1, p2);
+                    split2_f16(scale4(rb[h], sw[h]), p1, p2);
                     *reinterpret_cast<uint2*>(Bp + swz) = p1;
                     *reinterpret_cast<uint2*>(Bp + PLANE + swz) = p2;
                     continue;
@@ -239,6 +289,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #else
 #define LS_PH(i)
 #endif
+    if constexpr (H2) {
+        // operand range (see GemmAux): per-row powers of two from a pre-pass over this tile's rows, or from the caller's row maxima
+        if (!aux.noscale) {
+            float ma[NST], mw[NST];
+#pragma unroll
+            for (int h = 0; h < NST; ++h) { ma[h] = 0.f; mw[h] = 0.f; }
+            const bool pre_a = aux.a_rowmax == nullptr, pre_w = aux.w_rowmax == nullptr;
+            if (pre_a || pre_w)
+                for (int k0 = kbeg; k0 < kend; k0 += BK) {
+                    gload(k0);
+#pragma unroll
+                    for (int h = 0; h < NST; ++h) { ma[h] = amax4(ma[h], ra[h]); mw[h] = amax4(mw[h], rb[h]); }
+                }
+#pragma unroll
+            for (int h = 0; h < NST; ++h) {
+                const int r = sr0 + h * RSTEP;
+                if (pre_a) ma[h] = max8(ma[h]);
+                else {
+                    ma[h] = 0.f;
+                    if (arow[h] >= 0) for (int q = 0; q < aux.a_parts; ++q) ma[h] = fmaxf(ma[h], aux.a_rowmax[(size_t)arow[h] * aux.a_parts + q]);
+                }
+                if (pre_w) mw[h] = max8(mw[h]);
+                else mw[h] = n0 + r < N ? aux.w_rowmax[n0 + r] : 0.f;
+                float ia, iw;
+                pow2_scale(ma[h], sa[h], ia);
+                pow2_scale(mw[h], sw[h], iw);
+                if ((tid & 7) == 0) { rsc[r] = ia; rsc[GM + r] = iw; }
+            }
+        }
+    }
     gload(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
@@ -335,10 +415,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wn * 64 + j * 32 + col_l;
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
+            float cs = 1.f;
+            if constexpr (H2) cs = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r];
-                if constexpr (H2) v = fmaf(acx[i][j][r], 0.0009765625f, v);
+                if constexpr (H2) v = fmaf(acx[i][j][r], 0.0009765625f, v) * (rsc[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rowh] * cs);
                 v += bv;
                 if (relu) v = fmaxf(v, 0.0f);
                 stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
@@ -347,7 +429,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         // wave-local hand-off through LDS: same wave writes and reads, LDS ops of a wave complete in order
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask);
+        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask,
+                        gridDim.y == 1 ? aux.out_rowmax : nullptr, 2 * ntiles_n, 2 * tn + wn);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -363,12 +446,13 @@ template <bool KAL>   // K range of this launch is a whole number of 32-k slabs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_h2_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc,
     int M, int N, int K, int relu, int ntiles_n, const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk, size_t slab_stride,
-    const float* __restrict__ mask) {
+    const float* __restrict__ mask, GemmAux aux) {
     constexpr int STG = 32 * 68;
     constexpr int PLANE = GM * 64;         // one f16 plane: 128 rows x 32 k
     constexpr int BUF = 4 * PLANE;         // A hi, A lo, B hi, B lo
     static_assert(2 * BUF >= 4 * STG * 4, "epilogue staging aliases the operand buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];   // inverse power-of-two scales of the tile's A rows, then of its W rows (GemmAux)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = logical / ntiles_n, tn = logical % ntiles_n;
@@ -428,12 +512,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int r = sr0 + h * 32;
         swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
     }
-    auto lstore2 = [&](char* plane_hi, const float4& v, int off) {
+    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {
         uint2 ph, pl;
-        split2_f16(v, ph, pl);
+        split2_f16(scale4(v, sc), ph, pl);
         *reinterpret_cast<uint2*>(plane_hi + off) = ph;
         *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
     };
+    // operand range: one exact power of two per staged row (GemmAux), from the caller's row maxima or a pre-pass over the rows
+    float sa[4] = {1.f, 1.f, 1.f, 1.f}, sw[4] = {1.f, 1.f, 1.f, 1.f};
+    if (aux.noscale) rsc[tid] = 1.f;
+    else {
+        float ma[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f};
+        if (aux.a_rowmax) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float* rp = aux.a_rowmax + (size_t)((arow[h] - A) / lda) * aux.a_parts;
+                for (int q = 0; q < aux.a_parts; ++q) ma[h] = fmaxf(ma[h], rp[q]);
+            }
+        } else {
+            for (int k0 = kbeg; k0 < kend; k0 += 32) {
+                gload_a(k0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) ma[h] = amax4(ma[h], ra[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) ma[h] = max8(ma[h]);
+        }
+        if (aux.w_rowmax) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) mw[h] = aux.w_rowmax[(brow[h] - W) / ldw];
+        } else {
+            for (int k0 = kbeg; k0 < kend; k0 += 32) {
+                gload_b(k0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) mw[h] = amax4(mw[h], rb[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) mw[h] = max8(mw[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float ia, iw;
+            pow2_scale(ma[h], sa[h], ia);
+            pow2_scale(mw[h], sw[h], iw);
+            if ((tid & 7) == 0) { rsc[sr0 + h * 32] = ia; rsc[GM + sr0 + h * 32] = iw; }
+        }
+    }
     const int lr = lane & 31;
     int offa[2], offb[2];   // byte offset of this lane's operand row inside a plane, per 32-row MFMA tile (slot XOR applied per half)
 #pragma unroll
@@ -442,7 +566,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 
     gload_a(kbeg); gload_b(kbeg);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], swz[h]); }
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], sw[h], swz[h]); }
     gload_a(kbeg + 32); gload_b(kbeg + 32);
     __syncthreads();
 
@@ -469,13 +593,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[0], swz[0]); lstore2(An, ra[1], swz[1]); } else { lstore2(Bn, rb[0], swz[0]); lstore2(Bn, rb[1], swz[1]); }
+            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2(Bn, rb[0], sw[0], swz[0]); lstore2(Bn, rb[1], sw[1], swz[1]); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[2], swz[2]); lstore2(An, ra[3], swz[3]); gload_a(k0 + 64); }
-            else { lstore2(Bn, rb[2], swz[2]); lstore2(Bn, rb[3], swz[3]); gload_b(k0 + 64); }
+            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
+            else { lstore2(Bn, rb[2], sw[2], swz[2]); lstore2(Bn, rb[3], sw[3], swz[3]); gload_b(k0 + 64); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -495,16 +619,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wn * 64 + j * 32 + col_l;
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
+            const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) + bv;
-                if (relu) v = fmaxf(v, 0.0f);
-                stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                for (int rl = 0; rl < 4; ++rl) {
+                    const int r = r4 * 4 + rl;
+                    float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs) + bv;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask);
+        store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask,
+                        gridDim.y == 1 ? aux.out_rowmax : nullptr, 2 * ntiles_n, 2 * tn + wn);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -521,13 +653,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 template <bool KAL>   // K is a whole number of 32-k slabs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_vn_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ G, int ldg, float* __restrict__ out,
-    int M, int C, int K, int npts, float oms, int ntiles_n) {
+    int M, int C, int K, int npts, float oms, int ntiles_n, GemmAux aux) {
     constexpr int TR = 30;                 // useful rows per 32-row MFMA tile
     constexpr int STG = 32 * 68;
     constexpr int PLANE = GM * 64;         // one f16 plane: 128 rows x 32 k
     constexpr int BUF = 4 * PLANE;         // A hi, A lo, B hi, B lo
     static_assert(2 * BUF >= 4 * STG * 4, "epilogue staging aliases the operand buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];   // inverse power-of-two scales of the staged A rows, then of the staged W rows (GemmAux)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = logical / ntiles_n, tn = logical % ntiles_n;
@@ -581,12 +714,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int r = sr0 + h * 32;
         swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
     }
-    auto lstore2 = [&](char* plane_hi, const float4& v, int off) {
+    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {
         uint2 ph, pl;
-        split2_f16(v, ph, pl);
+        split2_f16(scale4(v, sc), ph, pl);
         *reinterpret_cast<uint2*>(plane_hi + off) = ph;
         *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
     };
+    // operand range: one exact power of two per staged row (GemmAux), from the caller's row maxima or a pre-pass over the rows
+    float sa[4] = {1.f, 1.f, 1.f, 1.f}, sw[4] = {1.f, 1.f, 1.f, 1.f};
+    if (aux.noscale) rsc[tid] = 1.f;
+    else {
+        float ma[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f};
+        if (aux.a_rowmax) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float* rp = aux.a_rowmax + (size_t)((arow[h] - A) / lda) * aux.a_parts;
+                for (int q = 0; q < aux.a_parts; ++q) ma[h] = fmaxf(ma[h], rp[q]);
+            }
+        } else {
+            for (int k0 = kbeg; k0 < kend; k0 += 32) {
+                gload_a(k0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) ma[h] = amax4(ma[h], ra[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) ma[h] = max8(ma[h]);
+        }
+        if (aux.w_rowmax) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) mw[h] = aux.w_rowmax[(brow[h] - W) / ldw];
+        } else {
+            for (int k0 = kbeg; k0 < kend; k0 += 32) {
+                gload_b(k0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) mw[h] = amax4(mw[h], rb[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) mw[h] = max8(mw[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float ia, iw;
+            pow2_scale(ma[h], sa[h], ia);
+            pow2_scale(mw[h], sw[h], iw);
+            if ((tid & 7) == 0) { rsc[sr0 + h * 32] = ia; rsc[GM + sr0 + h * 32] = iw; }
+        }
+    }
     const int lr = lane & 31;
     int offa[2], offb[2];   // byte offset of this lane's operand row inside a plane, per 32-row MFMA tile (slot XOR applied per half)
 #pragma unroll
@@ -595,7 +768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 
     gload_a(kbeg); gload_b(kbeg);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], swz[h]); }
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], sw[h], swz[h]); }
     gload_a(kbeg + 32); gload_b(kbeg + 32);
     __syncthreads();
 
@@ -622,13 +795,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[0], swz[0]); lstore2(An, ra[1], swz[1]); } else { lstore2(Bn, rb[0], swz[0]); lstore2(Bn, rb[1], swz[1]); }
+            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2(Bn, rb[0], sw[0], swz[0]); lstore2(Bn, rb[1], sw[1], swz[1]); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[2], swz[2]); lstore2(An, ra[3], swz[3]); gload_a(k0 + 64); }
-            else { lstore2(Bn, rb[2], swz[2]); lstore2(Bn, rb[3], swz[3]); gload_b(k0 + 64); }
+            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
+            else { lstore2(Bn, rb[2], sw[2], swz[2]); lstore2(Bn, rb[3], sw[3], swz[3]); gload_b(k0 + 64); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -643,10 +816,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                for (int rl = 0; rl < 4; ++rl) {
+                    const int r = r4 * 4 + rl;
+                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs);
+                }
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         const int row0 = m0 + (wm * 2 + i) * TR;       // first row of this M-tile
@@ -803,13 +985,14 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const float* __restric
 template <int KK, bool GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_h2_smallk_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc, int M,
-    int N, int relu, int ntiles_m, int per_n, const int32_t* __restrict__ a_rows, int gNd, int gNs) {
+    int N, int relu, int ntiles_m, int per_n, const int32_t* __restrict__ a_rows, int gNd, int gNs, GemmAux aux) {
     constexpr int STG = 32 * 68;
     constexpr int NSL = KK / 32;                    // 32-k slabs
     constexpr int PLANE = GM * 64;                  // one f16 plane of one slab: 128 rows x 32 k
     constexpr int OPER = 2 * NSL * PLANE;           // hi + lo planes of all slabs of one operand
     constexpr int ABYTES = (OPER > 4 * STG * 4) ? OPER : 4 * STG * 4;   // the A planes double as the epilogue staging area
     __shared__ __attribute__((aligned(16))) char smem[ABYTES + OPER];
+    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];   // inverse power-of-two scales of the current tile's A rows, then of the W rows (GemmAux)
     char* Ap = smem;
     char* Bp = smem + ABYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -824,20 +1007,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int r = sr0 + h * 32;
         swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
     }
-    auto lstore2 = [&](char* base, int slab, const float4& v, int off) {
+    auto lstore2 = [&](char* base, int slab, const float4& v, float sc, int off) {
         uint2 ph, pl;
-        split2_f16(v, ph, pl);
+        split2_f16(scale4(v, sc), ph, pl);
         *reinterpret_cast<uint2*>(base + (2 * slab) * PLANE + off) = ph;
         *reinterpret_cast<uint2*>(base + (2 * slab + 1) * PLANE + off) = pl;
     };
-    // W tile, once (columns past N: clamped row, computed and never stored)
+    const bool scaled = !aux.noscale;
+    if (!scaled) rsc[tid] = 1.f;
+    // W tile, once (columns past N: clamped row, computed and never stored); each row scaled by its own power of two (GemmAux: the
+    // whole K of a row is in this thread group's registers, so the row maximum costs three DPP steps)
+    {
+        float4 rw[NSL][4];
 #pragma unroll
-    for (int sl = 0; sl < NSL; ++sl)
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int gn = min(n0 + sr0 + h * 32, N - 1);
+                rw[sl][h] = *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + sl * 32 + sk);
+            }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int gn = min(n0 + sr0 + h * 32, N - 1);
-            lstore2(Bp, sl, *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + sl * 32 + sk), swz[h]);
+            float sw = 1.f;
+            if (scaled) {
+                float mw = 0.f, iw;
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) mw = amax4(mw, rw[sl][h]);
+                pow2_scale(max8(mw), sw, iw);
+                if ((tid & 7) == 0) rsc[GM + sr0 + h * 32] = iw;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) lstore2(Bp, sl, rw[sl][h], sw, swz[h]);
         }
+    }
     float bv[2] = {0.f, 0.f};
     const int lr = lane & 31;
 #pragma unroll
@@ -870,11 +1072,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     load_tile(min(tm, ntiles_m - 1));
     for (; tm < ntiles_m; tm += per_n) {
         const int m0 = tm * GM;
-        __syncthreads();                               // previous tile's staging reads are done (and the W planes are written)
+        __syncthreads();                               // previous tile's staging and scale reads are done (and the W planes are written)
 #pragma unroll
-        for (int sl = 0; sl < NSL; ++sl)
+        for (int h = 0; h < 4; ++h) {
+            float sa = 1.f;
+            if (scaled) {
+                float ma = 0.f, ia;
 #pragma unroll
-            for (int h = 0; h < 4; ++h) lstore2(Ap, sl, ra[sl][h], swz[h]);
+                for (int sl = 0; sl < NSL; ++sl) ma = amax4(ma, ra[sl][h]);
+                pow2_scale(max8(ma), sa, ia);
+                if ((tid & 7) == 0) rsc[sr0 + h * 32] = ia;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) lstore2(Ap, sl, ra[sl][h], sa, swz[h]);
+        }
         __syncthreads();
         load_tile(min(tm + per_n, ntiles_m - 1));      // next A tile in flight under the MFMAs and the stores (last iteration: re-reads its own)
 
@@ -917,14 +1128,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const bool full_tile = vec_ok && (m0 + GM <= M) && (n0 + GN <= N);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            // (the row scales are read BEFORE the staging writes below: stg aliases the A planes, not rsc, but the next tile's scales
+            //  are only written after the loop-top barrier)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) + bv[j];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                    const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl) {
+                        const int r = r4 * 4 + rl;
+                        float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs) + bv[j];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+                    }
                 }
+            }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
             store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, nullptr);
@@ -969,7 +1190,9 @@ size_t gemm_scratch_floats(int M, int N, int K) {
 
 int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
                        int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st, bool latency_path = false,
-                       int pieces = 3, const float* mask = nullptr) {
+                       int pieces = 3, const float* mask = nullptr, GemmAux aux = GemmAux()) {
+    static const bool range_off = getenv("LS_GEMM_RANGE") && atoi(getenv("LS_GEMM_RANGE")) == 0;   // A/B: the unscaled round-2 split
+    if (range_off) aux.noscale = 1;
     LS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem (M=%d N=%d K=%d)", M, N, K);
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
@@ -1010,13 +1233,13 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         const size_t slab = (size_t)M * N;
         if (split && pieces == 22)
             hipLaunchKernelGGL(LS_H2_KERNEL, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
-                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr);
+                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr, aux);
         else if (split)
             hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
-                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr);
+                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr, aux);
         else
             hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tm * tn, ns), dim3(256), 0, st, A, lda, W, ldw, nullptr, scratch, N, M, N, K, 0, tn,
-                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr);
+                               a_rows, gNd, gNs, kchunk, slab, (const float*)nullptr, aux);
         LS_LAUNCH_CHECK();
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv((long long)M * (N / 4), 256)), dim3(256), 0, st, scratch, slab, ns, bias, out,
                            ldc, M, N, relu);
@@ -1024,25 +1247,25 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         return LS_OK;
     }
     static const bool persist = !(getenv("LS_GEMM_PERSIST") && atoi(getenv("LS_GEMM_PERSIST")) == 0);   // A/B: K = 32 / 64 on the tiled kernel
-    if (split && pieces == 22 && persist && !mask && (K == 32 || K == 64) && tm >= 16 && !h2_unpipelined) {
+    if (split && pieces == 22 && persist && !mask && (K == 32 || K == 64) && tm >= 16 && !h2_unpipelined && !aux.out_rowmax) {
         int per_n = cdiv(512, tn);   // two resident workgroups per CU (registers), spread evenly over the N-tiles
         if (per_n > tm) per_n = tm;
-#define LS_H2SK(KK, G) hipLaunchKernelGGL((gemm_h2_smallk_kernel<KK, G>), dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, relu, tm, per_n, a_rows, gNd, gNs)
+#define LS_H2SK(KK, G) hipLaunchKernelGGL((gemm_h2_smallk_kernel<KK, G>), dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, relu, tm, per_n, a_rows, gNd, gNs, aux)
         if (K == 32) { if (a_rows) LS_H2SK(32, true); else LS_H2SK(32, false); }
         else { if (a_rows) LS_H2SK(64, true); else LS_H2SK(64, false); }
 #undef LS_H2SK
     } else if (split && pieces == 22)
         hipLaunchKernelGGL(LS_H2_KERNEL, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                           gNd, gNs, K, (size_t)0, mask);
+                           gNd, gNs, K, (size_t)0, mask, aux);
     else if (split && pieces == 2)
         hipLaunchKernelGGL((gemm_f32_kernel<true, 2>), dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                           gNd, gNs, K, (size_t)0, mask);
+                           gNd, gNs, K, (size_t)0, mask, aux);
     else if (split)
         hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                           gNd, gNs, K, (size_t)0, mask);
+                           gNd, gNs, K, (size_t)0, mask, aux);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
-                           gNd, gNs, K, (size_t)0, mask);
+                           gNd, gNs, K, (size_t)0, mask, aux);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -1076,11 +1299,13 @@ bool gemm_vn_supported(int M, int C, int K) {
     return on && h2 && C % 64 == 0 && K % 4 == 0 && K >= 32 && M % 3 == 0;
 }
 int gemm_vn_dispatch(const float* A, int lda, const float* W, int ldw, const float* G, int ldg, float* out, int M, int C, int K, int npts, float oms,
-                     hipStream_t st) {
+                     hipStream_t st, GemmAux aux) {
+    static const bool range_off = getenv("LS_GEMM_RANGE") && atoi(getenv("LS_GEMM_RANGE")) == 0;
+    if (range_off) aux.noscale = 1;
     LS_REQUIRE(gemm_vn_supported(M, C, K) && lda % 4 == 0 && ldw % 4 == 0, "gemm_vn: unsupported shape (M=%d C=%d K=%d)", M, C, K);
     const int tm = cdiv(M, 120), tn = C / 64;
-    if (K % 32 == 0) hipLaunchKernelGGL(gemm_vn_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn);
-    else hipLaunchKernelGGL(gemm_vn_kernel<false>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn);
+    if (K % 32 == 0) hipLaunchKernelGGL(gemm_vn_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn, aux);
+    else hipLaunchKernelGGL(gemm_vn_kernel<false>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn, aux);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

@@ -91,6 +91,15 @@ __device__ __forceinline__ void vn_act(float& y0, float& y1, float& y2, float k0
     y0 -= f * k0; y1 -= f * k1; y2 -= f * k2;
 }
 
+// operand range of the f16-split GEMMs (gemm.hip, "operand range of the f16 split"): optional caller-supplied row maxima
+struct GemmAux {
+    const float* a_rowmax = nullptr;   // [rows of A][a_parts]: max over the parts bounds max|A[row, :]|; indexed by the SOURCE row when a_rows gathers
+    int a_parts = 0;
+    const float* w_rowmax = nullptr;   // [N]
+    float* out_rowmax = nullptr;       // [M][2 * cdiv(N, 128)]: max|out[row, 64-column block]| written by the epilogue (un-split launches only)
+    int noscale = 0;                   // LS_GEMM_RANGE=0: the round-2 arithmetic (no row scaling; |a| < 65504 required), A/B timing
+};
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace ls

@@ -1,0 +1,266 @@
+"""Operand RANGE of the f16-split GEMMs (csrc/gemm.hip "operand range of the f16 split", the fused attention kernel in csrc/edge.hip).
+
+The default GEMM forms an fp32 product from two f16 pieces; f16 covers 2^-14 .. 65504 while the reference's fp32 path has no such
+window: a trained encoder multiplies its head outputs by scale_factor = 64000
+(/root/reference/lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:231-250), so with a scale of ~1 its conv_c outputs sit at
+~1.5e-5, and More_Solver's gradients (/root/reference/lib_more/more_solver.py:137-173, mean-reduced losses over 1024 points) at
+1e-6 .. 1e-8.  Every row of A and W is therefore scaled by its own exact power of two before the split.  These tests put the operands
+where the un-scaled split failed:
+  * GEMM level: exact power-of-two row scalings must change NOTHING but the exponent of the result (bit for bit), tiny / huge /
+    mixed rows keep the fp32-chain error bound against fp64, non-finite rows stay local;
+  * layer and encoder level: the synthetic weights rescaled per layer by exact powers of two so that every layer's output sits at
+    2^-17, 2^-20 or 2^+14, and the tail in the scale_factor regime -- compared with the oracle PER INSTANCE AND PER LAYER at 1e-4;
+  * decoder backward with gradients of the size a mean-reduced loss produces.
+"""
+import numpy as np
+import pytest
+import torch
+
+from livingscenes_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def rows(f):
+    return f.permute(0, 3, 2, 1).contiguous()
+
+
+def _hip(cfg, w, dcfg=None, dw=None):
+    from livingscenes_amd import ops, packing
+    desc, blob = packing.pack_model(w, cfg, dw, dcfg)
+    return ops.HipModel(desc, blob, _dev())
+
+
+# ------------------------------------------------------------------------------------------------ GEMM level
+# shapes chosen to reach every f16-split kernel of gemm.hip: the persistent K = 32 / 64 kernels (M >= 2048), the two-barrier tiled
+# kernel (K <= 64, few tiles), the pipelined kernel (K >= 128; 136 = ragged last slab), split-K (few tiles, long K, workspace)
+SHAPES = [(4096, 256, 32), (4099, 200, 64), (300, 130, 32), (77, 257, 64), (3000, 384, 256), (1000, 200, 136), (192, 1024, 512), (640, 768, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_row_scaling_by_powers_of_two_changes_only_the_exponent(M, N, K):
+    """out(diag(2^a) A, diag(2^w) W) == diag(2^a) out(A, W) diag(2^w) BIT FOR BIT, rows scaled independently over 2^-40 .. 2^+30:
+    a row's arithmetic sees nothing but that row's mantissas."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    ea = torch.randint(-40, 31, (M,), generator=g).double()
+    ew = torch.randint(-25, 21, (N,), generator=g).double()
+    sa, sw = (2.0 ** ea).float(), (2.0 ** ew).float()
+    base = ops.gemm(A.to(_dev()), W.to(_dev())).cpu()
+    out = ops.gemm((A * sa[:, None]).to(_dev()), (W * sw[:, None]).to(_dev())).cpu()
+    want = base.double() * (2.0 ** ea)[:, None] * (2.0 ** ew)[None, :]
+    assert torch.isfinite(out).all()
+    assert torch.equal(out.double(), want)
+
+
+@pytest.mark.parametrize("scale_a,scale_w", [(1e-6, 1e-6), (3e6, 1e-7), (1e-9, 1.0), (7e4, 7e4), (1e-20, 1e12)])
+@pytest.mark.parametrize("M,N,K", [(3000, 260, 64), (3000, 260, 256), (256, 260, 768)])
+def test_gemm_tiny_and_huge_operands_keep_the_fp32_chain_bound(M, N, K, scale_a, scale_w):
+    """All operands far below the f16 normal range (1e-6: the round-2 split lost 1e-5 .. 1e-4 there) or above f16's maximum
+    (65504: the round-2 split returned NaN): componentwise error against fp64 within the fp32 FMA chain's own bound."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(K)
+    A = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, K, generator=g)) * scale_a
+    W = torch.randn(N, K, generator=g) * torch.exp(2 * torch.randn(N, K, generator=g)) * scale_w
+    out = ops.gemm(A.to(_dev()), W.to(_dev())).cpu().double()
+    assert torch.isfinite(out).all()
+    ref = A.double() @ W.double().T
+    unit = (A.double().abs() @ W.double().abs().T) * 2.0 ** -24
+    assert ((out - ref).abs() / unit).max() < 16.0
+
+
+def test_gemm_rows_of_very_different_magnitude_and_nonfinite_rows_stay_local():
+    """Rows spanning 1e-12 .. 1e+8 in ONE call: each row is as accurate as if it were alone (relative to ITS OWN scale); a row
+    holding Inf / NaN makes that row non-finite and leaves every other row bit-identical."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for K in (64, 256):
+        M, N = 2048 + 37, 200
+        A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        mag = 10.0 ** (torch.rand(M, generator=g) * 20 - 12)
+        A = A * mag[:, None]
+        out = ops.gemm(A.to(_dev()), W.to(_dev())).cpu()
+        ref = A.double() @ W.double().T
+        unit = (A.double().abs() @ W.double().abs().T) * 2.0 ** -24
+        assert ((out.double() - ref).abs() / unit).max() < 16.0, K
+        A2 = A.clone()
+        A2[5, 3], A2[700, 0], A2[2050, K - 1] = float("inf"), float("nan"), float("-inf")
+        out2 = ops.gemm(A2.to(_dev()), W.to(_dev())).cpu()
+        bad = torch.zeros(M, dtype=torch.bool)
+        bad[[5, 700, 2050]] = True
+        # (a non-finite row may hold NaN or Inf: only locality is pinned)
+        assert (~torch.isfinite(out2[bad])).any(dim=1).all(), K
+        assert torch.equal(out2[~bad], out[~bad]), K
+
+
+# ------------------------------------------------------------------------------------------------ encoder at other magnitudes
+def _rescaled_weights(cfg, w, x, target_log2):
+    """Multiply the VecLinear weights of every layer by exact powers of two so that the layer's OUTPUT (max |.| of dst_f_i in the
+    oracle's trace) sits at 2^target_log2[i]; the K / Q branches get the same factor as V so that the whole table GEMM of the layer
+    works at that magnitude.  The network is positively homogeneous layer by layer, so one trace of the original weights suffices."""
+    from oracle import net
+    tr = {}
+    net.encoder_forward(w, cfg, x, trace=tr)
+    L, a0, g0 = cfg["num_layers"], cfg["atten_start_layer"], cfg["res_global_start_layer"]
+    w2 = {k: v.clone() for k, v in w.items()}
+    cum = 0
+    for i in range(L):
+        nat = float(np.log2(tr[f"dst_f_{i}"].abs().max().item()))
+        k = int(round(target_log2[i] - nat - cum))
+        cum += k
+        f = 2.0 ** k
+        w2[f"V_list.{i}.lin.weight"] = w[f"V_list.{i}.lin.weight"] * f
+        if i >= a0:
+            w2[f"K_list.{i}.lin.weight"] = w[f"K_list.{i}.lin.weight"] * f
+            w2[f"Q_list.{i}.lin.weight"] = w[f"Q_list.{i}.lin.weight"] * f
+    return w2, cum
+
+
+@pytest.mark.parametrize("target", [-17, -20, 14])
+def test_layer_operators_vs_oracle_at_other_feature_magnitudes(target):
+    """Released widths, every layer's output at 2^target (7.6e-6, 9.5e-7, 16384): each layer operator on the oracle's own tensors,
+    compared PER INSTANCE (1e-4 of that instance's max-norm), then the tail."""
+    from oracle import net
+    cfg = synth.default_encoder_cfg()
+    B, N = 2, 1024
+    x = synth.make_instances(B, N, seed=11, rigid=False)
+    x = (x - x.mean(-1, keepdim=True)) / 1.2
+    w, _ = _rescaled_weights(cfg, synth.make_encoder_weights(cfg, 0), x, [target] * cfg["num_layers"])
+    tr = {}
+    center, scale, z_so3, z_inv = net.encoder_forward(w, cfg, x, trace=tr)
+    m = _hip(cfg, w)
+    d = _dev()
+    L, g0, ds = cfg["num_layers"], cfg["res_global_start_layer"], cfg["down_sample_layers"]
+    for i in range(L):
+        assert abs(np.log2(tr[f"dst_f_{i}"].abs().max().item()) - target) < 1.01, i    # the fixture is where it claims to be
+        src = rows(tr[f"src_f_{i}"]).to(d)
+        if i == 0:
+            src = src.reshape(B, N, 3)
+        rows_i = tr[f"fps_idx_{i}"].to(torch.int32).to(d) if i in ds else None
+        msg = m.edgeconv(i, src, tr[f"knn_idx_{i}"].to(torch.int32).to(d), rows_i)
+        for b in range(B):
+            assert relerr(msg[b], rows(tr[f"msg_f_{i}"])[b]) < TOL, f"edge-conv layer {i} instance {b}"
+        if i >= g0:
+            out = m.vn_lna_global(i, rows(tr[f"msg_f_{i}"]).to(d))
+            for b in range(B):
+                assert relerr(out[b], rows(tr[f"dst_f_{i}"])[b]) < TOL, f"global conv layer {i} instance {b}"
+    hz, hi, hs, ht = m.encoder_tail(rows(tr[f"dst_f_{L - 1}"]).to(d))
+    for b in range(B):
+        assert relerr(hz[b], z_so3[b]) < TOL and relerr(hi[b], z_inv[b]) < TOL, b
+        assert relerr(hs[b], scale[b]) < TOL and relerr(ht[b], center.reshape(B, 3)[b]) < TOL, b
+
+
+@pytest.mark.parametrize("target", [-17, -20, 14, "checkpoint"])
+def test_encoder_forward_vs_oracle_at_other_feature_magnitudes(target):
+    """The whole encoder with every layer at 2^target, and in the regime scale_factor = 64000 implies for a trained checkpoint
+    ("checkpoint": layers at O(1), conv_c scaled so that mean |x_c| = 1.5e-5, i.e. pred_scale ~ 1): codes per instance within 1e-4,
+    FPS / layer-0 k-NN bit-exact, deeper graphs identical up to near-ties.  Power-of-two weight scalings commute with every
+    rounding of the network, so the graphs must ALSO equal those of the un-scaled weights bit for bit."""
+    from oracle import net
+    cfg = synth.default_encoder_cfg()
+    B, N = 3, 1024
+    w0 = synth.make_encoder_weights(cfg, 0)
+    x = synth.make_instances(B, N, seed=5, rigid=False)
+    x = (x - x.mean(-1, keepdim=True)) / 1.1
+    if target == "checkpoint":
+        tr0 = {}
+        _, scale0, _, _ = net.encoder_forward(w0, cfg, x, trace=tr0)
+        k = int(round(np.log2(1.0 / scale0.mean().item())))          # pred_scale = 64000 * mean|x_c|  ->  ~1
+        w = {kk: v.clone() for kk, v in w0.items()}
+        w["conv_c.lin.weight"] = w0["conv_c.lin.weight"] * 2.0 ** k
+    else:
+        w, _ = _rescaled_weights(cfg, w0, x, [target] * cfg["num_layers"])
+    tr = {}
+    center, scale, z_so3, z_inv = net.encoder_forward(w, cfg, x, trace=tr)
+    if target == "checkpoint":
+        assert 0.4 < scale.mean().item() < 2.5
+    m = _hip(cfg, w)
+    hz, hi, hs, ht, knn_l, fps_l = m.encode(x.to(_dev()), pre_normalised=True, trace=True)
+    z0 = _hip(cfg, w0).encode(x.to(_dev()), pre_normalised=True, trace=True)
+    for i in range(cfg["num_layers"]):
+        assert torch.equal(knn_l[i], z0[4][i]), f"layer {i}: the graph changed under a power-of-two weight scaling"
+    assert torch.equal(hz, z0[0]) and torch.equal(hi, z0[1])            # cevn outputs: scale-free
+    assert np.array_equal(knn_l[0].cpu().numpy(), tr["knn_idx_0"].numpy().astype(np.int32))
+    for j, i in enumerate(cfg["down_sample_layers"]):
+        assert np.array_equal(fps_l[j].cpu().numpy(), tr[f"fps_idx_{i}"].numpy().astype(np.int32))
+    flipped = any(not np.array_equal(knn_l[i].cpu().numpy(), tr[f"knn_idx_{i}"].numpy()) for i in range(1, cfg["num_layers"]))
+    if flipped:   # near-tie somewhere: judge the codes on the device's graph (as test_encoder_forward_vs_oracle does)
+        for i in range(1, cfg["num_layers"]):
+            assert (knn_l[i].cpu().numpy() == tr[f"knn_idx_{i}"].numpy()).mean() > 0.995
+        graph = {i: knn_l[i].cpu() for i in range(1, cfg["num_layers"])}
+        center, scale, z_so3, z_inv = net.encoder_forward(w, cfg, x, graph=graph)
+    for b in range(B):
+        assert relerr(hz[b], z_so3[b]) < TOL and relerr(hi[b], z_inv[b]) < TOL, b
+        assert relerr(hs[b], scale[b]) < TOL and relerr(ht[b], center.reshape(B, 3)[b]) < TOL, b
+
+
+# ------------------------------------------------------------------------------------------------ decoder
+@pytest.mark.parametrize("log2_gscale", [-17, -27, 18])
+def test_sdf_backward_with_small_and_large_upstream_gradients(log2_gscale):
+    """ls_sdf_backward with grad_sdf of the size a mean-reduced loss over 1024 points hands it (2^-17 = 7.6e-6, 2^-27 = 7.5e-9;
+    More_Solver, more_solver.py:137-173): dz sits far below the f16 normal range through the whole backward chain (the round-2
+    split lost 1e-5 .. 1e-3 there).  The backward pass is linear in grad_sdf and powers of two commute with every rounding, so the
+    gradients must equal 2^k times the gradients of the O(1) problem BIT FOR BIT; the O(1) problem itself is held to 1e-4 of the
+    max-norm against fp64 autograd through the oracle (grad_s, a sum of 1024 terms of either sign, against the sum of their
+    magnitudes)."""
+    from livingscenes_amd import ops, packing
+    from oracle import net
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    ew, dw = synth.make_encoder_weights(ecfg, 3), synth.make_decoder_weights(dcfg, 3)
+    desc, blob = packing.pack_model(ew, ecfg, dw, dcfg)
+    m = ops.HipModel(desc, blob, _dev())
+    B, M = 2, 1024
+    g = torch.Generator().manual_seed(77)
+    L = dcfg["latent_size"]
+    code = {"z_so3": torch.randn(B, L, 3, generator=g) * 0.05, "z_inv": torch.randn(B, L, generator=g) * 0.05,
+            "s": torch.rand(B, generator=g) * 0.5 + 0.75, "t": torch.randn(B, 1, 3, generator=g) * 0.1}
+    q = synth.make_queries(B, M, seed=5) * code["s"][:, None, None] + code["t"]
+    gsdf = torch.randn(B, M, generator=g)
+    leaves = {k: v.clone().double().requires_grad_(True) for k, v in code.items()}
+    ql = q.clone().double().requires_grad_(True)
+    sdf_ref = net.field_query_with_grad({k: v.double() for k, v in dw.items()}, dcfg, ql, leaves)   # fp64 autograd: the yardstick
+    (sdf_ref * gsdf.double()).sum().backward()
+    dev = _dev()
+    sdf, saved = m.sdf_decode_train(q.to(dev), code["z_so3"].to(dev), code["z_inv"].to(dev), code["s"].to(dev), code["t"].to(dev))
+    base = m.sdf_backward(saved, gsdf.to(dev))
+    gq, gso3, ginv, gs, gt = base
+    assert relerr(gso3, leaves["z_so3"].grad) < TOL
+    assert relerr(ginv, leaves["z_inv"].grad) < TOL
+    assert relerr(gt, leaves["t"].grad.reshape(B, 3)) < TOL
+    assert relerr(gq, ql.grad) < TOL
+    # grad_s[b] = -sum_m <dq_m, q_m> / s: judged against the magnitude of what is summed
+    qn = (ql.detach() - leaves["t"].detach()) / leaves["s"].detach()[:, None, None]
+    terms = ((ql.grad * leaves["s"].detach()[:, None, None]) * qn).sum(-1).abs().sum(-1) / leaves["s"].detach()
+    assert ((gs.cpu().double() - leaves["s"].grad).abs() / terms).max() < TOL
+    f = 2.0 ** log2_gscale
+    sdf2, saved2 = m.sdf_decode_train(q.to(dev), code["z_so3"].to(dev), code["z_inv"].to(dev), code["s"].to(dev), code["t"].to(dev))
+    scaled = m.sdf_backward(saved2, (gsdf * f).to(dev))
+    for name, a, b_ in zip(("query", "z_so3", "z_inv", "s", "t"), scaled, base):
+        assert torch.equal(a, b_ * f), name
+
+
+def test_decoder_forward_on_activations_outside_the_f16_range():
+    """DeepSDF_Decoder.forward / ls_gemm_f32 with un-normalised inputs (|a| up to 1e6, e.g. millimetre-scale features): finite and
+    within tolerance -- the round-2 split returned NaN here."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(5000, 512, generator=g) * 1e6
+    W = torch.randn(768, 512, generator=g) * 0.03
+    b = torch.randn(768, generator=g) * 1e6
+    out = ops.gemm(A.to(_dev()), W.to(_dev()), b.to(_dev()), relu=True).cpu()
+    ref = (A.double() @ W.double().T + b.double()).clamp(min=0)
+    assert torch.isfinite(out).all() and relerr(out, ref) < 2e-6
