@@ -102,14 +102,34 @@ int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, un
  * matrix cores as TWO-PIECE splits with a scaled residual (a = h + l/1024, h = f16(a), l = f16((a - h) * 1024): 2^-22 |a|; three
  * v_mfma_f32_32x32x16_f16 per 16 k, main and cross terms in separate fp32 accumulators): measured against fp64 this is as accurate
  * as an fp32 FMA chain (the fp32 accumulation error dominates both) and exact on integer-valued operands below 2^22.
- * PRECONDITION |a|, |w| < 65 504 (f16 range).  LS_GEMM_MODE=bf16x3 in the environment selects three-piece bf16 splits instead
- * (six v_mfma_f32_32x32x16_bf16 per 16 k, any fp32 range, ~1.5x the time); LS_GEMM_BF16X3=0 the fp32-MFMA kernel
- * (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains).  A row's result does not depend on the other rows of the call.
+ * RANGE: any finite fp32 operands.  Every row of A and every row of W is multiplied by its own exact power of two before the split
+ * (row maximum -> [2^14, 2^15)) and the accumulators by the inverse afterwards, so the f16 window follows each row: elements down to
+ * 2^-27 of their row's maximum keep the full 22 bits, the absolute floor is 2^-49 of the row maximum, nothing overflows; rows that hold
+ * Inf / NaN give non-finite results in that row only.  A row's result depends on that row of A and on W only -- not on the other rows of
+ * the call -- as long as the launch does not split K (split-K: M * N < 192 tiles of 128 x 128 and K >= 128 and a workspace is given;
+ * it changes the fp32 summation order with M; ls_gemm_f32_ex with workspace = NULL never splits).
+ * LS_GEMM_MODE=bf16x3 in the environment selects three-piece bf16 splits instead (six v_mfma_f32_32x32x16_bf16 per 16 k, ~1.5x the
+ * time); LS_GEMM_BF16X3=0 the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains); LS_GEMM_RANGE=0 the un-scaled
+ * round-2 split (A/B timing only: |a|, |w| < 65 504 required, small operands lose bits).
  * K % 4 == 0, lda/ldw/ldc % 4 == 0; bias may be NULL; relu in {0,1}.  workspace: ls_gemm_workspace_bytes(M, N, K) bytes
  * (split-K slabs of under-filled long-K problems; 0 -> may be NULL). */
 size_t ls_gemm_workspace_bytes(int M, int N, int K);
 int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M,
                 int N, int K, int relu, void* workspace, size_t workspace_bytes, void* stream);
+/* The same GEMM for callers that chain several of them (an MLP): the row maxima the range scaling needs can be handed over instead
+ * of being re-derived by a pre-pass over the operands (which costs ~30 % at K >= 128):
+ *   a_rowmax [M][a_parts] or NULL: max over the parts >= max|A[row, :]| (any upper bound serves; a factor of two of slack costs one
+ *                                  bit at the bottom of the 27-binade window);   w_rowmax [N] or NULL: likewise for W (ls_rowmax_f32 once
+ *                                  per weight matrix);
+ *   out_rowmax [M][ls_gemm_rowmax_parts(N)] or NULL: receives max|out[row, 64-column block]| -- the next layer's a_rowmax.  Not
+ *                                  written by a launch that splits K: pass workspace = NULL when chaining.
+ * Results are bit-identical to ls_gemm_f32 whenever the maxima handed over are the exact ones. */
+int ls_gemm_rowmax_parts(int N);
+int ls_gemm_f32_ex(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
+                   int relu, const float* a_rowmax, int a_parts, const float* w_rowmax, float* out_rowmax, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* out[r] = max_k |X[r * ld + k]|, k < K  (X [rows, K]) */
+int ls_rowmax_f32(const float* X, int rows, int K, int ld, float* out, void* stream);
 
 /* Shape_Prior.encode prologue, model_utils.py:166-177: centroid, scale_0 = mean of the 5 largest
  * entries of the N x N distance matrix, normalised cloud.

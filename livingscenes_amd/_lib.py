@@ -87,6 +87,9 @@ SIGNATURES = {
     "ls_fps_f32": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _SZ, _P]),
     "ls_gemm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "ls_gemm_f32": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "ls_gemm_rowmax_parts": (_I, [_I]),
+    "ls_gemm_f32_ex": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _SZ, _P]),
+    "ls_rowmax_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "ls_encode_prologue_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "ls_cosine_scores_workspace_bytes": (_SZ, [_I, _I]),
     "ls_cosine_scores_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),

@@ -251,6 +251,19 @@ __device__ __forceinline__ float group_sum(float v) {  // all-reduce over aligne
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_maxf(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
+template <int LPP>
+__device__ __forceinline__ float group_max(float v) {  // all-reduce (max) over aligned groups of LPP lanes
+    v = dpp_maxf<0x140>(dpp_maxf<0x141>(dpp_maxf<0x4E>(dpp_maxf<0xB1>(v))));
+    if constexpr (LPP >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if constexpr (LPP >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float amax_f4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 struct F43 { float4 x, y, z; };  // one xyz triple for four channels
 __device__ __forceinline__ F43 ld43(const float* p, int ldt) {
     F43 r;
@@ -282,7 +295,9 @@ template <int LPP, int NCH>
 __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
                                                            int NQ, int q_via_rows, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
-                                                           float oms, float inv_sqrt_dk, float* __restrict__ out, int total) {
+                                                           float oms, float inv_sqrt_dk, float* __restrict__ out, int total,
+                                                           float* __restrict__ rowmax) {
+    // rowmax (nullable) [total * 3]: max|out[row, :]| -- the operand range of the GEMM that reads `out` (gemm.hip, GemmAux)
     constexpr int PPW = 64 / LPP;
     // lane-private LDS slots ([neighbour][thread]: conflict-free without padding -> 32 KB per chunk pair, five workgroups per CU):
     // head scores per chunk and |k|^2 per neighbour.  Keeping these arrays out of VGPRs lets the neighbour loops stay rolled
@@ -360,6 +375,7 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     }
 
     // ---- C: V branch, weighted sum
+    float rmx = 0.f, rmy = 0.f, rmz = 0.f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = (ch * LPP + ll) * 4;
@@ -377,13 +393,21 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
             acc.y.x += w * y.y.x; acc.y.y += w * y.y.y; acc.y.z += w * y.y.z; acc.y.w += w * y.y.w;
             acc.z.x += w * y.z.x; acc.z.y += w * y.z.y; acc.z.z += w * y.z.z; acc.z.w += w * y.z.w;
         }
+        const float inv = 1.0f / sum[ch];
+        const float4 ox = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
+        const float4 oy = make_float4(acc.y.x * inv, acc.y.y * inv, acc.y.z * inv, acc.y.w * inv);
+        const float4 oz = make_float4(acc.z.x * inv, acc.z.y * inv, acc.z.z * inv, acc.z.w * inv);
         if (live) {
-            const float inv = 1.0f / sum[ch];
             float* op = out + (size_t)pid * 3 * Co + c4;
-            *reinterpret_cast<float4*>(op) = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
-            *reinterpret_cast<float4*>(op + Co) = make_float4(acc.y.x * inv, acc.y.y * inv, acc.y.z * inv, acc.y.w * inv);
-            *reinterpret_cast<float4*>(op + 2 * Co) = make_float4(acc.z.x * inv, acc.z.y * inv, acc.z.z * inv, acc.z.w * inv);
+            *reinterpret_cast<float4*>(op) = ox;
+            *reinterpret_cast<float4*>(op + Co) = oy;
+            *reinterpret_cast<float4*>(op + 2 * Co) = oz;
         }
+        rmx = fmaxf(rmx, amax_f4(ox)); rmy = fmaxf(rmy, amax_f4(oy)); rmz = fmaxf(rmz, amax_f4(oz));
+    }
+    if (rowmax) {   // wave-uniform
+        rmx = group_max<LPP>(rmx); rmy = group_max<LPP>(rmy); rmz = group_max<LPP>(rmz);
+        if (live && ll == 0) { float* rp = rowmax + (size_t)pid * 3; rp[0] = rmx; rp[1] = rmy; rp[2] = rmz; }
     }
 }
 
@@ -465,7 +489,7 @@ template <int LPP, int CIN>
 __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
                                                            const uint4* __restrict__ Wp, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, float oms, float inv_sqrt_dk,
-                                                           float* __restrict__ out, int total) {
+                                                           float* __restrict__ out, int total, float* __restrict__ rowmax) {
     constexpr int PPW = 64 / LPP, PW = 4 * PPW, ROWS = 3 * PW, MT = (ROWS + 31) / 32, Co = LPP * 4, SC = 2 * Co, NT = SC / 32, SLD = SC + 4,
                   KS = CIN / 16, ASTR = CIN * 2 + 16;   // A plane row stride in bytes (+16: conflict-free 16-byte fragment reads)
     static_assert(MT * NT == 8, "two output tiles per wave");
@@ -607,12 +631,19 @@ __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restri
             acc.y.x += w * y.y.x; acc.y.y += w * y.y.y; acc.y.z += w * y.y.z; acc.y.w += w * y.y.w;
             acc.z.x += w * y.z.x; acc.z.y += w * y.z.y; acc.z.z += w * y.z.z; acc.z.w += w * y.z.w;
         }
+        const float inv = 1.0f / sum;
+        const float4 ox = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
+        const float4 oy = make_float4(acc.y.x * inv, acc.y.y * inv, acc.y.z * inv, acc.y.w * inv);
+        const float4 oz = make_float4(acc.z.x * inv, acc.z.y * inv, acc.z.z * inv, acc.z.w * inv);
         if (live) {
-            const float inv = 1.0f / sum;
             float* op = out + (size_t)pid * 3 * Co + c4;
-            *reinterpret_cast<float4*>(op) = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
-            *reinterpret_cast<float4*>(op + Co) = make_float4(acc.y.x * inv, acc.y.y * inv, acc.y.z * inv, acc.y.w * inv);
-            *reinterpret_cast<float4*>(op + 2 * Co) = make_float4(acc.z.x * inv, acc.z.y * inv, acc.z.z * inv, acc.z.w * inv);
+            *reinterpret_cast<float4*>(op) = ox;
+            *reinterpret_cast<float4*>(op + Co) = oy;
+            *reinterpret_cast<float4*>(op + 2 * Co) = oz;
+        }
+        if (rowmax) {   // wave-uniform: max|out[row, :]| for the GEMM that reads `out` (gemm.hip, GemmAux)
+            const float rmx = group_max<LPP>(amax_f4(ox)), rmy = group_max<LPP>(amax_f4(oy)), rmz = group_max<LPP>(amax_f4(oz));
+            if (live && ll == 0) { float* rp = rowmax + (size_t)pid * 3; rp[0] = rmx; rp[1] = rmy; rp[2] = rmz; }
         }
     }
 }
@@ -620,11 +651,11 @@ __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restri
 // can this layer shape take the fused kernel?
 bool edge_attn_fq_supported(int Co, int Cin) { return (Co == 64 && (Cin == 32 || Cin == 64)) || (Co == 128 && Cin == 64); }
 int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, const void* wq_planes, const int32_t* knn, const int32_t* dst_rows, int B,
-                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st) {
+                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax) {
     LS_REQUIRE(head_c == 16 && edge_attn_fq_supported(Co, Cin) && ldt % 4 == 0 && wq_planes, "edge_attn_fq: unsupported shape (Co=%d Cin=%d ldt=%d)", Co, Cin, ldt);
     const float isd = 1.0f / sqrtf(3.0f * head_c), oms = 1.0f - neg_slope;
     const int total = B * Nd;
-#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total)
+#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax)
     if (Co == 64 && Cin == 32) LS_FQ(16, 32);
     else if (Co == 64) LS_FQ(16, 64);
     else LS_FQ(32, 64);
@@ -636,12 +667,12 @@ int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, cons
 template <int LPP, int NCH>
 static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
                           const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float isd, float* out,
-                          hipStream_t st) {
+                          hipStream_t st, float* rowmax) {
     const int total = B * Nd, ppb = 4 * (64 / LPP);
     static const int lds_pad = getenv("LS_EDGE_LDS_PAD") ? atoi(getenv("LS_EDGE_LDS_PAD")) : 0;   // A/B: unused dynamic LDS = fewer workgroups per CU
     if (lds_pad > 30000) (void)hipFuncSetAttribute((const void*)edge_attn_v4_kernel<LPP, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
     hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), lds_pad, st, T, ldt, Tq, ldq, NQ, qvr, knn,
-                       dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total);
+                       dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total, rowmax);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -664,16 +695,19 @@ int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, 
     return LS_OK;
 }
 
+// does edge_attn_launch write the row maxima of its output for this shape? (the float4-lane kernels do, the generic one does not)
+bool edge_attn_emits_rowmax(int Co, int ldt, int ldq) { return ldt % 4 == 0 && ldq % 4 == 0 && (Co == 64 || Co == 128 || Co == 256 || Co == 512); }
 int edge_attn_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
                      const int32_t* dst_rows, int B, int Nd, int Ns, int Co, int head_c, float neg_slope, float* out,
-                     hipStream_t st) {
+                     hipStream_t st, float* rowmax) {
+    LS_REQUIRE(!rowmax || edge_attn_emits_rowmax(Co, ldt, ldq), "edge_attn: no row maxima from the generic kernel (Co=%d)", Co);
     LS_REQUIRE(head_c == 16 && Co % 16 == 0, "edge_attn: head width must be 16 and divide Co (head_c=%d Co=%d)", head_c, Co);
     const float isd = 1.0f / sqrtf(3.0f * head_c);
     if (ldt % 4 == 0 && ldq % 4 == 0) {
-        if (Co == 64) return launch_attn_v4<16, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
-        if (Co == 128) return launch_attn_v4<32, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
-        if (Co == 256) return launch_attn_v4<64, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
-        if (Co == 512) return launch_attn_v4<64, 2>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st);
+        if (Co == 64) return launch_attn_v4<16, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
+        if (Co == 128) return launch_attn_v4<32, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
+        if (Co == 256) return launch_attn_v4<64, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
+        if (Co == 512) return launch_attn_v4<64, 2>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
     }
     const int total = B * Nd;
     const size_t smem = (size_t)4 * (3 * Co + 2 * (Co / 16) * EK) * sizeof(float);

@@ -105,7 +105,19 @@ __device__ __forceinline__ float dpp_fmax(float v) {
 // max over aligned groups of 8 lanes (the 8 staging threads of one operand row) / 16 lanes, in every lane of the group
 __device__ __forceinline__ float max8(float v) { return dpp_fmax<0x141>(dpp_fmax<0x4E>(dpp_fmax<0xB1>(v))); }
 __device__ __forceinline__ float max16(float v) { return dpp_fmax<0x140>(max8(v)); }
-__device__ __forceinline__ float4 scale4(const float4& v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+// split of s * v (s: the row's power of two); the multiply is spelled as packed fp32 (v_pk_mul_f32: the file is built without SLP vectorisation)
+template <int WHICH>   // 0 = A operand, 1 = W operand (dev timing variants below)
+__device__ __forceinline__ void split2_f16s(const float4& v, float s, uint2& h, uint2& l) {
+#if defined(LS_VAR_NO_AMUL)
+    if constexpr (WHICH == 0) { split2_f16(v, h, l); return; }
+#endif
+#if defined(LS_VAR_NO_WMUL)
+    if constexpr (WHICH == 1) { split2_f16(v, h, l); return; }
+#endif
+    const f32x2_t sv = {s, s};
+    split2_f16_pair(f32x2_t{v.x, v.y} * sv, h.x, l.x);
+    split2_f16_pair(f32x2_t{v.z, v.w} * sv, h.y, l.y);
+}
 
 constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 
@@ -119,6 +131,9 @@ constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 __device__ __forceinline__ void store_half_tile(const float* stg, float* __restrict__ out, int ldc, int M, int N, int gm0, int gn0,
                                                 int lane, bool full_tile, bool vec_ok, const float* __restrict__ mask,
                                                 float* __restrict__ rowmax = nullptr, int rm_parts = 0, int rm_part = 0) {
+#if defined(LS_VAR_NO_EMIT)
+    rowmax = nullptr;
+#endif
     if (full_tile) {
         float4 v[8];
 #pragma unroll
@@ -260,10 +275,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 const int swz = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
                 uint2 p1, p2, p3;
                 if constexpr (H2) {
-                    split2_f16(scale4(ra[h], sa[h]), p1, p2);
+                    split2_f16s<0>(ra[h], sa[h], p1, p2);
                     *reinterpret_cast<uint2*>(Ap + swz) = p1;
                     *reinterpret_cast<uint2*>(Ap + PLANE + swz) = p2;
-                    split2_f16(scale4(rb[h], sw[h]), p1, p2);
+                    split2_f16s<1>(rb[h], sw[h], p1, p2);
                     *reinterpret_cast<uint2*>(Bp + swz) = p1;
                     *reinterpret_cast<uint2*>(Bp + PLANE + swz) = p2;
                     continue;
@@ -512,9 +527,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int r = sr0 + h * 32;
         swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
     }
-    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {
+    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {   // A rows
         uint2 ph, pl;
-        split2_f16(scale4(v, sc), ph, pl);
+        split2_f16s<0>(v, sc, ph, pl);
+        *reinterpret_cast<uint2*>(plane_hi + off) = ph;
+        *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
+    };
+    auto lstore2w = [&](char* plane_hi, const float4& v, float sc, int off) {   // W rows
+        uint2 ph, pl;
+        split2_f16s<1>(v, sc, ph, pl);
         *reinterpret_cast<uint2*>(plane_hi + off) = ph;
         *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
     };
@@ -566,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 
     gload_a(kbeg); gload_b(kbeg);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], sw[h], swz[h]); }
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); lstore2w(smem + 2 * PLANE, rb[h], sw[h], swz[h]); }
     gload_a(kbeg + 32); gload_b(kbeg + 32);
     __syncthreads();
 
@@ -593,13 +614,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2(Bn, rb[0], sw[0], swz[0]); lstore2(Bn, rb[1], sw[1], swz[1]); }
+            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2w(Bn, rb[0], sw[0], swz[0]); lstore2w(Bn, rb[1], sw[1], swz[1]); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
             if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
-            else { lstore2(Bn, rb[2], sw[2], swz[2]); lstore2(Bn, rb[3], sw[3], swz[3]); gload_b(k0 + 64); }
+            else { lstore2w(Bn, rb[2], sw[2], swz[2]); lstore2w(Bn, rb[3], sw[3], swz[3]); gload_b(k0 + 64); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -714,9 +735,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int r = sr0 + h * 32;
         swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
     }
-    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {
+    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {   // A rows
         uint2 ph, pl;
-        split2_f16(scale4(v, sc), ph, pl);
+        split2_f16s<0>(v, sc, ph, pl);
+        *reinterpret_cast<uint2*>(plane_hi + off) = ph;
+        *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
+    };
+    auto lstore2w = [&](char* plane_hi, const float4& v, float sc, int off) {   // W rows
+        uint2 ph, pl;
+        split2_f16s<1>(v, sc, ph, pl);
         *reinterpret_cast<uint2*>(plane_hi + off) = ph;
         *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
     };
@@ -768,7 +795,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 
     gload_a(kbeg); gload_b(kbeg);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); lstore2(smem + 2 * PLANE, rb[h], sw[h], swz[h]); }
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); lstore2w(smem + 2 * PLANE, rb[h], sw[h], swz[h]); }
     gload_a(kbeg + 32); gload_b(kbeg + 32);
     __syncthreads();
 
@@ -795,13 +822,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2(Bn, rb[0], sw[0], swz[0]); lstore2(Bn, rb[1], sw[1], swz[1]); }
+            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2w(Bn, rb[0], sw[0], swz[0]); lstore2w(Bn, rb[1], sw[1], swz[1]); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
             if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
-            else { lstore2(Bn, rb[2], sw[2], swz[2]); lstore2(Bn, rb[3], sw[3], swz[3]); gload_b(k0 + 64); }
+            else { lstore2w(Bn, rb[2], sw[2], swz[2]); lstore2w(Bn, rb[3], sw[3], swz[3]); gload_b(k0 + 64); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -836,15 +863,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int it = 0; it < 5; ++it) {
             const int item = it * 64 + lane, pl = item >> 5, c = item & 31;   // point 0..9 of the tile, channel
             const int grow = row0 + 3 * pl;
+            float y0 = 0.f, y1 = 0.f, y2 = 0.f;
             if (grow < M) {
                 const int ch = c0 + 32 * wn + c;
                 const float* g = G + (size_t)((grow / 3) / npts) * 3 * ldg + 2 * C + ch;
                 const float* sp = stg + 3 * pl * 68 + c;
-                float y0 = sp[0] + g[0], y1 = sp[68] + g[ldg], y2 = sp[136] + g[2 * ldg];
+                y0 = sp[0] + g[0]; y1 = sp[68] + g[ldg]; y2 = sp[136] + g[2 * ldg];
                 const float k0 = sp[32] + g[C], k1 = sp[68 + 32] + g[ldg + C], k2 = sp[136 + 32] + g[2 * ldg + C];
                 vn_act(y0, y1, y2, k0, k1, k2, oms);
                 float* op = out + (size_t)grow * C + ch;
                 op[0] = y0; op[C] = y1; op[2 * C] = y2;
+            }
+            if (aux.out_rowmax) {   // wave-uniform; [M][C / 32]: max|out[row, this wave's 32 channels]| (the half-wave of a point)
+                float m0_ = max16(fabsf(y0)), m1_ = max16(fabsf(y1)), m2_ = max16(fabsf(y2));
+                m0_ = fmaxf(m0_, __shfl_xor(m0_, 16, 64)); m1_ = fmaxf(m1_, __shfl_xor(m1_, 16, 64)); m2_ = fmaxf(m2_, __shfl_xor(m2_, 16, 64));
+                if (c == 0 && grow < M) {
+                    float* rp = aux.out_rowmax + (size_t)grow * (2 * ntiles_n) + 2 * tn + wn;
+                    rp[0] = m0_; rp[2 * ntiles_n] = m1_; rp[4 * ntiles_n] = m2_;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1009,7 +1045,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     auto lstore2 = [&](char* base, int slab, const float4& v, float sc, int off) {
         uint2 ph, pl;
-        split2_f16(scale4(v, sc), ph, pl);
+        split2_f16s<0>(v, sc, ph, pl);
         *reinterpret_cast<uint2*>(base + (2 * slab) * PLANE + off) = ph;
         *reinterpret_cast<uint2*>(base + (2 * slab + 1) * PLANE + off) = pl;
     };
@@ -1173,6 +1209,22 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     op[0] = a.x; op[1] = a.y; op[2] = a.z; op[3] = a.w;
 }
 
+// out[r] = max_k |W[r][k]| (weights: once per model, ls_model_create) -- the w_rowmax of GemmAux
+__global__ __launch_bounds__(256) void gemm_rowmax_kernel(const float* __restrict__ W, int rows, int K, int ldw, float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float m = 0.f;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(W[(size_t)r * ldw + k]));
+    m = wave_max(m);
+    if (lane == 0) out[r] = m;
+}
+int gemm_rowmax_launch(const float* W, int rows, int K, int ldw, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_rowmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, W, rows, K, ldw, out);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int gemm_rowmax_parts(int N) { return 2 * cdiv(N, GN); }   // parts per row of GemmAux::out_rowmax for an N-column output
+
 // Under-filled grids with a long K loop (the per-instance "mean" rows of the residual global conv: M = 3B rows against
 // K = C up to 512; conv_c) are pure latency: 32 workgroups x 16 dependent k-steps = 44 us for 0.2 GFLOP.  They are split
 // along K into slices written as partial slabs and combined by a second launch.
@@ -1225,7 +1277,7 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
 #define LS_H2_KERNEL ((h2_unpipelined || K <= 64) ? gemm_f32_kernel<true, 22> : (K % 32 == 0 ? gemm_h2_kernel<true> : gemm_h2_kernel<false>))
     static const int default_pieces = (getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) ? 3 : 22;
     if (pieces == 3) pieces = default_pieces;
-    const int nsplit = (scratch && !mask) ? gemm_choose_splits(M, N, K) : 1;
+    const int nsplit = (scratch && !mask) ? gemm_choose_splits(M, N, K) : 1;   // (a split launch writes no out_rowmax: callers check gemm_scratch_floats)
     if (nsplit > 1) {
         const int kq = split ? 32 : GK;
         int kchunk = cdiv(cdiv(K, nsplit), kq) * kq;
@@ -1270,16 +1322,16 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     return LS_OK;
 }
 int gemm_dispatch_gather(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
-                         int K, int relu, const int32_t* a_rows, int gNd, int gNs, hipStream_t st) {
-    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, a_rows, gNd, gNs, nullptr, st);
+                         int K, int relu, const int32_t* a_rows, int gNd, int gNs, hipStream_t st, GemmAux aux) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, a_rows, gNd, gNs, nullptr, st, false, 3, nullptr, aux);
 }
 int gemm_dispatch(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
-                  int K, int relu, hipStream_t st) {
-    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, nullptr, st);
+                  int K, int relu, hipStream_t st, GemmAux aux) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, nullptr, st, false, 3, nullptr, aux);
 }
 int gemm_dispatch_ws(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
-                     int K, int relu, float* scratch, hipStream_t st) {
-    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, scratch, st);
+                     int K, int relu, float* scratch, hipStream_t st, GemmAux aux) {
+    return gemm_dispatch_full(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, nullptr, 0, 0, scratch, st, false, 3, nullptr, aux);
 }
 // opt-in two-piece products (decoder throughput mode); never splits K
 int gemm_dispatch_fast2(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N,
@@ -1288,8 +1340,8 @@ int gemm_dispatch_fast2(const float* A, int lda, const float* W, int ldw, const 
 }
 // out = (mask > 0) ? A W^T : 0 with `mask` laid out like `out` (never splits K); pieces = 3 | 2
 int gemm_dispatch_masked(const float* A, int lda, const float* W, int ldw, float* out, int ldc, int M, int N, int K, const float* mask, int pieces,
-                         hipStream_t st) {
-    return gemm_dispatch_full(A, lda, W, ldw, nullptr, out, ldc, M, N, K, 0, nullptr, 0, 0, nullptr, st, false, pieces, mask);
+                         hipStream_t st, GemmAux aux) {
+    return gemm_dispatch_full(A, lda, W, ldw, nullptr, out, ldc, M, N, K, 0, nullptr, 0, 0, nullptr, st, false, pieces, mask, aux);
 }
 // out [M = B * npts * 3, C] = VN-act(A W[0:C]^T + G lin part, A W[C:2C]^T + G dir part): see gemm_vn_kernel.  false = shape / mode not
 // supported (the caller runs GEMM + vn_act_rows instead)

@@ -61,6 +61,20 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// wave maximum on the DPP network (no LDS crossbar): the result is valid in LANE 63 only
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_fmax_rm(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xF, false)));
+}
+__device__ __forceinline__ float wave_max_lane63(float v) {
+    v = dpp_fmax_rm<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_fmax_rm<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_fmax_rm<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_fmax_rm<0x140, 0xF>(v);   // row_mirror
+    v = dpp_fmax_rm<0x142, 0xA>(v);   // row_bcast15 -> rows 1, 3
+    v = dpp_fmax_rm<0x143, 0xC>(v);   // row_bcast31 -> rows 2, 3
+    return v;
+}
 // reductions inside aligned groups of 16 lanes (one attention head = 16 channels = one DPP row)
 __device__ __forceinline__ float row16_sum(float v) {
 #pragma unroll

@@ -26,21 +26,25 @@ int knn_compose_hints_launch(const int32_t* prev_knn, const int32_t* prev_rows, 
 bool knn_would_sweep(int C, int Ns, unsigned flags);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, void*, size_t, hipStream_t);
 size_t fps_scratch_bytes_per_cloud(int N);
-int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
+int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t, GemmAux aux = GemmAux());
+int gemm_rowmax_launch(const float* W, int rows, int K, int ldw, float* out, hipStream_t st);
+int gemm_rowmax_parts(int N);
+int sdf_affine_rowmax_parts(int out_dim);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
 int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
-int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
+int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
+bool edge_attn_emits_rowmax(int Co, int ldt, int ldq);
 bool edge_attn_fq_supported(int Co, int Cin);
-int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t);
+int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
 size_t edge_wq_planes_bytes(int Co, int Cin);
 int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipStream_t st);
-int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t);
-int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
+int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t, GemmAux aux = GemmAux());
+int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 bool gemm_vn_supported(int M, int C, int K);
 int gemm_vn_dispatch(const float*, int, const float*, int, const float*, int, float*, int, int, int, int, float, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_fast2(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
-int gemm_dispatch_masked(const float*, int, const float*, int, float*, int, int, int, int, const float*, int, hipStream_t);
+int gemm_dispatch_masked(const float*, int, const float*, int, float*, int, int, int, int, const float*, int, hipStream_t, GemmAux aux = GemmAux());
 size_t gemm_scratch_floats(int M, int N, int K);
 int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipStream_t);
 size_t prologue_scratch_floats(int B);
@@ -52,11 +56,12 @@ int tail_launch(const float*, int, int, int, int, const float*, const float*, co
 int sdf_prep_launch(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, float*,
                     float*, hipStream_t);
 int sdf_affine_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
-                      hipStream_t);
+                      hipStream_t, float* rowmax = nullptr);
 int sdf_out_launch(const float*, int, int, const float*, const float*, long long, float*, hipStream_t);
 int sdf_affine_rows_launch(const float*, const int32_t*, const float*, const float*, const float*, const float*, long long, int, int, int,
-                           float*, hipStream_t);
-int sdf_out_bwd_launch(const float*, const float*, const float*, const float*, int, int, long long, float*, hipStream_t);
+                           float*, hipStream_t, float* rowmax = nullptr);
+int sdf_out_bwd_launch(const float*, const float*, const float*, const float*, int, int, long long, float*, hipStream_t, float* rowmax = nullptr,
+                       const float* wmax = nullptr);
 int relu_mask_launch(float*, const float*, long long, int, int, hipStream_t);
 int sdf_affine_bwd_launch(const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*, float*,
                           float*, bool, hipStream_t);
@@ -83,6 +88,11 @@ struct ls_model {
     void* wq_planes[LS_MAX_LAYERS] = {};   // attention layers 2 - 4: destination-side weights as f16 MFMA fragments (edge.hip, edge_attn_fq_kernel)
     float* dec_wt = nullptr;            // transposed decoder weights [kin_l][out_l], built by the first backward call
     size_t dec_wt_off[12] = {};
+    // max|row| of every weight matrix a GEMM reads (gemm.hip, GemmAux::w_rowmax): saves the kernels their pre-pass over W
+    struct WMax { const float* base; size_t rows; int K; const float* wmax; };
+    std::vector<WMax> wreg;
+    float* wmax_pool = nullptr;         // blob matrices (ls_model_create)
+    float* wmax_pool_t = nullptr;       // transposed decoder weights (first backward call)
     hipStream_t side = nullptr;    // FPS chain
     hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -144,7 +154,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_hint, o_inv, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_hint, o_inv, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -153,7 +163,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     int cur = N;
     p.nlevels = 0;
     p.levelN[0] = N;
-    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0, maxKs = 0, maxGws = 0;
+    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0, maxKs = 0, maxGws = 0, maxRm = 0;
     for (int i = 0; i < p.L; ++i) {
         p.Ns[i] = cur;
         const int f = d.down_factor[i] > 1 ? d.down_factor[i] : 1;
@@ -185,6 +195,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         }
         maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
         maxC = std::max(maxC, (size_t)p.Co[i]);
+        if (i >= d.res_global_start_layer) maxRm = std::max(maxRm, (size_t)p.Nd[i]);
         // split-K slabs of the under-filled GEMMs (residual global conv: per-point part and per-instance mean part)
         maxGws = std::max(maxGws, std::max(gemm_scratch_floats(B * p.Nd[i] * 3, 2 * p.Co[i], p.Co[i]), gemm_scratch_floats(B * 3, 4 * p.Co[i], p.Co[i])));
         maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
@@ -219,10 +230,46 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_Tc = take((size_t)B * p.NP * 3 * p.Cdp * 4);
     maxGws = std::max(maxGws, gemm_scratch_floats(B * p.NP * 3, p.Cdp, p.Co[p.L - 1]));
     p.o_gws = take(maxGws * 4 + 256);
+    // row maxima of the messages / layer outputs, chained into the GEMMs that read them (gemm.hip, GemmAux)
+    p.o_rm_msg = take((size_t)B * maxRm * 3 * 4);
+    p.o_rm_out[0] = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);
+    p.o_rm_out[1] = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);
     // staging of the captured-graph path: the graph reads x from / writes the codes to FIXED addresses inside the workspace
     p.o_xin = take((size_t)B * 3 * N * 4);
     p.o_out = take((size_t)B * (4 * (size_t)d.c_dim + 4) * 4);
     p.total = off;
+    return LS_OK;
+}
+
+static int dec_out(const ls_model_desc& d, int l);
+// ------------------------------------------------------------------------------------------------ weight row maxima
+// rows [W, W + N*K) of a registered matrix with the same K -> their maxima; nullptr = not registered (the GEMM then scans W itself)
+static const float* wmax_for(const ls_model* m, const float* W, int N, int K) {
+    for (const auto& e : m->wreg) {
+        if (e.K != K || W < e.base) continue;
+        const size_t off = (size_t)(W - e.base);
+        if (off % K == 0 && off / K + (size_t)N <= e.rows) return e.wmax + off / K;
+    }
+    return nullptr;
+}
+static GemmAux aux_w(const ls_model* m, const float* W, int N, int K) {
+    GemmAux a;
+    a.w_rowmax = wmax_for(m, W, N, K);
+    return a;
+}
+struct WSpec { const float* base; size_t rows; int K; };
+static int wmax_register(ls_model* m, const std::vector<WSpec>& specs, float** pool, hipStream_t st) {
+    size_t total = 0;
+    for (const auto& sp : specs) total += sp.rows;
+    if (!total) return LS_OK;
+    LS_HIP_CHECK(hipMalloc((void**)pool, total * sizeof(float)));
+    size_t off = 0;
+    for (const auto& sp : specs) {
+        const int rc = gemm_rowmax_launch(sp.base, (int)sp.rows, sp.K, sp.K, *pool + off, st);
+        if (rc != LS_OK) return rc;
+        m->wreg.push_back({sp.base, sp.rows, sp.K, *pool + off});
+        off += sp.rows;
+    }
     return LS_OK;
 }
 
@@ -258,32 +305,44 @@ static EdgeTables edge_tables_layout(const ls_model* m, int i, const float* cur,
     return EdgeTables{T + pc, nc, nc, Ns, 1};
 }
 // the folded VN-Linear contraction of layer i >= 1 (edge.hip header): cur [B,Ns,3,Cin] -> table(s) in T
+// a_rowmax (nullable) [B*Ns*3][a_parts]: row maxima of `cur` from the kernel that wrote it (GemmAux)
 static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, float* T, hipStream_t gs,
-                       EdgeTables& et) {
+                       EdgeTables& et, const float* a_rowmax = nullptr, int a_parts = 0) {
     const ls_model_desc& d = m->d;
     const int Cin = layer_cin(d, i), nc = layer_ncols(d, i), pc = layer_pcols(d, i), qc = nc - pc;
     const float* W = m->blob + d.off_edge[i];
     et = edge_tables_layout(m, i, cur, dst_rows, B, Ns, Nd, T);
     PROF(LS_K_GEMM_EDGE, i, gs);
     // attention layers 2 - 4 (fused): only the neighbour-side table; the destination side is computed inside the edge kernel (edge.hip)
-    if (et.cur) return gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
+    GemmAux ax = aux_w(m, W, nc, Cin);
+    ax.a_rowmax = a_rowmax; ax.a_parts = a_parts;
+    if (et.cur) return gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs, ax);
     if (dst_rows) {
         // down-sampled layer: P table on all source points, Q table only on the FPS-selected destination points
-        int rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs);
-        if (rc == LS_OK) rc = gemm_dispatch_gather(cur, Cin, W + (size_t)pc * Cin, Cin, nullptr, const_cast<float*>(et.Tq), qc, B * Nd * 3, qc, Cin, 0, dst_rows, Nd, Ns, gs);
+        int rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs, ax);
+        GemmAux aq = ax;
+        if (aq.w_rowmax) aq.w_rowmax += pc;
+        if (rc == LS_OK) rc = gemm_dispatch_gather(cur, Cin, W + (size_t)pc * Cin, Cin, nullptr, const_cast<float*>(et.Tq), qc, B * Nd * 3, qc, Cin, 0, dst_rows, Nd, Ns, gs, aq);
         return rc;
     }
-    return gemm_dispatch(cur, Cin, W, Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, gs);
+    return gemm_dispatch(cur, Cin, W, Cin, nullptr, T, nc, B * Ns * 3, nc, Cin, 0, gs, ax);
 }
 // gather + VN activation + mean-pool | attention of layer i >= 1 over the tables
+// rm_out (nullable) [B*Nd*3]: receives max|out[row, :]| when the kernel taken can write it; *rm_written says whether it did
 static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, const int32_t* knn, const int32_t* dst_rows, int B, int Nd,
-                      int Ns, float* out, hipStream_t st) {
+                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr) {
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
+    if (rm_written) *rm_written = false;
     if (i >= d.atten_start_layer) {
         PROF(LS_K_EDGE_ATTN, i, st);
-        if (et.cur) return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st);
-        return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st);
+        if (et.cur) {
+            if (rm_written) *rm_written = rm_out != nullptr;
+            return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
+        }
+        if (!edge_attn_emits_rowmax(Co, et.ldp, et.ldq)) rm_out = nullptr;
+        if (rm_written) *rm_written = rm_out != nullptr;
+        return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
     }
     PROF(LS_K_EDGE_POOL, i, st);
     return edge_pool_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, out, st);
@@ -293,10 +352,14 @@ static size_t global_conv_gws_floats(const ls_model_desc& d, int i, int B, int N
     const int Co = d.feat_dim[i];
     return std::max(gemm_scratch_floats(B * Nd * 3, 2 * Co, Co), gemm_scratch_floats(B * 3, 4 * Co, Co));
 }
-static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, float* g, float* G, float* TG, float* gws, float* out, hipStream_t st) {
+// rm_msg (nullable) [B*Nd*3]: row maxima of msg from the kernel that wrote it; rm_out (nullable) [B*Nd*3][Co/32]: receives those of `out`
+// (*rm_written: whether the path taken wrote them) -- gemm.hip, GemmAux
+static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, float* g, float* G, float* TG, float* gws, float* out, hipStream_t st,
+                       const float* rm_msg = nullptr, float* rm_out = nullptr, bool* rm_written = nullptr) {
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
     const float* Wg = m->blob + d.off_glob[i];
+    if (rm_written) *rm_written = false;
     int rc;
     { PROF(LS_K_MEAN, i, st); rc = mean_points_launch(msg, B, Nd, Co, g, st); }
     if (rc != LS_OK) return rc;
@@ -305,11 +368,17 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
         PROF(LS_K_GEMM_GLOB, i, st);
         rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, gws, st);
         if (rc != LS_OK) return rc;
-        return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st);
+        GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
+        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? 1 : 0;
+        ax.out_rowmax = rm_out;
+        if (rm_written) *rm_written = rm_out != nullptr;
+        return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st, ax);
     }
     {
         PROF(LS_K_GEMM_GLOB, i, st);
-        rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, gws, st);
+        GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
+        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? 1 : 0;
+        rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, gws, st, ax);
         if (rc == LS_OK) rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, gws, st);
     }
     if (rc != LS_OK) return rc;
@@ -318,12 +387,15 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
 }
 // conv_c + pooling + heads (vec_dgcnn_atten.py:231-250) + the encode epilogue (model_utils.py:182-195)
 static int encoder_tail(ls_model* m, const float* cur, int B, int NP, float* Tc, float* gws, const float* centroid, const float* scale0,
-                        float* z_so3, float* z_inv, float* s_out, float* t_out, hipStream_t st) {
+                        float* z_so3, float* z_inv, float* s_out, float* t_out, hipStream_t st, const float* rm_cur = nullptr, int rm_parts = 0) {
     const ls_model_desc& d = m->d;
     const int Cl = d.feat_dim[d.num_layers - 1], Cdp = (int)align_up((size_t)d.c_dim + 1, 4);
     const float* W = m->blob;
     int rc;
-    { PROF(LS_K_GEMM_TAIL, 0, st); rc = gemm_dispatch_ws(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, Cdp, B * NP * 3, Cdp, Cl, 0, gws, st); }
+    { PROF(LS_K_GEMM_TAIL, 0, st);
+      GemmAux ax = aux_w(m, W + d.off_convc, Cdp, Cl);
+      ax.a_rowmax = rm_cur; ax.a_parts = rm_parts;
+      rc = gemm_dispatch_ws(cur, Cl, W + d.off_convc, Cl, nullptr, Tc, Cdp, B * NP * 3, Cdp, Cl, 0, gws, st, ax); }
     if (rc != LS_OK) return rc;
     PROF(LS_K_TAIL, 0, st);
     return tail_launch(Tc, Cdp, B, NP, d.c_dim, W + d.off_inv_t, W + d.off_c_fc0_t, W + d.off_c_misc, d.neg_slope, d.scale_factor,
@@ -379,6 +451,23 @@ int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* b
         return LS_ERR_WORKSPACE;
     }
     return gemm_dispatch_ws(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (float*)workspace, (hipStream_t)stream);
+}
+int ls_gemm_rowmax_parts(int N) { return N > 0 ? gemm_rowmax_parts(N) : 0; }
+int ls_gemm_f32_ex(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
+                   int relu, const float* a_rowmax, int a_parts, const float* w_rowmax, float* out_rowmax, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    LS_REQUIRE(!a_rowmax || a_parts >= 1, "gemm_ex: a_rowmax needs a_parts >= 1");
+    GemmAux ax;
+    ax.a_rowmax = a_rowmax; ax.a_parts = a_rowmax ? a_parts : 0; ax.w_rowmax = w_rowmax; ax.out_rowmax = out_rowmax;
+    const size_t sb = (workspace && lda % 4 == 0 && ldw % 4 == 0) ? ls_gemm_workspace_bytes(M, N, K) : 0;
+    LS_REQUIRE(!(sb && out_rowmax), "gemm_ex: a split-K launch (M=%d N=%d K=%d with a workspace) writes no out_rowmax: pass workspace = NULL", M, N, K);
+    if (!sb) return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream, ax);
+    if (sb > workspace_bytes) { set_error("gemm_ex: workspace %zu < required %zu (ls_gemm_workspace_bytes)", workspace_bytes, sb); return LS_ERR_WORKSPACE; }
+    return gemm_dispatch_ws(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (float*)workspace, (hipStream_t)stream, ax);
+}
+int ls_rowmax_f32(const float* X, int rows, int K, int ld, float* out, void* stream) {
+    LS_REQUIRE(X && out && rows > 0 && K > 0 && ld >= K, "rowmax: bad argument");
+    return gemm_rowmax_launch(X, rows, K, ld, out, (hipStream_t)stream);
 }
 int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out, void* stream) {
     LS_REQUIRE(B > 0, "prologue: empty batch");
@@ -452,6 +541,25 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
         const int rc = edge_presplit_wq_launch(m->blob + desc->off_edge[i] + (size_t)layer_pcols(*desc, i) * Cin, Co, Cin, m->wq_planes[i], nullptr);
         if (rc != LS_OK || hipDeviceSynchronize() != hipSuccess) { ls_model_destroy(m); return LS_ERR_HIP; }
     }
+    {   // row maxima of every matrix the GEMMs read (GemmAux::w_rowmax)
+        std::vector<WSpec> specs;
+        const ls_model_desc& d = *desc;
+        for (int i = 1; i < d.num_layers; ++i) specs.push_back({m->blob + d.off_edge[i], (size_t)layer_ncols(d, i), layer_cin(d, i)});
+        for (int i = d.res_global_start_layer; i < d.num_layers; ++i)
+            if (i >= 0) specs.push_back({m->blob + d.off_glob[i], (size_t)4 * d.feat_dim[i], d.feat_dim[i]});
+        if (d.num_layers >= 1) specs.push_back({m->blob + d.off_convc, align_up((size_t)d.c_dim + 1, 4), d.feat_dim[d.num_layers - 1]});
+        if (d.dec_num_linear >= 3) {
+            int kin = d.dec_width;
+            for (int l = 1; l < d.dec_num_linear - 1; ++l) {
+                const int outw = dec_out(d, l);
+                specs.push_back({m->blob + d.off_dec_w[l], (size_t)outw, kin});
+                kin = outw;
+            }
+            specs.push_back({m->blob + d.off_dec_w[d.dec_num_linear - 1], 1, kin});
+        }
+        const int rc = wmax_register(m, specs, &m->wmax_pool, nullptr);
+        if (rc != LS_OK || hipDeviceSynchronize() != hipSuccess) { ls_model_destroy(m); return LS_ERR_HIP; }
+    }
     *out = m;
     return LS_OK;
 }
@@ -460,6 +568,8 @@ void ls_model_destroy(ls_model_t* m) {
     if (!m) return;
     if (m->blob) (void)hipFree(m->blob);
     if (m->dec_wt) (void)hipFree(m->dec_wt);
+    if (m->wmax_pool) (void)hipFree(m->wmax_pool);
+    if (m->wmax_pool_t) (void)hipFree(m->wmax_pool_t);
     for (int i = 0; i < LS_MAX_LAYERS; ++i)
         if (m->wq_planes[i]) (void)hipFree(m->wq_planes[i]);
     if (m->side) (void)hipStreamDestroy(m->side);
@@ -543,6 +653,8 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
     size_t knn_off = 0, fps_off = 0;
     const int32_t* prev_knn = nullptr;
     const int32_t* prev_rows = nullptr;   // the previous layer's FPS selection (rows of its source set), if it down-sampled
+    const float* cur_rm = nullptr;        // row maxima of `cur` ([rows][cur_rm_parts]) when the kernel that wrote it emitted them (GemmAux)
+    int cur_rm_parts = 0;
     for (int i = 0; i < p.L; ++i) {
         if (i == m->debug_layers) {
             static bool printed = false;
@@ -566,6 +678,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
         const bool attn = i >= d.atten_start_layer;
         const bool glob = i >= d.res_global_start_layer;
         float* mp = glob ? msg : nxt;
+        bool msg_rm = false;
         if (i == 0) {
             { PROF(LS_K_KNN, i, st); rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
             if (rc != LS_OK) return rc;
@@ -582,7 +695,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 LS_HIP_CHECK(hipStreamWaitEvent(gs, m->ev_feat[i], 0));
             }
             EdgeTables et;
-            rc = edge_tables(m, i, cur, dst_rows, B, Ns, Nd, T, gs, et);
+            rc = edge_tables(m, i, cur, dst_rows, B, Ns, Nd, T, gs, et, cur_rm, cur_rm_parts);
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
             { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
@@ -603,12 +716,16 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
-            rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st);
+            rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm);
             if (rc != LS_OK) return rc;
         }
+        cur_rm = nullptr; cur_rm_parts = 0;
         if (glob) {
-            rc = global_conv(m, i, msg, B, Nd, F(p.o_g), F(p.o_G), F(p.o_TG), F(p.o_gws), nxt, st);
+            bool out_rm = false;
+            rc = global_conv(m, i, msg, B, Nd, F(p.o_g), F(p.o_G), F(p.o_TG), F(p.o_gws), nxt, st, msg_rm ? F(p.o_rm_msg) : nullptr,
+                             F(p.o_rm_out[i & 1]), &out_rm);
             if (rc != LS_OK) return rc;
+            if (out_rm) { cur_rm = F(p.o_rm_out[i & 1]); cur_rm_parts = Co / 32; }
         }
         std::swap(cur, nxt);
         prev_knn = knn;
@@ -618,7 +735,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
 
     // ---- tail
     return encoder_tail(m, cur, B, p.NP, F(p.o_Tc), F(p.o_gws), pre_normalised ? nullptr : centroid, pre_normalised ? nullptr : scale0,
-                        z_so3, z_inv, s_out, t_out, st);
+                        z_so3, z_inv, s_out, t_out, st, cur_rm, cur_rm_parts);
 }
 
 namespace ls { int scatter_codes_launch(const float* packed, int B, int c, float* z_so3, float* z_inv, float* s, float* t, hipStream_t st); }
@@ -788,6 +905,7 @@ static int dec_out(const ls_model_desc& d, int l) {  // padded output width of l
 }
 
 // split-K scratch (floats) that covers every GEMM of the decoder forward and backward at `rows` query rows
+static int sdf_rm_parts(int w) { return std::max(sdf_affine_rowmax_parts(w), gemm_rowmax_parts(w)); }
 static size_t sdf_gemm_scratch(const ls_model_desc& d, long long rows) {
     size_t mx = 0;
     int kin = d.dec_width;
@@ -807,6 +925,7 @@ size_t ls_sdf_workspace_bytes(const ls_model_t* m, int B, int M) {
     b += 2 * align_up((size_t)B * w * 4 * 4, 256);   // A0, A4
     b += 2 * align_up((size_t)B * w * 4, 256);       // beff0, beff4
     b += 2 * align_up((size_t)B * M * w * 4, 256);   // ping-pong activations
+    b += 2 * align_up((size_t)B * M * sdf_rm_parts((int)w) * 4, 256);   // row maxima of the activations (GemmAux)
     return b;
 }
 // training form: every layer's activations are kept for the backward pass, plus its scratch
@@ -821,6 +940,7 @@ size_t ls_sdf_train_workspace_bytes(const ls_model_t* m, int B, int M) {
     b += 2 * align_up((size_t)B * w * 4 * 4, 256) + 2 * align_up((size_t)B * w * 4, 256);      // dA0, dA4, dbeff0, dbeff4
     b += align_up((size_t)B * M * 4 * 4, 256);                                                  // dQ
     b += align_up(sdf_gemm_scratch(m->d, (long long)B * M) * 4, 256) + 256;                      // split-K slabs (small M only)
+    b += 2 * align_up((size_t)B * M * sdf_rm_parts((int)w) * 4, 256);                           // row maxima of the activations / gradients (GemmAux)
     return b;
 }
 
@@ -829,6 +949,7 @@ struct SdfBuffers {
     float* h[12];       // output of linear layer l (post-ReLU); inference: two ping-pong buffers
     float *dzA, *dzB, *dA0, *dA4, *db0, *db4, *dQ;
     float* gws;         // split-K scratch for the under-filled GEMMs (NULL when the grid is large enough)
+    float* rm[2];       // row maxima of the activations / gradients, ping-pong: [rows][sdf_rm_parts(w)] (GemmAux)
 };
 static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, int M, bool train, bool allow_splitk = true) {
     SdfBuffers sb{};
@@ -847,6 +968,8 @@ static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, in
         // inference never splits K: a query's SDF must not depend on how many other queries share the call (MISE evaluates
         // the same lattice point in calls of very different sizes; split-K changes the fp32 summation order)
         sb.gws = nullptr;
+        sb.rm[0] = take((size_t)B * M * sdf_rm_parts(w) * 4);
+        sb.rm[1] = take((size_t)B * M * sdf_rm_parts(w) * 4);
         return sb;
     }
     for (int l = 0; l < nl - 1; ++l) sb.h[l] = take((size_t)B * M * w * 4);
@@ -857,8 +980,10 @@ static SdfBuffers sdf_buffers(const ls_model_desc& d, void* workspace, int B, in
     sb.db0 = take((size_t)B * w * 4);
     sb.db4 = take((size_t)B * w * 4);
     sb.dQ = take((size_t)B * M * 16);
-    sb.gws = sdf_gemm_scratch(d, (long long)B * M) ? take(sdf_gemm_scratch(d, (long long)B * M) * 4) : nullptr;
+    sb.gws = sdf_gemm_scratch(d, (long long)B * M) ? take(sdf_gemm_scratch(d, (long long)B * M) * 4 + 256) : nullptr;
     if (!allow_splitk) sb.gws = nullptr;
+    sb.rm[0] = take((size_t)B * M * sdf_rm_parts(w) * 4);
+    sb.rm[1] = take((size_t)B * M * sdf_rm_parts(w) * 4);
     return sb;
 }
 
@@ -880,28 +1005,42 @@ static int sdf_forward(ls_model_t* m, const SdfBuffers& sb, const float* query, 
     }
     if (rc != LS_OK) return rc;
     // layer 0: pure affine in (q, |q|)
+    // operand range of the GEMMs (gemm.hip, GemmAux): every kernel that writes an activation also writes its row maxima, the GEMM that
+    // reads it takes them instead of scanning its A rows; the weights carry theirs from ls_model_create
+    const bool chain = !m->sdf_bf16x2;
+    bool have = chain;   // sb.rm[ri] holds the row maxima of h[l - 1], rm_parts per row
+    int ri = 0, rm_parts = sdf_affine_rowmax_parts(w);
     { PROF(LS_K_SDF_AFFINE, 0, st);
-      rc = row_inst ? sdf_affine_rows_launch(query, row_inst, s, t, sb.A0, sb.b0, rows, w, w, 0, sb.h[0], st)
-                    : sdf_affine_launch(query, s, t, sb.A0, sb.b0, B, M, w, w, 0, sb.h[0], st); }
+      rc = row_inst ? sdf_affine_rows_launch(query, row_inst, s, t, sb.A0, sb.b0, rows, w, w, 0, sb.h[0], st, chain ? sb.rm[0] : nullptr)
+                    : sdf_affine_launch(query, s, t, sb.A0, sb.b0, B, M, w, w, 0, sb.h[0], st, chain ? sb.rm[0] : nullptr); }
     if (rc != LS_OK) return rc;
     int kin = w;
     for (int l = 1; l < nl - 1; ++l) {
         const int outw = dec_out(d, l);
         const float* cur = sb.h[l - 1];
         float* nxt = sb.h[l];
+        GemmAux ax = aux_w(m, W + d.off_dec_w[l], outw, kin);
+        ax.a_rowmax = have ? sb.rm[ri] : nullptr;
+        ax.a_parts = have ? rm_parts : 0;
         if (l == li) {
             { PROF(LS_K_GEMM_SDF, l, st);
               rc = (m->sdf_bf16x2 && !sb.gws) ? gemm_dispatch_fast2(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, (int)rows, outw, kin, 0, st)
-                                              : gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, (int)rows, outw, kin, 0, sb.gws, st); }
+                                              : gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, nullptr, nxt, w, (int)rows, outw, kin, 0, sb.gws, st, ax); }
             if (rc != LS_OK) return rc;
             PROF(LS_K_SDF_AFFINE, l, st);
-            rc = row_inst ? sdf_affine_rows_launch(query, row_inst, s, t, sb.A4, sb.b4, rows, w, w, 1, nxt, st)
-                          : sdf_affine_launch(query, s, t, sb.A4, sb.b4, B, M, w, w, 1, nxt, st);
+            float* rmo = chain ? sb.rm[ri ^ 1] : nullptr;
+            rc = row_inst ? sdf_affine_rows_launch(query, row_inst, s, t, sb.A4, sb.b4, rows, w, w, 1, nxt, st, rmo)
+                          : sdf_affine_launch(query, s, t, sb.A4, sb.b4, B, M, w, w, 1, nxt, st, rmo);
+            if (chain) { ri ^= 1; have = true; rm_parts = sdf_affine_rowmax_parts(w); }
         } else {
             PROF(LS_K_GEMM_SDF, l, st);
+            const bool emit = chain && !(sb.gws && gemm_scratch_floats((int)rows, outw, kin) > 0);   // a split-K launch writes no row maxima
+            if (emit) ax.out_rowmax = sb.rm[ri ^ 1];
             rc = (m->sdf_bf16x2 && !sb.gws)
                      ? gemm_dispatch_fast2(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, (int)rows, outw, kin, 1, st)
-                     : gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, (int)rows, outw, kin, 1, sb.gws, st);
+                     : gemm_dispatch_ws(cur, w, W + d.off_dec_w[l], kin, W + d.off_dec_b[l], nxt, w, (int)rows, outw, kin, 1, sb.gws, st, ax);
+            if (emit) { ri ^= 1; rm_parts = gemm_rowmax_parts(outw); }
+            have = emit;
         }
         if (rc != LS_OK) return rc;
         kin = outw;
@@ -928,6 +1067,7 @@ size_t ls_sdf_rows_workspace_bytes(const ls_model_t* m, int B, long long R) {
     const size_t w = (size_t)m->d.dec_width;
     size_t b = 2 * align_up((size_t)B * w * 4 * 4, 256) + 2 * align_up((size_t)B * w * 4, 256);
     b += 2 * align_up((size_t)R * w * 4, 256);
+    b += 2 * align_up((size_t)R * sdf_rm_parts((int)w) * 4, 256);
     return b;
 }
 int ls_sdf_decode_rows(ls_model_t* m, const float* query, const int32_t* row_inst, const float* z_so3, const float* z_inv, const float* s,
@@ -950,6 +1090,8 @@ int ls_sdf_decode_rows(ls_model_t* m, const float* query, const int32_t* row_ins
     float* hB = take((size_t)R * w * 4);
     for (int l = 0; l < nl - 1; ++l) sb.h[l] = (l & 1) ? hB : hA;
     sb.gws = nullptr;   // batch-invariant: no split-K (see sdf_buffers)
+    sb.rm[0] = take((size_t)R * sdf_rm_parts(w) * 4);
+    sb.rm[1] = take((size_t)R * sdf_rm_parts(w) * 4);
     return sdf_forward(m, sb, query, z_so3, z_inv, s, t, B, (int)R, sdf, (hipStream_t)stream, row_inst);
 }
 
@@ -980,7 +1122,10 @@ static int build_dec_wt(ls_model_t* m, hipStream_t st) {   // transposed main we
         if (rc != LS_OK) return rc;
         kin = outw;
     }
-    return LS_OK;
+    std::vector<WSpec> specs;
+    kin = w;
+    for (int l = 1; l < nl - 1; ++l) { const int outw = dec_out(d, l); specs.push_back({m->dec_wt + m->dec_wt_off[l], (size_t)kin, outw}); kin = outw; }
+    return wmax_register(m, specs, &m->wmax_pool_t, st);
 }
 
 // Gradients of sum(grad_sdf * sdf) w.r.t. the code and the query points, after ls_sdf_decode_train on the SAME arguments and
@@ -1009,7 +1154,12 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
     float* dz = sb.dzA;     // dz_l: gradient w.r.t. the pre-activation of layer l, row stride w
     float* other = sb.dzB;
     // last layer: dz_{nl-2}
-    rc = sdf_out_bwd_launch(grad_sdf, sdf, W + d.off_dec_w[nl - 1], sb.h[nl - 2], w, outw[nl - 2], rows, dz, st);
+    // operand range (gemm.hip, GemmAux): dz carries its row maxima from kernel to kernel like the activations of the forward pass
+    const bool chain = !m->sdf_bf16x2;
+    const float* w8max = wmax_for(m, W + d.off_dec_w[nl - 1], 1, outw[nl - 2]);
+    bool have = chain && w8max;   // sb.rm[ri] holds the row maxima (or an upper bound) of dz, rm_parts per row
+    int ri = 0, rm_parts = 1;
+    rc = sdf_out_bwd_launch(grad_sdf, sdf, W + d.off_dec_w[nl - 1], sb.h[nl - 2], w, outw[nl - 2], rows, dz, st, have ? sb.rm[0] : nullptr, w8max);
     if (rc != LS_OK) return rc;
     bool dq_started = false;
     for (int l = nl - 2; l >= 1; --l) {
@@ -1022,11 +1172,21 @@ int ls_sdf_backward(ls_model_t* m, const float* query, const float* z_so3, const
         // dh_{l-1} [rows, kin] = dz_l [rows, out_l] . W_l [out_l][kin]  ==  dz_l . (Wt_l [kin][out_l])^T
         // the ReLU derivative [h_{l-1} > 0] is applied in the GEMM's store when the launch does not split K (h and dh share the row stride w)
         const bool fuse_mask = !sb.gws && kin % 4 == 0;
+        GemmAux ax = aux_w(m, m->dec_wt + m->dec_wt_off[l], kin, outw[l]);
+        ax.a_rowmax = have ? sb.rm[ri] : nullptr;
+        ax.a_parts = have ? rm_parts : 0;
         if (fuse_mask) {
-            rc = gemm_dispatch_masked(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], other, w, (int)rows, kin, outw[l], sb.h[l - 1], m->sdf_bf16x2 ? 2 : 3, st);
+            if (chain) ax.out_rowmax = sb.rm[ri ^ 1];   // after the mask
+            rc = gemm_dispatch_masked(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], other, w, (int)rows, kin, outw[l], sb.h[l - 1], m->sdf_bf16x2 ? 2 : 3, st, ax);
+            if (chain) { ri ^= 1; rm_parts = gemm_rowmax_parts(kin); have = true; }
         } else {
-            rc = gemm_dispatch_ws(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, sb.gws, st);
+            // (an un-masked, possibly split-K launch: its maxima would still bound the masked values, but a split launch writes none)
+            const bool emit = chain && !(sb.gws && gemm_scratch_floats((int)rows, kin, outw[l]) > 0);
+            if (emit) ax.out_rowmax = sb.rm[ri ^ 1];
+            rc = gemm_dispatch_ws(dz, w, m->dec_wt + m->dec_wt_off[l], outw[l], nullptr, other, w, (int)rows, kin, outw[l], 0, sb.gws, st, ax);
             if (rc != LS_OK) return rc;
+            if (emit) { ri ^= 1; rm_parts = gemm_rowmax_parts(kin); }
+            have = emit;
             rc = relu_mask_launch(other, sb.h[l - 1], rows, kin, w, st);
         }
         if (rc != LS_OK) return rc;

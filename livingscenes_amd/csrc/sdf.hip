@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void sdf_prep_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void sdf_affine_kernel(const float* __restrict__ query, const float* __restrict__ s,
                                                          const float* __restrict__ t, const float* __restrict__ A,
                                                          const float* __restrict__ beff, int M, int out_dim, int ldh,
-                                                         int accumulate, int rows_per_block, float* __restrict__ h) {
+                                                         int accumulate, int rows_per_block, float* __restrict__ h,
+                                                         float* __restrict__ rowmax) {
+    // rowmax (nullable) [rows][4 * gridDim.x]: max|h[row, this wave's 64 columns]| -- the operand range of the GEMM that reads h (gemm.hip, GemmAux)
+    const int rm_parts = 4 * gridDim.x, rm_part = 4 * blockIdx.x + (threadIdx.x >> 6);
     const int b = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
     const int r0 = blockIdx.z * rows_per_block;
     const bool on = o < out_dim;
@@ -58,7 +61,12 @@ __global__ __launch_bounds__(256) void sdf_affine_kernel(const float* __restrict
         if (on) {
             float* hp = h + ((size_t)b * M + r) * ldh + o;
             if (accumulate) v += *hp;
-            *hp = fmaxf(v, 0.f);
+            v = fmaxf(v, 0.f);
+            *hp = v;
+        } else v = 0.f;
+        if (rowmax) {
+            const float wm = wave_max_lane63(v);
+            if ((threadIdx.x & 63) == 63) rowmax[((size_t)b * M + r) * rm_parts + rm_part] = wm;
         }
     }
 }
@@ -69,7 +77,8 @@ __global__ __launch_bounds__(256) void sdf_affine_rows_kernel(const float* __res
                                                               const float* __restrict__ s, const float* __restrict__ t,
                                                               const float* __restrict__ A, const float* __restrict__ beff, long long R,
                                                               int out_dim, int ldh, int accumulate, int rows_per_block,
-                                                              float* __restrict__ h) {
+                                                              float* __restrict__ h, float* __restrict__ rowmax) {
+    const int rm_parts = 4 * gridDim.x, rm_part = 4 * blockIdx.x + (threadIdx.x >> 6);
     const int o = blockIdx.x * 256 + threadIdx.x;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     const bool on = o < out_dim;
@@ -93,7 +102,12 @@ __global__ __launch_bounds__(256) void sdf_affine_rows_kernel(const float* __res
         if (on) {
             float* hp = h + (size_t)r * ldh + o;
             if (accumulate) v += *hp;
-            *hp = fmaxf(v, 0.f);
+            v = fmaxf(v, 0.f);
+            *hp = v;
+        } else v = 0.f;
+        if (rowmax) {
+            const float wm = wave_max_lane63(v);
+            if ((threadIdx.x & 63) == 63) rowmax[(size_t)r * rm_parts + rm_part] = wm;
         }
     }
 }
@@ -129,13 +143,15 @@ __global__ __launch_bounds__(256) void sdf_out_kernel(const float* __restrict__ 
 // dz[row][c] = g[row] (1 - sdf[row]^2) w[c] [h[row][c] > 0]
 __global__ __launch_bounds__(256) void sdf_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ sdf,
                                                           const float* __restrict__ w, const float* __restrict__ h, int ldh, int width,
-                                                          long long rows, float* __restrict__ dz) {
+                                                          long long rows, float* __restrict__ dz, float* __restrict__ rowmax,
+                                                          const float* __restrict__ wmax) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one float4 of a row
     const int w4 = width / 4;
     if (i >= rows * w4) return;
     const long long row = i / w4;
     const int c = (int)(i % w4) * 4;
     const float sv = sdf[row], gz = g[row] * (1.0f - sv * sv);
+    if (rowmax && c == 0) rowmax[row] = fabsf(gz) * wmax[0];   // an upper bound of max|dz[row, :]| (GemmAux: any bound serves)
     const float4 hv = *reinterpret_cast<const float4*>(h + (size_t)row * ldh + c);
     const float4 wv = *reinterpret_cast<const float4*>(w + c);
     float4 o;
@@ -278,8 +294,9 @@ __global__ void transpose_kernel(const float* __restrict__ W, int rows, int cols
 }
 
 int sdf_out_bwd_launch(const float* g, const float* sdf, const float* w, const float* h, int ldh, int width, long long rows, float* dz,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(sdf_out_bwd_kernel, dim3(cdiv(rows * (width / 4), 256)), dim3(256), 0, st, g, sdf, w, h, ldh, width, rows, dz);
+                       hipStream_t st, float* rowmax, const float* wmax) {
+    if (!wmax) rowmax = nullptr;
+    hipLaunchKernelGGL(sdf_out_bwd_kernel, dim3(cdiv(rows * (width / 4), 256)), dim3(256), 0, st, g, sdf, w, h, ldh, width, rows, dz, rowmax, wmax);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -327,22 +344,23 @@ int sdf_prep_launch(const float* inv_t, const float* so3_t, const float* wlen, c
     return LS_OK;
 }
 int sdf_affine_launch(const float* query, const float* s, const float* t, const float* A, const float* beff, int B, int M,
-                      int out_dim, int ldh, int accumulate, float* h, hipStream_t st) {
+                      int out_dim, int ldh, int accumulate, float* h, hipStream_t st, float* rowmax) {
     const int rpb = 64;
     // gridDim.y / .z are limited to 65535: say so instead of a generic launch failure (direct C-ABI callers; ops.sdf_decode chunks)
     LS_REQUIRE(B <= 65535 && cdiv(M, rpb) <= 65535, "sdf_decode: B=%d or M=%d too large for one call (B <= 65535, M <= %d): split the queries", B, M,
                65535 * rpb);
     hipLaunchKernelGGL(sdf_affine_kernel, dim3(cdiv(out_dim, 256), B, cdiv(M, rpb)), dim3(256), 0, st, query, s, t, A, beff, M,
-                       out_dim, ldh, accumulate, rpb, h);
+                       out_dim, ldh, accumulate, rpb, h, rowmax);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
+int sdf_affine_rowmax_parts(int out_dim) { return 4 * cdiv(out_dim, 256); }
 int sdf_affine_rows_launch(const float* query, const int32_t* row_inst, const float* s, const float* t, const float* A, const float* beff,
-                           long long R, int out_dim, int ldh, int accumulate, float* h, hipStream_t st) {
+                           long long R, int out_dim, int ldh, int accumulate, float* h, hipStream_t st, float* rowmax) {
     const int rpb = 64;
     LS_REQUIRE(cdiv(R, rpb) <= 65535, "sdf_decode_rows: R=%lld rows too many for one call (<= %d): split the rows", R, 65535 * rpb);
     hipLaunchKernelGGL(sdf_affine_rows_kernel, dim3(cdiv(out_dim, 256), (unsigned)cdiv(R, rpb)), dim3(256), 0, st, query, row_inst, s, t, A,
-                       beff, R, out_dim, ldh, accumulate, rpb, h);
+                       beff, R, out_dim, ldh, accumulate, rpb, h, rowmax);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

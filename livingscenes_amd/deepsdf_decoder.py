@@ -51,8 +51,10 @@ class DeepSDF_Decoder(nn.Module):
                     W = (lin.weight_g.detach().double() * v / v.norm(dim=1, keepdim=True)).float()
                 else:
                     W = lin.weight.detach().float()
+                if W.shape[1] % 4:                      # ls_gemm_f32 wants K % 4 == 0 (513-wide input): zero-pad the weights once
+                    W = torch.nn.functional.pad(W, (0, 4 - W.shape[1] % 4))
                 ws.append((W.contiguous(), lin.bias.detach().float().contiguous()))
-            self._fold, self._fold_key = ws, key
+            self._fold, self._fold_key, self._wmax = ws, key, None
         return self._fold
 
     def forward(self, input, phase="val"):
@@ -66,13 +68,14 @@ class DeepSDF_Decoder(nn.Module):
         x0 = input.reshape(-1, L).float().contiguous()
         x = x0
         last = self.num_layers - 2
-        for layer, (W, b) in enumerate(self._folded()):
+        fold = self._folded()
+        if getattr(self, "_wmax", None) is None or self._wmax[0].device != x0.device:
+            self._wmax = [ops.rowmax(W.to(x0.device)) for W, _ in fold]        # operand range of the weights, once (ls_gemm_f32_ex)
+        rm = None                                       # row maxima of x, chained from GEMM to GEMM (None: the kernel scans x itself)
+        for layer, (W, b) in enumerate(fold):
             if layer in self.latent_in:
-                x = torch.cat([x, x0], 1)
-            k = x.shape[1]
-            if k % 4:                                   # ls_gemm_f32 wants K % 4 == 0 (513-wide input): zero-pad both operands
-                pad = 4 - k % 4
-                x = torch.nn.functional.pad(x, (0, pad))
-                W = torch.nn.functional.pad(W, (0, pad))
-            x = ops.gemm(x.contiguous(), W.contiguous(), b, relu=layer < last)
+                x, rm = torch.cat([x, x0], 1), None
+            if x.shape[1] != W.shape[1]:
+                x, rm = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1])), rm
+            x, rm = ops.gemm_chain(x.contiguous(), W, b, relu=layer < last, a_rowmax=rm, w_rowmax=self._wmax[layer], want_rowmax=layer < last)
         return torch.tanh(x).view(B, N)

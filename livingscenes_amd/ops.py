@@ -63,6 +63,30 @@ def gemm(A, W, bias=None, relu=False):
     return out
 
 
+def rowmax(X):
+    """max_k |X[r, k]| -> [rows]: the operand range ls_gemm_f32_ex takes for a weight matrix (once) or an input."""
+    X = _f32(X)
+    out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+    call(X.device, "ls_rowmax_f32", ptr(X), X.shape[0], X.shape[1], X.shape[1], ptr(out), stream_ptr(X.device))
+    return out
+
+
+def gemm_chain(A, W, bias=None, relu=False, a_rowmax=None, w_rowmax=None, want_rowmax=True):
+    """ls_gemm_f32_ex: the GEMM of ``gemm`` for a chain of layers -- takes the row maxima of its operands (``a_rowmax`` [M, parts] from
+    the previous call, ``w_rowmax`` [N] from ``rowmax(W)``) and returns (out, out_rowmax [M, parts']) for the next one.  Never splits
+    K (a row's result does not depend on the other rows of the call)."""
+    A, W = _f32(A), _f32(W)
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    parts = load().ls_gemm_rowmax_parts(N)
+    orm = torch.empty(M, parts, dtype=torch.float32, device=A.device) if want_rowmax else None
+    a_parts = 0 if a_rowmax is None else (1 if a_rowmax.dim() == 1 else a_rowmax.shape[1])
+    call(A.device, "ls_gemm_f32_ex", ptr(A), K, ptr(W), K, ptr(bias), ptr(out), N, M, N, K, int(relu), ptr(a_rowmax), a_parts, ptr(w_rowmax),
+         ptr(orm), None, 0, stream_ptr(A.device))
+    return out, orm
+
+
 def encode_prologue(x):
     """x [B,3,N] -> (pts [B,N,3], centroid [B,3], scale0 [B])."""
     x = _f32(x)

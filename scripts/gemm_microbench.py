@@ -19,14 +19,26 @@ if "--check" in sys.argv:
         bound = (A.double().abs() @ W.double().abs().T) * 2.0 ** -24
         print(f"K={K:4d}: max err / (2^-24 sum|a||w|) = {((out - ref).abs() / bound).max().item():.3f}   rel-to-max {((out - ref).abs().max() / ref.abs().max()).item():.2e}")
 if len(sys.argv) > 1: shapes = [s for s in shapes if sys.argv[1] in s[0]]
-for name, M, N, K in shapes:
-    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
-    for _ in range(3): ops.gemm(A, W)
+def timed(fn):
+    for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): ops.gemm(A, W)
+    for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    wr = M * N * 4 / ms / 1e9; fl = 2.0 * M * N * K / ms / 1e9
-    print(f"{name:12s} M={M:7d} N={N:5d} K={K:4d}: {ms*1e3:8.1f} us   write {wr:6.2f} TB/s   {fl:6.1f} TFLOP/s")
+    return e0.elapsed_time(e1) / 10
+
+
+for name, M, N, K in shapes:
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
+    # three forms, interleaved twice (the chip's clock drifts under load): ls_gemm_f32 (the kernel scans its operand rows for the range
+    # scaling), ls_gemm_f32_ex with the row maxima of A and W handed over, the same + writing the output's row maxima
+    am, wm = ops.rowmax(A), ops.rowmax(W)
+    forms = [lambda: ops.gemm(A, W), lambda: ops.gemm_chain(A, W, a_rowmax=am, w_rowmax=wm, want_rowmax=False),
+             lambda: ops.gemm_chain(A, W, a_rowmax=am, w_rowmax=wm, want_rowmax=True)]
+    if ops.load().ls_gemm_workspace_bytes(M, N, K):   # split-K shape: the chained forms never split
+        forms = forms[:1]
+    ms = [min(timed(f), timed(f)) for f in forms]
+    wr = M * N * 4 / ms[0] / 1e9; fl = 2.0 * M * N * K / ms[0] / 1e9
+    extra = "" if len(ms) == 1 else f"   maxima given {ms[1]*1e3:8.1f} us   + emitted {ms[2]*1e3:8.1f} us"
+    print(f"{name:12s} M={M:7d} N={N:5d} K={K:4d}: {ms[0]*1e3:8.1f} us   write {wr:6.2f} TB/s   {fl:6.1f} TFLOP/s{extra}")

@@ -238,19 +238,22 @@ def test_sdf_backward_with_small_and_large_upstream_gradients(log2_gscale):
     sdf, saved = m.sdf_decode_train(q.to(dev), code["z_so3"].to(dev), code["z_inv"].to(dev), code["s"].to(dev), code["t"].to(dev))
     base = m.sdf_backward(saved, gsdf.to(dev))
     gq, gso3, ginv, gs, gt = base
-    assert relerr(gso3, leaves["z_so3"].grad) < TOL
-    assert relerr(ginv, leaves["z_inv"].grad) < TOL
-    assert relerr(gt, leaves["t"].grad.reshape(B, 3)) < TOL
-    assert relerr(gq, ql.grad) < TOL
-    # grad_s[b] = -sum_m <dq_m, q_m> / s: judged against the magnitude of what is summed
-    qn = (ql.detach() - leaves["t"].detach()) / leaves["s"].detach()[:, None, None]
-    terms = ((ql.grad * leaves["s"].detach()[:, None, None]) * qn).sum(-1).abs().sum(-1) / leaves["s"].detach()
-    assert ((gs.cpu().double() - leaves["s"].grad).abs() / terms).max() < TOL
     f = 2.0 ** log2_gscale
     sdf2, saved2 = m.sdf_decode_train(q.to(dev), code["z_so3"].to(dev), code["z_inv"].to(dev), code["s"].to(dev), code["t"].to(dev))
     scaled = m.sdf_backward(saved2, (gsdf * f).to(dev))
     for name, a, b_ in zip(("query", "z_so3", "z_inv", "s", "t"), scaled, base):
         assert torch.equal(a, b_ * f), name
+    assert relerr(gso3, leaves["z_so3"].grad) < TOL
+    assert relerr(ginv, leaves["z_inv"].grad) < TOL
+    assert relerr(gt, leaves["t"].grad.reshape(B, 3)) < TOL
+    # per query: a query whose pre-activation sits within fp32 round-off of a ReLU kink takes the other branch in fp64 and its own
+    # gradient jumps by O(|w|) -- allowed for a handful of the 2048 queries, never for the sums above
+    perq = (gq.cpu().double() - ql.grad).abs().amax(-1) / ql.grad.abs().max()
+    assert (perq > TOL).double().mean() < 0.005 and perq.median() < 1e-5
+    # grad_s[b] = -sum_m <dq_m, q_m> / s: judged against the magnitude of what is summed
+    qn = (ql.detach() - leaves["t"].detach()) / leaves["s"].detach()[:, None, None]
+    terms = ((ql.grad * leaves["s"].detach()[:, None, None]) * qn).sum(-1).abs().sum(-1) / leaves["s"].detach()
+    assert ((gs.cpu().double() - leaves["s"].grad).abs() / terms).max() < TOL
 
 
 def test_decoder_forward_on_activations_outside_the_f16_range():
