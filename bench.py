@@ -244,11 +244,13 @@ def main():
         if multi:
             dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
 
+    last = [None] * nfl    # every handle's most recent result (the post-run check compares ALL of them, not one)
+
     def run(n, events=None):
         out = None
         for i in range(n):
             with torch.cuda.stream(streams[i % nfl]):
-                out = step(sps[i % nfl])
+                out = last[i % nfl] = step(sps[i % nfl])
                 if events is not None:
                     events[i].record()
         return out
@@ -270,6 +272,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    last_main = list(last)    # the handles' results of the TIMED region (the secondary FMA run below overwrites `last`)
     # per-step completion times (event per step on its stream): the spread of the inter-completion intervals shows a host hiccup or
     # a straggling step that the K-step mean hides (the driver's 20-step region is ~35 ms)
     done_ms = sorted(ev0.elapsed_time(e) for e in step_done)
@@ -312,6 +315,13 @@ def main():
         dt_fma = float(dt_f.item())
 
     emb, m, R, t = out
+    # every handle of the timed region saw the same batch: their last results must agree BIT FOR BIT (reproducibility with all the
+    # streams in flight); checked outside the timed region on every handle that ran
+    def same(a, b):
+        return all(torch.equal(a[0][k], b[0][k]) for k in ("z_so3", "z_inv", "s", "t")) and torch.equal(a[1]["matches0"], b[1]["matches0"]) \
+            and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    ran = [r for r in last_main if r is not None]
+    handles_identical = all(same(ran[0], r) for r in ran[1:])
     # sanity of the measured work (outside the timed region): matches are the identity permutation, poses are rotations
     n_correct = int((m["matches0"].cpu() == torch.arange(n_obj)).sum())
     det_ok = bool((torch.det(R.cpu()) > 0.99).all())
@@ -426,6 +436,7 @@ def main():
                        "steps_in_flight": nfl, "host_enqueue_ms_per_step": round(dt_host / args.steps * 1e3, 3), "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "knn_arithmetic": "canonical (separately rounded mul/add)"},
             "check": {"oracle_relerr": oracle_check, "rotations_proper": det_ok, "matches_identity": f"{n_correct}/{n_obj}",
+                      "handles_bit_identical": f"{handles_identical} ({len(ran)} handles, last step of each)",
                       "note": "oracle_relerr: max-norm relative error of the timed codes against the CPU oracle on instances spread over the batch "
                               "(tests/test_hip_fullbatch.py checks the same batch in pytest); weights are untrained, so the matcher is not expected "
                               "to recover the identity permutation"},

@@ -79,7 +79,12 @@ __device__ __forceinline__ void softmin_rows(const float* __restrict__ x, const 
     if (i0 >= N) return;
     const float eps = eps_p[p];
     if (!(eps > 0.f)) {
-        if (prev && lane < RB && i0 + lane < N) out[(size_t)p * N + i0 + lane] = prev[(size_t)p * N + i0 + lane];
+        // schedule ended: the potential passes through; without a previous potential the defined value is 0 (never left unwritten:
+        // callers allocate `out` uninitialised)
+        if (lane < RB && i0 + lane < N) out[(size_t)p * N + i0 + lane] = prev ? prev[(size_t)p * N + i0 + lane] : 0.f;
+        if constexpr (GRAD) {
+            if (lane < RB && i0 + lane < N) { float* gp = grad + ((size_t)p * N + i0 + lane) * 3; gp[0] = 0.f; gp[1] = 0.f; gp[2] = 0.f; }
+        }
         return;
     }
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;

@@ -103,41 +103,8 @@ class More_Solver:
             shared = {k: pick(c1[k], c2[k]).contiguous() for k in ("z_so3", "z_inv", "s", "t")}
             src, tgt = pick(pc2, pc1).contiguous(), pick(pc1, pc2).contiguous()
             g0 = torch.cat([pick(R21, R12), pick(t21, t12)], 2).contiguous()
-            hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 0)          # batch-invariant decoder arithmetic: P pairs == each pair alone
-            # opt-in (not in the reference's yaml): registration.decoder_bf16_pieces = 2 runs the refinement's decoder GEMMs with
-            # two-piece bf16 products (2^-16 per product, 3e-6 of max|sdf| end to end, ~1.4x faster GEMMs); default 3 = fp32-accurate
             two_piece = int(reg.get("decoder_bf16_pieces", 3)) == 2
-            if two_piece:
-                hip.set_option(_lib.OPT_SDF_BF16X2, 1)
-            try:
-                opt = ops.Se3Adam(g0, src, stop)
-                steps_run = 0
-                # length of the Sinkhorn epsilon-schedule loop: read back once, then guessed as (largest seen + 1) and VERIFIED at the
-                # host read every 16 steps (a schedule grows by one entry when a pair's bounding-box diameter doubles; 16 steps of
-                # at most lr radians / units each cannot do that) -- no device -> host round trip inside a step
-                sched_len, needs = None, []
-                for i in range(n_steps):
-                    lr = lr0 * (0.1 ** sum(i >= ms for ms in (300, 340, 380)))          # MultiStepLR([300, 340, 380], 0.1), :143
-                    sdf, saved = hip.sdf_decode_train(opt.query, shared["z_so3"], shared["z_inv"], shared["s"], shared["t"])
-                    loss, gsdf = ops.smooth_l1(sdf)
-                    gq = hip.sdf_backward(saved, gsdf, need_code_grad=False)[0]              # the code is fixed here (:137-141)
-                    sl, sg, need = divergence_batch(opt.query, tgt, lmax=sched_len, return_need=True)
-                    if sched_len is None:
-                        sched_len = int(need) + 1
-                    needs.append(need)
-                    opt.step(gq + sg, loss + sl, lr)
-                    steps_run = i + 1
-                    if i % 16 == 15:                                            # one host read per 16 steps
-                        worst = int(torch.stack(needs).max())
-                        if worst > sched_len:
-                            raise RuntimeError(f"Sinkhorn schedule grew from {sched_len} to {worst} entries within 16 steps (diverging pose?)")
-                        sched_len, needs = worst + 1, []
-                        if not bool(opt.active.any()):                          # every pair stopped early
-                            break
-            finally:
-                hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 1)
-                if two_piece:
-                    hip.set_option(_lib.OPT_SDF_BF16X2, 0)
+            opt, steps_run = self._refine_se3(shared, src, tgt, g0, n_steps, lr0, stop, two_piece=two_piece)
             best = opt.best_g
             Rb = best[:, :, :3].transpose(1, 2)
             inv = torch.cat([Rb, -(Rb @ best[:, :, 3:4])], 2)
@@ -148,6 +115,54 @@ class More_Solver:
         if return_info:
             return R, t, {"reverse": reverse, "min_loss": opt.min_loss, "active": opt.active, "steps": steps_run, "pre_icp": best}
         return R, t
+
+    def _refine_se3(self, shared, src, tgt, g0, n_steps, lr0, stop, two_piece=False, trace=None):
+        """The refinement loop of more_solver.py:137-173 for P pairs in lock-step (csrc/optim.hip; oracle twin: oracle/optim.py
+        registration_loop): shared = the code dict the decoder is conditioned on (P rows), src / tgt [P,N,3] / [P,M,3], g0 [P,3,4].
+        -> (ops.Se3Adam state, steps run).  ``trace`` (list) receives (g [P,3,4], loss [P]) after every step (tests)."""
+        from .. import _lib
+        from ..sinkhorn import divergence_batch
+        hip = self.model.hip_model()
+        # batch-invariant decoder arithmetic (P pairs == each pair alone); opt-in (not in the reference's yaml):
+        # registration.decoder_bf16_pieces = 2 runs the refinement's decoder GEMMs with two-piece bf16 products (2^-16 per product).
+        # The handle's previous settings are restored afterwards (a caller-chosen option is not clobbered).
+        prev_split = hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 0)
+        prev_x2 = hip.set_option(_lib.OPT_SDF_BF16X2, 1) if two_piece else None
+        try:
+            opt = ops.Se3Adam(g0, src, stop)
+            steps_run = 0
+            # length of the Sinkhorn epsilon-schedule loop: read back once, then guessed as (largest seen + 1) and VERIFIED at the
+            # host read every 16 steps (a schedule grows by one entry when a pair's bounding-box diameter doubles; 16 steps of
+            # at most lr radians / units each cannot do that) -- no device -> host round trip inside a step
+            sched_len, needs = None, []
+            for i in range(n_steps):
+                lr = lr0 * (0.1 ** sum(i >= ms for ms in (300, 340, 380)))          # MultiStepLR([300, 340, 380], 0.1), :143
+                sdf, saved = hip.sdf_decode_train(opt.query, shared["z_so3"], shared["z_inv"], shared["s"], shared["t"])
+                loss, gsdf = ops.smooth_l1(sdf)
+                gq = hip.sdf_backward(saved, gsdf, need_code_grad=False)[0]              # the code is fixed here (:137-141)
+                sl, sg, need = divergence_batch(opt.query, tgt, lmax=sched_len, return_need=True)
+                if sched_len is None:
+                    sched_len = int(need) + 1
+                needs.append(need)
+                opt.step(gq + sg, loss + sl, lr)
+                steps_run = i + 1
+                if trace is not None:
+                    trace.append((opt.g.clone(), (loss + sl).clone()))
+                if i % 16 == 15:                                            # one host read per 16 steps
+                    worst = int(torch.stack(needs).max())
+                    if worst > sched_len:
+                        # a pose ran away far enough to double a bounding box within 16 steps: those steps used a schedule one
+                        # entry short (a coarser final epsilon for that pair); widen and carry on rather than abort the whole batch
+                        import warnings
+                        warnings.warn(f"Sinkhorn schedule grew from {sched_len} to {worst} entries within 16 steps (diverging pose?)")
+                    sched_len, needs = worst + 1, []
+                    if not bool(opt.active.any()):                          # every pair stopped early
+                        break
+        finally:
+            hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, prev_split)
+            if two_piece:
+                hip.set_option(_lib.OPT_SDF_BF16X2, prev_x2)
+        return opt, steps_run
 
     def _sample(self, pcs, n_in):
         """Ragged FPS of a list of clouds [Ni,3] to n_in points each: ONE launch."""
@@ -202,7 +217,7 @@ class More_Solver:
         min_loss = torch.full((P,), 100.0, device=pc.device)
         improved = torch.zeros(P, dtype=torch.bool, device=pc.device)
         hip = self.model.hip_model()
-        hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 0)
+        prev_split = hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 0)
         try:
             for _ in range(n_steps):
                 optimizer.zero_grad()
@@ -216,7 +231,7 @@ class More_Solver:
                 improved |= better
                 optimizer.zero_grad()
         finally:
-            hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 1)
+            hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, prev_split)
         return {k: code[k].detach() for k in ("z_inv", "z_so3", "s", "t")}, improved
 
     def _mesh_from_latent(self, latent_code):

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/livingscenes_hip.h).  Inputs/outputs are HIP torch tensors;
 torch only provides device memory and the current stream.  No CPU fallback anywhere (see _lib.ptr)."""
 import ctypes
+import os
 
 import torch
 
@@ -243,8 +244,17 @@ class HipModel:
         return ws
 
     def set_option(self, option, value):
-        """ls_model_set_option (_lib.OPT_*)."""
+        """ls_model_set_option (_lib.OPT_*) -> the value the option had before (the library's default the first time), so that a
+        temporary change can be undone without clobbering a caller's setting."""
+        opts = self.__dict__.setdefault("_opts", {})
+        if int(option) not in opts:
+            defaults = {_lib.OPT_SDF_TRAIN_SPLITK: 1, _lib.OPT_SDF_BF16X2: int(os.environ.get("LS_SDF_BF16X2", "0") != "0"),
+                        _lib.OPT_ENCODE_GRAPH: int(os.environ.get("LS_ENCODE_GRAPH", "0") != "0")}
+            opts[int(option)] = defaults.get(int(option), 0)
+        prev = opts[int(option)]
         check(load().ls_model_set_option(self._h, int(option), int(value)), "ls_model_set_option")
+        opts[int(option)] = int(value)
+        return prev
 
     def profile_begin(self):
         check(load().ls_profile_begin(self._h), "ls_profile_begin")

@@ -13,6 +13,19 @@ from torch import nn
 from . import ops, packing
 
 
+# Every nn.Parameter / sub-module registration in the process bumps this counter (torch's global registration hooks): hip_model()
+# re-walks its parameter list when it moved (setattr of a new Parameter, a swapped sub-module, weight-norm re-wrapping ...).
+_REGISTRATIONS = [0]
+
+
+def _bump(*_args):
+    _REGISTRATIONS[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
+torch.nn.modules.module.register_module_module_registration_hook(_bump)
+
+
 class VecLinear(nn.Module):
     """Parameter container of VecLinear (so3 mode, vector path only): weight [v_out, v_in], no bias."""
 
@@ -96,9 +109,11 @@ class VecDGCNN_att(nn.Module):
         The parameter LIST is cached per decoder object (walking the module tree costs more than the check itself: this runs on
         every encode), the per-tensor (data_ptr, _version) check is not."""
         cache = getattr(self, "_hip_plist", None)
-        if cache is None or cache[0] is not decoder:
+        if cache is None or cache[0] is not decoder or cache[2] != _REGISTRATIONS[0]:
+            # (re-)walk the trees: first use, another decoder, or some module registered a parameter / sub-module since the last walk
+            # (a replaced nn.Parameter or a swapped sub-module would otherwise keep matching the stale list)
             plist = list(self.parameters()) + ([] if decoder is None else list(decoder.parameters()))
-            self._hip_plist = cache = (decoder, plist)
+            self._hip_plist = cache = (decoder, plist, _REGISTRATIONS[0])
         plist = cache[1]
         key = tuple([(p.data_ptr(), p._version) for p in plist])
         if self._hip is None or self._hip_key != key:

@@ -131,3 +131,78 @@ def test_config3_scene_pair_at_released_settings(released_prior):
         assert 100 < f.shape[0] < 0.5 * n_full and f.max() == np.asarray(mesh.vertices).shape[0] - 1, (f.shape[0], n_full)
         # (edge-collapse decimation may pinch a rough surface into non-manifold edges -- the reference's does, bit for bit the same:
         #  tests/test_simplify_cpu.py -- so watertightness is only asserted for the un-decimated extraction, test_hip_surface.py)
+
+
+def test_config3_scene_pair_optim_registration_at_released_settings(released_prior):
+    """configs[3] with the branch eval_3rscan.py:381 actually runs -- registration.optim true, step_size.so3 0.05, early_stop_threshold
+    10 (/root/reference/configs/more_3rscan.yaml:12-17; n_steps capped at 24 of the 400 for test time, same code path): raw clouds of
+    10 - 25 k points, ragged FPS to 1 024, released encoder / decoder widths, all matched pairs refined in lock-step.  Checked against
+    the oracle twin of the loop (oracle/optim.py, PARITY UNPINNED for torchlie / geomloss / roma) started from the same codes:
+    the choice of the shared code, the refined pose before ICP, the best loss; then _solve_end2end(optim=True) end to end."""
+    from livingscenes_amd import ops
+    from livingscenes_amd.lib_more.more_solver import More_Solver
+    from oracle import more, net
+    from oracle import optim as oo
+    sp, (ecfg, dcfg, ew, dw) = released_prior
+    dev = _dev()
+    steps = 24
+    cfg = {"shape_priors": {"n_input_point": 1024}, "fps": {"n_init": 1, "random_start": False},
+           "registration": {"optim": True, "step_size": {"so3": 0.05}, "n_steps": steps, "early_stop_threshold": 10}}
+    solver = More_Solver(cfg, model=sp)
+    sizes = [10000, 25000, 14000]
+
+    def scan(seed):
+        r = np.random.default_rng(seed)
+        clouds = []
+        for i, n in enumerate(sizes):
+            c = torch.as_tensor(synth.canonical_shape(n, 700 + i), dtype=torch.float32)
+            Rm = torch.as_tensor(synth._rand_rot(r), dtype=torch.float32)
+            clouds.append(c @ Rm.T + torch.as_tensor(r.uniform(-2, 2, 3), dtype=torch.float32))
+        return clouds
+    c1, c2 = scan(1), scan(2)
+    R, t, info = solver._solve_pairwise_registration_optim_batch([c.to(dev) for c in c1], [c.to(dev) for c in c2], icp=False, return_info=True)
+    assert info["steps"] == steps
+    # ---- the same three pairs through the oracle loop, from the HIP codes of the FPS-sampled clouds (encoder parity: test above)
+    P = 3
+    pc1 = torch.stack([c[net.sample_farthest_points(c[None], 1024)[1][0]] for c in c1])
+    pc2 = torch.stack([c[net.sample_farthest_points(c[None], 1024)[1][0]] for c in c2])
+    with torch.no_grad():
+        code = sp.encode(torch.cat([pc1, pc2], 0).transpose(1, 2).contiguous().to(dev))
+    code = {k: v.cpu() for k, v in code.items()}
+    k1 = {k: v[:P] for k, v in code.items()}
+    k2 = {k: v[P:] for k, v in code.items()}
+    err1 = net.field_query(dw, dcfg, pc1, k1).abs().mean(1)
+    err2 = net.field_query(dw, dcfg, pc2, k2).abs().mean(1)
+    reverse = err1 < err2                                                 # more_solver.py:124-135
+    assert np.array_equal(reverse.numpy(), info["reverse"].cpu().numpy())
+    se1, se2 = k1["z_so3"] + k1["t"], k2["z_so3"] + k2["t"]
+    R12, t12, _, _ = more.kabsch_transformation_estimation(se1, se2)
+    R21, t21, _, _ = more.kabsch_transformation_estimation(se2, se1)
+    pick = lambda a, b: torch.where(reverse.view(-1, *([1] * (a.dim() - 1))), a, b)
+    shared = {k: pick(k1[k], k2[k]) for k in k1}
+    src, tgt = pick(pc2, pc1), pick(pc1, pc2)
+    g0 = torch.cat([pick(R21, R12), pick(t21, t12)], 2)
+    st = oo.registration_loop(dw, dcfg, shared, src, tgt, g0, steps, 0.05, 10.0)
+    best = st.best_g
+    Rb = best[:, :, :3].transpose(1, 2)
+    best = pick(torch.cat([Rb, -(Rb @ best[:, :, 3:4])], 2), best)      # inverse for the reversed direction (:175-179)
+    assert relerr(info["pre_icp"], best) < 1e-3
+    assert relerr(info["min_loss"], st.min_loss) < 1e-3
+    for i in range(P):
+        assert abs(float(torch.det(R[i])) - 1) < 1e-4
+    # ---- end to end as eval_3rscan drives it: encode_fps -> matcher -> the same batched refinement -> ICP
+    mx = max(sizes)
+
+    def scene(clouds):
+        pc, mask = torch.zeros(3, 3, mx), torch.zeros(3, 1, mx, dtype=torch.bool)
+        for i, c in enumerate(clouds):
+            pc[i, :, :c.shape[0]] = c.T
+            mask[i, :, :c.shape[0]] = True
+        return {"pc": pc.to(dev), "pc_mask": mask.to(dev)}
+    out = solver._solve_end2end(scene(c1), scene(c2), optim=True, mesh=False)
+    assert out["matches"].tolist() == [0, 1, 2]
+    R2, t2 = solver._solve_pairwise_registration_optim_batch([c.to(dev) for c in c1], [c.to(dev) for c in c2], icp=True)
+    for i in range(P):
+        T = out["registration"][i][0]
+        assert abs(float(torch.det(T[:3, :3])) - 1) < 1e-4
+        assert relerr(T[:3, :3], R2[i]) < 1e-4 and relerr(T[:3, 3], t2[i, :, 0]) < 1e-4

@@ -1,12 +1,12 @@
 """BASELINE configs[1]+[2] at FULL batch, exactly as bench.py runs it: 64 instances x 1024 points (the 32-object scene and its
-rescan, seed 1000), 8 model handles on 8 streams all in flight, GPU_MAX_HW_QUEUES=16.  Kernel dispatch depends on B (candidate
+rescan, seed 1000), 12 model handles on 12 streams all in flight (the configuration bench.py times), GPU_MAX_HW_QUEUES=16.  Kernel dispatch depends on B (candidate
 split heuristics, un-split grids, XCD remap, handles sharing the chip), so the B <= 3 encoder parity cases of
 test_hip_parity.py do not cover this configuration.
 
 Checks (reference: model_utils.py:165-197, lib_more/matcher_new.py:109-139, lib_more/pose_estimation.py:29-102):
   * 8 instances spread over the batch (rows 0, 9, ..., 63) against oracle.net.shape_prior_encode: z_so3 / z_inv / s / t within
     1e-4 of max-norm, FPS and layer-0 k-NN indices exact, per-layer k-NN agreement > 99.5 %;
-  * all 8 handles return bit-identical codes, matches and poses (and equal to a later single traced pass);
+  * all 12 handles return bit-identical codes, matches and poses (and equal to a later single traced pass);
   * sequential_matcher assignments BIT-EXACT and Kabsch poses within 1e-4 against oracle.more run on the HIP codes.
 """
 import os
@@ -34,15 +34,15 @@ def relerr(a, b):
 def fullbatch(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("fullbatch") / "out.npz")
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
-    subprocess.run([sys.executable, os.path.join(REPO, "tests", "tools", "fullbatch_worker.py"), out, "32", "1024", "8"],
+    subprocess.run([sys.executable, os.path.join(REPO, "tests", "tools", "fullbatch_worker.py"), out, "32", "1024", "12"],
                    check=True, env=env, cwd=REPO, timeout=900)
     return dict(np.load(out))
 
 
 def test_fullbatch_handles_are_bit_identical(fullbatch):
     r = fullbatch
-    assert int(r["hw_queues"]) == 16 and int(r["handles"]) == 8
-    for i in range(1, 8):
+    assert int(r["hw_queues"]) == 16 and int(r["handles"]) == 12
+    for i in range(1, 12):
         for k in ("z_so3", "z_inv", "s", "t", "m0", "m1", "pose_R", "pose_t"):
             assert np.array_equal(r[f"h{i}_{k}"], r[f"h0_{k}"]), (i, k)
     for k in ("z_so3", "z_inv", "s"):

@@ -431,3 +431,18 @@ def test_3rscan_reader_matches_the_reference_loader(golden):
             same(f"s{i}_r{k}_", r)
             assert np.array_equal(r["moving_ids"].numpy(), g[f"s{i}_r{k}_moving_ids"]) and np.array_equal(r["static_ids"].numpy(), g[f"s{i}_r{k}_static_ids"])
             assert np.array_equal(r["rescan2ref_tsfm"].numpy(), g[f"s{i}_r{k}_rescan2ref_tsfm"])
+
+
+def test_packed_fp32_build_guard_fires_without_the_flag(tmp_path):
+    """build.py's determinism pin: edge.hip compiled WITHOUT -fno-slp-vectorize carries compiler-formed v_pk_*_f32 in the
+    gather kernels and the guard must refuse it; the objects of the real build pass."""
+    import subprocess
+    from livingscenes_amd import build as B
+    B.build()
+    B.check_packed_fp32(os.path.join(B.LIBDIR, "obj"))
+    flags = [f for f in B.FLAGS if f != "-fno-slp-vectorize"]
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-x", "hip", "-c", os.path.join(B.CSRC, "edge.hip"), "-o", str(tmp_path / "edge.o")])
+    import shutil
+    shutil.copy(os.path.join(B.LIBDIR, "obj", "pointwise.o"), tmp_path / "pointwise.o")
+    with pytest.raises(RuntimeError, match="packed fp32"):
+        B.check_packed_fp32(str(tmp_path))
