@@ -286,9 +286,20 @@ __device__ __forceinline__ void act43(F43& y, const F43& k, float oms) {
     vn_act(y.x.z, y.y.z, y.z.z, k.x.z, k.y.z, k.z.z, oms);
     vn_act(y.x.w, y.y.w, y.z.w, k.x.w, k.y.w, k.z.w, oms);
 }
+// (explicit fma chain, in this order: see vn_act in ls_common.h)
 __device__ __forceinline__ float dot43(const F43& a, const F43& b) {
-    return a.x.x * b.x.x + a.y.x * b.y.x + a.z.x * b.z.x + a.x.y * b.x.y + a.y.y * b.y.y + a.z.y * b.z.y +
-           a.x.z * b.x.z + a.y.z * b.y.z + a.z.z * b.z.z + a.x.w * b.x.w + a.y.w * b.y.w + a.z.w * b.z.w;
+    float s = a.x.x * b.x.x;
+    s = __builtin_fmaf(a.y.x, b.y.x, s); s = __builtin_fmaf(a.z.x, b.z.x, s);
+    s = __builtin_fmaf(a.x.y, b.x.y, s); s = __builtin_fmaf(a.y.y, b.y.y, s); s = __builtin_fmaf(a.z.y, b.z.y, s);
+    s = __builtin_fmaf(a.x.z, b.x.z, s); s = __builtin_fmaf(a.y.z, b.y.z, s); s = __builtin_fmaf(a.z.z, b.z.z, s);
+    s = __builtin_fmaf(a.x.w, b.x.w, s); s = __builtin_fmaf(a.y.w, b.y.w, s); s = __builtin_fmaf(a.z.w, b.z.w, s);
+    return s;
+}
+// acc += w * y on an xyz triple of four channels
+__device__ __forceinline__ void fma43(F43& acc, float w, const F43& y) {
+    acc.x.x = __builtin_fmaf(w, y.x.x, acc.x.x); acc.x.y = __builtin_fmaf(w, y.x.y, acc.x.y); acc.x.z = __builtin_fmaf(w, y.x.z, acc.x.z); acc.x.w = __builtin_fmaf(w, y.x.w, acc.x.w);
+    acc.y.x = __builtin_fmaf(w, y.y.x, acc.y.x); acc.y.y = __builtin_fmaf(w, y.y.y, acc.y.y); acc.y.z = __builtin_fmaf(w, y.y.z, acc.y.z); acc.y.w = __builtin_fmaf(w, y.y.w, acc.y.w);
+    acc.z.x = __builtin_fmaf(w, y.z.x, acc.z.x); acc.z.y = __builtin_fmaf(w, y.z.y, acc.z.y); acc.z.z = __builtin_fmaf(w, y.z.z, acc.z.z); acc.z.w = __builtin_fmaf(w, y.z.w, acc.z.w);
 }
 
 template <int LPP, int NCH>
@@ -336,6 +347,9 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     const float inv_q = 1.0f / fmaxf(sqrtf(group_sum<LPP>(ssq)), 1e-12f);
 
     // ---- B: K branch -> per-head scores for the 16 neighbours, Frobenius norms of k
+    // (rolled loops, two neighbours of loads per iteration: the software-pipelined form of edge_attn_fq_kernel was measured here too --
+    //  layers 5 / 6 have 8 192 / 2 048 destination points, a handful of waves per CU whose serial chain is the time either way, and the
+    //  48 prefetch registers cost a workgroup per CU: 48.6 / 33.8 -> 51.4 / 34.7 us.  Not kept.)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c4 = (ch * LPP + ll) * 4;
@@ -389,9 +403,7 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
             const F43 kd = add43(ld43(Tr + Co + c4, ldt), qd);
             act43(y, kd, oms);
             const float w = l_score[ch][k][tid];
-            acc.x.x += w * y.x.x; acc.x.y += w * y.x.y; acc.x.z += w * y.x.z; acc.x.w += w * y.x.w;
-            acc.y.x += w * y.y.x; acc.y.y += w * y.y.y; acc.y.z += w * y.y.z; acc.y.w += w * y.y.w;
-            acc.z.x += w * y.z.x; acc.z.y += w * y.z.y; acc.z.z += w * y.z.z; acc.z.w += w * y.z.w;
+            fma43(acc, w, y);
         }
         const float inv = 1.0f / sum[ch];
         const float4 ox = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
@@ -486,7 +498,7 @@ int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipS
 }
 
 template <int LPP, int CIN>
-__global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
                                                            const uint4* __restrict__ Wp, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, float oms, float inv_sqrt_dk,
                                                            float* __restrict__ out, int total, float* __restrict__ rowmax) {
@@ -588,20 +600,41 @@ __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restri
     __syncthreads();   // every wave has its q: the slab may be overwritten
 
     // ---- B: K branch -> per-head scores for the 16 neighbours, normalised by the Frobenius norm of k
+    // The gathers are a two-deep software pipeline (round 3): the 16 neighbour indices sit in registers (four 16-byte loads up front
+    // instead of a dependent index load in front of every row gather) and the rows of neighbours k+1, k+2 are in flight while
+    // neighbour k is activated.  The rolled loop it replaces ran index load -> wait -> twelve row loads -> wait -> compute, two full
+    // L2 round trips per pair of neighbours with nothing of one iteration overlapping the next (s_waitcnt vmcnt(0) at the loop top).
+    int nb[EK];
+    {
+        const int4* kp = reinterpret_cast<const int4*>(ki);
+#pragma unroll
+        for (int u = 0; u < EK / 4; ++u) { const int4 v = kp[u]; nb[4 * u] = v.x; nb[4 * u + 1] = v.y; nb[4 * u + 2] = v.z; nb[4 * u + 3] = v.w; }
+    }
+    auto nrow = [&](int k) { return Tb + (size_t)nb[k] * 3 * ldt + c4; };
     qgemm(2 * Co);
     __syncthreads();
     {
+        F43 py0 = ld43(nrow(0) + 2 * Co, ldt), pd0 = ld43(nrow(0) + 3 * Co, ldt);
+        F43 py1 = ld43(nrow(1) + 2 * Co, ldt), pd1 = ld43(nrow(1) + 3 * Co, ldt);
         const F43 ql = lds43(0), qd = lds43(Co);
-#pragma unroll 2
+#pragma unroll
         for (int k = 0; k < EK; ++k) {
-            const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
-            F43 y = add43(ld43(Tr + 2 * Co + c4, ldt), ql);
-            const F43 kd = add43(ld43(Tr + 3 * Co + c4, ldt), qd);
+            F43 y = py0, kd = pd0;
+            py0 = py1; pd0 = pd1;
+            if (k + 2 < EK) { py1 = ld43(nrow(k + 2) + 2 * Co, ldt); pd1 = ld43(nrow(k + 2) + 3 * Co, ldt); }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this neighbour's arithmetic (the scheduler would sink it to its first use)
+            y = add43(y, ql);
+            kd = add43(kd, qd);
             act43(y, kd, oms);
             const float invk = 1.0f / fmaxf(sqrtf(group_sum<LPP>(dot43(y, y))), 1e-12f);
             l_score[k][tid] = quad_sum(dot43(y, qf)) * inv_q * invk * inv_sqrt_dk;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // (the row addresses are re-derived from the indices in phase C: sixteen 64-bit addresses kept alive across the soft-max cost
+    //  more registers than the two instructions that rebuild each)
+#pragma unroll
+    for (int k = 0; k < EK; ++k) asm volatile("" : "+v"(nb[k]));
     __syncthreads();   // done with the k slab
     qgemm(0);
     float mx = -INFINITY, sum = 0.f;
@@ -620,16 +653,20 @@ __global__ __launch_bounds__(256) void edge_attn_fq_kernel(const float* __restri
         const F43 ql = lds43(0), qd = lds43(Co);
         F43 acc;
         acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
+        F43 py0 = ld43(nrow(0), ldt), pd0 = ld43(nrow(0) + Co, ldt);
+        F43 py1 = ld43(nrow(1), ldt), pd1 = ld43(nrow(1) + Co, ldt);
+#pragma unroll
         for (int k = 0; k < EK; ++k) {
-            const float* Tr = Tb + (size_t)ki[k] * 3 * ldt;
-            F43 y = add43(ld43(Tr + c4, ldt), ql);
-            const F43 kd = add43(ld43(Tr + Co + c4, ldt), qd);
+            F43 y = py0, kd = pd0;
+            py0 = py1; pd0 = pd1;
+            if (k + 2 < EK) { py1 = ld43(nrow(k + 2), ldt); pd1 = ld43(nrow(k + 2) + Co, ldt); }
+            __builtin_amdgcn_sched_barrier(0);
+            y = add43(y, ql);
+            kd = add43(kd, qd);
             act43(y, kd, oms);
             const float w = l_score[k][tid];
-            acc.x.x += w * y.x.x; acc.x.y += w * y.x.y; acc.x.z += w * y.x.z; acc.x.w += w * y.x.w;
-            acc.y.x += w * y.y.x; acc.y.y += w * y.y.y; acc.y.z += w * y.y.z; acc.y.w += w * y.y.w;
-            acc.z.x += w * y.z.x; acc.z.y += w * y.z.y; acc.z.z += w * y.z.z; acc.z.w += w * y.z.w;
+            fma43(acc, w, y);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float inv = 1.0f / sum;
         const float4 ox = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);

@@ -98,11 +98,14 @@ __device__ __forceinline__ float acc_sq(float d, float diff) {
 // With p = <y,k> un-normalised this is  y - (1-slope) * min(p,0) / max(|k|^2, 1e-24) * k : one v_rcp_f32 instead of a
 // correctly rounded sqrt and division (~14 instead of ~40 VALU operations per 3-vector; the edge kernels apply it per edge and
 // channel).  Differs from the reference's operation order at the 1e-7 level, like the rest of the folded edge-conv.
+// Every multiply-add is SPELLED as an fma (round 3): with -ffp-contract=fast the compiler chose which products to fuse per call site, and
+// two kernels that must agree bit for bit (the fused-destination attention kernel and the table path) stopped agreeing in the last bit
+// once their loops were restructured differently.
 __device__ __forceinline__ void vn_act(float& y0, float& y1, float& y2, float k0, float k1, float k2, float one_minus_slope) {
-    const float n2 = k0 * k0 + k1 * k1 + k2 * k2;
-    const float p = y0 * k0 + y1 * k1 + y2 * k2;
+    const float n2 = __builtin_fmaf(k2, k2, __builtin_fmaf(k1, k1, k0 * k0));
+    const float p = __builtin_fmaf(y2, k2, __builtin_fmaf(y1, k1, y0 * k0));
     const float f = one_minus_slope * fminf(p, 0.0f) * __builtin_amdgcn_rcpf(fmaxf(n2, 1e-24f));
-    y0 -= f * k0; y1 -= f * k1; y2 -= f * k2;
+    y0 = __builtin_fmaf(-f, k0, y0); y1 = __builtin_fmaf(-f, k1, y1); y2 = __builtin_fmaf(-f, k2, y2);
 }
 
 // operand range of the f16-split GEMMs (gemm.hip, "operand range of the f16 split"): optional caller-supplied row maxima

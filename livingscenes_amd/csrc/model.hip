@@ -117,6 +117,9 @@ struct ls_model {
                                    // race hunting by comparing workspaces (scripts/diag/)
     bool fps_side = true;          // LS_FPS_SIDE=0 runs the FPS chain on the caller's stream (A/B timing, race hunting)
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
+    unsigned skip_mask = 0;        // LS_SKIP=knn,attn,...: dev timing knob -- after LS_SKIP_AFTER (default 3) ls_encode calls on this handle the named
+    int skip_after = 3, calls = 0; // launches are skipped (their outputs keep the previous call's values): marginal cost of a kernel family
+                                   // with many steps in flight.  Results are then STALE: never set outside scripts/dev.
     bool profiling = false;
     std::vector<ProfRec> prof;          // pending (un-collected) event pairs
     std::vector<hipEvent_t> ev_pool;    // recycled events
@@ -521,6 +524,11 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     if (const char* ev = getenv("LS_KNN_HINTS")) m->hint_policy = !strcmp(ev, "prev") ? 1 : (!strcmp(ev, "auto") ? 2 : 0);
     if (const char* ev = getenv("LS_SDF_BF16X2")) m->sdf_bf16x2 = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_FILTER")) m->knn_filter = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_SKIP")) {
+        const char* names[] = {"knn", "attn", "pool", "l0", "tables", "glob", "fps", "tail", "prologue"};
+        for (int i = 0; i < 9; ++i) if (strstr(ev, names[i])) m->skip_mask |= 1u << i;
+        if (const char* ea = getenv("LS_SKIP_AFTER")) m->skip_after = atoi(ea);
+    }
     hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
     if (e != hipSuccess) { delete m; set_error("hipMalloc(model blob): %s", hipGetErrorString(e)); return LS_ERR_HIP; }
     e = hipMemcpy(m->blob, blob_host, (size_t)desc->blob_floats * sizeof(float), hipMemcpyHostToDevice);
@@ -617,10 +625,13 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
     float* pts0 = F(p.o_pts[0]);
     float* centroid = F(p.o_centroid);
     float* scale0 = F(p.o_scale0);
+    const unsigned skip = (m->skip_mask && m->calls++ >= m->skip_after) ? m->skip_mask : 0u;   // dev timing knob (LS_SKIP), see ls_model
+    enum { SK_KNN = 1, SK_ATTN = 2, SK_POOL = 4, SK_L0 = 8, SK_TABLES = 16, SK_GLOB = 32, SK_FPS = 64, SK_TAIL = 128, SK_PROLOGUE = 256 };
 
     {
         PROF(LS_K_PROLOGUE, 0, st);
-        if (pre_normalised) rc = transpose_cloud_launch(x, B, N, pts0, st);
+        if (skip & SK_PROLOGUE) rc = LS_OK;
+        else if (pre_normalised) rc = transpose_cloud_launch(x, B, N, pts0, st);
         else rc = prologue_launch(x, B, N, pts0, centroid, scale0, F(p.o_pro), st);
     }
     if (rc != LS_OK) return rc;
@@ -638,7 +649,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             toff += (size_t)B * p.levelN[l + 1];
             {
                 PROF(LS_K_FPS, l, fs);
-                rc = fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), nullptr, 0, fs);
+                rc = (skip & SK_FPS) ? LS_OK : fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), nullptr, 0, fs);
             }
             if (rc != LS_OK) return rc;
         }
@@ -680,10 +691,10 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
         float* mp = glob ? msg : nxt;
         bool msg_rm = false;
         if (i == 0) {
-            { PROF(LS_K_KNN, i, st); rc = knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
+            { PROF(LS_K_KNN, i, st); rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
             if (rc != LS_OK) return rc;
             LS_REQUIRE(!attn, "encoder: attention at layer 0 unsupported (atten_start_layer >= 1)");
-            { PROF(LS_K_EDGE_L0, i, st); rc = edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
+            { PROF(LS_K_EDGE_L0, i, st); rc = (skip & SK_L0) ? LS_OK : edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
         } else {
             const int Cin = p.Cin[i];
@@ -695,7 +706,8 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 LS_HIP_CHECK(hipStreamWaitEvent(gs, m->ev_feat[i], 0));
             }
             EdgeTables et;
-            rc = edge_tables(m, i, cur, dst_rows, B, Ns, Nd, T, gs, et, cur_rm, cur_rm_parts);
+            if (skip & SK_TABLES) { et = edge_tables_layout(m, i, cur, dst_rows, B, Ns, Nd, T); rc = LS_OK; }
+            else rc = edge_tables(m, i, cur, dst_rows, B, Ns, Nd, T, gs, et, cur_rm, cur_rm_parts);
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
             { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
@@ -713,16 +725,18 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                     if (rc != LS_OK) return rc;
                     seeds = I(p.o_hint);
                 }
-                rc = knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
+                rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
-            rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm);
+            if (skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) rc = LS_OK;
+            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm);
             if (rc != LS_OK) return rc;
         }
         cur_rm = nullptr; cur_rm_parts = 0;
         if (glob) {
             bool out_rm = false;
-            rc = global_conv(m, i, msg, B, Nd, F(p.o_g), F(p.o_G), F(p.o_TG), F(p.o_gws), nxt, st, msg_rm ? F(p.o_rm_msg) : nullptr,
+            if (skip & SK_GLOB) rc = LS_OK;
+            else rc = global_conv(m, i, msg, B, Nd, F(p.o_g), F(p.o_G), F(p.o_TG), F(p.o_gws), nxt, st, msg_rm ? F(p.o_rm_msg) : nullptr,
                              F(p.o_rm_out[i & 1]), &out_rm);
             if (rc != LS_OK) return rc;
             if (out_rm) { cur_rm = F(p.o_rm_out[i & 1]); cur_rm_parts = Co / 32; }
@@ -734,6 +748,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
     if (p.nlevels > 0 && !joined && m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
 
     // ---- tail
+    if (skip & SK_TAIL) return LS_OK;
     return encoder_tail(m, cur, B, p.NP, F(p.o_Tc), F(p.o_gws), pre_normalised ? nullptr : centroid, pre_normalised ? nullptr : scale0,
                         z_so3, z_inv, s_out, t_out, st, cur_rm, cur_rm_parts);
 }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# marginal cost of each kernel family in the 12-in-flight bench: skip the family's launches after the warm-up (stale results; timing only)
+out=gpurun_out/$1; mkdir -p $out
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['value']), d['ms_per_step'])"; }
+python bench.py --cpu-instances 0 --no-profile --no-fma-variant 2>/dev/null | tail -1 | line none >> $out/marginal.log
+for fam in knn attn pool l0 tables glob fps tail prologue "knn,attn" "knn,attn,tables,glob" "knn,attn,tables,glob,fps,pool,l0,tail,prologue"; do
+  LS_SKIP=$fam python bench.py --cpu-instances 0 --no-profile --no-fma-variant 2>/dev/null | tail -1 | line $fam >> $out/marginal.log
+done
+python bench.py --cpu-instances 0 --no-profile --no-fma-variant 2>/dev/null | tail -1 | line none >> $out/marginal.log
+for fam in knn attn tables glob fps; do
+  LS_SKIP=$fam python bench.py --cpu-instances 0 --no-profile --no-fma-variant --inflight 1 2>/dev/null | tail -1 | line "1fl:$fam" >> $out/marginal.log
+done
+python bench.py --cpu-instances 0 --no-profile --no-fma-variant --inflight 1 2>/dev/null | tail -1 | line "1fl:none" >> $out/marginal.log
+cat $out/marginal.log
