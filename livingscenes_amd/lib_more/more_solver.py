@@ -290,12 +290,20 @@ def _scene_clouds(scene):
     return [pc.T[mask.reshape(-1).bool()] for pc, mask in zip(scene["pc"], scene["pc_mask"])]
 
 
-def solve_end2end_batch(solver, pairs, mesh=False):
+def solve_end2end_batch(solver, pairs, mesh=False, optim=False, sharded=False, optim_chunk=128):
     """Batched form of More_Solver._solve_end2end over MANY (reference scan, rescan) pairs -- an extension the reference lacks
     (eval_3rscan.py walks the scenes one pair at a time): every scan of every pair goes through ONE ragged FPS launch and ONE
-    encoder batch, every matched pair of every scene through ONE registration batch (ragged FPS, encode, Kabsch, ICP).  The
-    ragged FPS runs one workgroup per raw cloud (18 ms for a 60 000-point cloud), so a single scene pair leaves the GPU idle;
-    hundreds of clouds per launch fill it.  Returns one dict per pair, as _solve_end2end (optim=False)."""
+    encoder batch, every matched pair of every scene through ONE registration batch (ragged FPS, encode, Kabsch, ICP; optim=True:
+    the 400-step refinement in lock-step, optim_chunk pairs per call).  The ragged FPS runs one workgroup per raw cloud (18 ms for a
+    60 000-point cloud), so a single scene pair leaves the GPU idle; hundreds of clouds per launch fill it.  Returns one dict per
+    pair, as _solve_end2end.
+
+    sharded=True (one process per GPU, torch.distributed initialised; SURVEY.md 8e, eval_3rscan.py:337-463 sharded over the node):
+    the flat (scene, instance) list is block-partitioned over the ranks for FPS + encode and the codes all-gathered (4.1 KB each);
+    the per-scene matchers run replicated (deterministic, 32 x 32); the flat list of matched pairs is block-partitioned again for
+    the registration and the (R | t) rows all-gathered (48 B per pair); every rank then holds every pose and every transformed code,
+    and meshes the pairs of ITS block (the SDF grids and meshes stay on the rank that made them: mesh_lst is None elsewhere)."""
+    from .. import sharding
     scans, where = [], []
     for ref, res in pairs:
         where.append((len(scans), len(scans) + 1))
@@ -303,13 +311,16 @@ def solve_end2end_batch(solver, pairs, mesh=False):
     clouds = [_scene_clouds(s) for s in scans]
     flat = [c for cl in clouds for c in cl]
     dev = flat[0].device
-    lens = torch.tensor([c.shape[0] for c in flat], device=dev)
-    buf = torch.zeros(len(flat), 3, int(lens.max()), device=dev)
-    mask = torch.zeros(len(flat), 1, int(lens.max()), dtype=torch.bool, device=dev)
-    for i, c in enumerate(flat):
-        buf[i, :, : c.shape[0]] = c.T
-        mask[i, :, : c.shape[0]] = True
-    codes = solver.model.encode_fps(buf, mask)
+    if sharded:
+        codes = sharding.sharded_encode_fps(solver.model, flat)
+    else:
+        lens = torch.tensor([c.shape[0] for c in flat], device=dev)
+        buf = torch.zeros(len(flat), 3, int(lens.max()), device=dev)
+        mask = torch.zeros(len(flat), 1, int(lens.max()), dtype=torch.bool, device=dev)
+        for i, c in enumerate(flat):
+            buf[i, :, : c.shape[0]] = c.T
+            mask[i, :, : c.shape[0]] = True
+        codes = solver.model.encode_fps(buf, mask)
     starts = [0]
     for cl in clouds:
         starts.append(starts[-1] + len(cl))
@@ -326,7 +337,16 @@ def solve_end2end_batch(solver, pairs, mesh=False):
                 reg1.append(clouds[a][i]); reg2.append(clouds[b][j]); slots.append((p, i, j))
         outs.append(out)
     if slots:
-        R, t = solver._solve_pairwise_registration_batch(reg1, reg2)
+        def register(lo, hi):
+            if not optim:
+                return solver._solve_pairwise_registration_batch(reg1[lo:hi], reg2[lo:hi])
+            Rs, ts = [], []
+            for c0 in range(lo, hi, optim_chunk):
+                Rc, tc = solver._solve_pairwise_registration_optim_batch(reg1[c0:min(hi, c0 + optim_chunk)], reg2[c0:min(hi, c0 + optim_chunk)])
+                Rs.append(Rc), ts.append(tc)
+            return torch.cat(Rs, 0), torch.cat(ts, 0)
+        R, t = sharding.sharded_pairs(len(slots), register) if sharded else register(0, len(slots))
+        mine = range(*sharding.shard_range(len(slots))) if sharded else range(len(slots))     # the pairs this rank meshes
         T = Rt_to_SE3(R, t)
         for k, (p, i, j) in enumerate(slots):
             out = outs[p]
@@ -336,8 +356,9 @@ def solve_end2end_batch(solver, pairs, mesh=False):
         if mesh:
             import numpy as np
             group = 16                                     # instances whose MISE rounds advance in lock-step
-            for g0 in range(0, len(slots), group):
-                part = slots[g0:g0 + group]
+            own = [slots[k] for k in mine]
+            for g0 in range(0, len(own), group):
+                part = own[g0:g0 + group]
                 cl = [outs[p]["codes"][i] for p, i, _ in part]
                 canon = {k: torch.cat([c[k] for c in cl], 0) for k in ("z_so3", "z_inv")}
                 canon["t"] = torch.zeros_like(torch.cat([c["t"] for c in cl], 0))   # canonical pose, as model_utils.py:296-298

@@ -84,6 +84,30 @@ def all_gather_codes(emb, counts=None):
     return unpack_codes(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(dev))
 
 
+def all_gather_rows(rows, counts):
+    """All ranks receive the float rows [n_r, W] of all ranks, concatenated in rank order (counts[r] = n_r; ragged and EMPTY shards are
+    padded to the largest, so every rank always takes part).  The generic form of all_gather_codes: also carries the (R | t) rows of the
+    registration results (12 floats = 48 B per pair)."""
+    rank, ws = world()
+    if ws == 1:
+        return rows
+    mx = max(max(counts), 1)
+    pad = rows.new_zeros(mx, rows.shape[1])
+    pad[: rows.shape[0]] = rows
+    dev = pad.device
+    if _host_staged():
+        pad = pad.cpu()
+    bufs = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(dev)
+
+
+def shard_counts(n_items, world_size=None):
+    if world_size is None:
+        world_size = world()[1]
+    return [shard_range(n_items, r, world_size)[1] - shard_range(n_items, r, world_size)[0] for r in range(world_size)]
+
+
 def gather_codes(emb, dst=0, counts=None):
     """Rank `dst` receives all codes (rank order); other ranks get None."""
     rank, ws = world()
@@ -117,3 +141,64 @@ def sharded_encode(model, x_all):
         emb = empty_codes(model.encoder.c_dim, x_all.device)
     counts = [shard_range(n, r, ws)[1] - shard_range(n, r, ws)[0] for r in range(ws)]
     return all_gather_codes(emb, counts)
+
+
+def sharded_encode_fps(model, clouds):
+    """Shape_Prior.encode_fps over a LIST of raw clouds [Ni,3] (the flat (scene, instance) list of SURVEY 8e): every rank samples and
+    encodes its block (one ragged FPS launch + one encoder batch per rank), the codes are all-gathered.  Same list on every rank."""
+    rank, ws = world()
+    n = len(clouds)
+    lo, hi = shard_range(n, rank, ws)
+    dev = clouds[0].device
+    if hi > lo:
+        mine = clouds[lo:hi]
+        mx = max(c.shape[0] for c in mine)
+        buf = torch.zeros(hi - lo, 3, mx, device=dev)
+        mask = torch.zeros(hi - lo, 1, mx, dtype=torch.bool, device=dev)
+        for i, c in enumerate(mine):
+            buf[i, :, : c.shape[0]] = c.T
+            mask[i, :, : c.shape[0]] = True
+        emb = model.encode_fps(buf, mask)
+    else:
+        emb = empty_codes(model.encoder.c_dim, dev)
+    return all_gather_codes(emb, shard_counts(n, ws))
+
+
+def sharded_pairs(n_pairs, register_block):
+    """Block-partition a list of n_pairs registration problems: `register_block(lo, hi)` -> (R [hi-lo,3,3], t [hi-lo,3,1]) for this
+    rank's block (never called on an empty block); the (R | t) rows are all-gathered: -> (R [n,3,3], t [n,3,1]) on every rank."""
+    rank, ws = world()
+    lo, hi = shard_range(n_pairs, rank, ws)
+    if hi > lo:
+        R, t = register_block(lo, hi)
+        rows = torch.cat([R.reshape(hi - lo, 9), t.reshape(hi - lo, 3)], 1).contiguous()
+    else:
+        rows = None
+    if rows is None:   # an empty block still needs a device / dtype for its zero-row message
+        rows = torch.zeros(0, 12, device=_some_device(), dtype=torch.float32)
+    allr = all_gather_rows(rows, shard_counts(n_pairs, ws))
+    return allr[:, :9].reshape(-1, 3, 3), allr[:, 9:].reshape(-1, 3, 1)
+
+
+def _some_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def sharded_sdf_grid(model, codes, query, gather=False):
+    """configs[4] (dense SDF reconstruction, instances sharded over the node): codes = dict with n rows, query [n,M,3] (or [1,M,3]
+    shared by all instances).  Every rank decodes ITS block of instances -> (lo, hi, sdf [hi-lo, M]); the grids stay on the rank that
+    made them (8 MB per 128^3 instance: the mesh step runs where the grid is) unless gather=True (then every rank gets [n, M])."""
+    rank, ws = world()
+    n = codes["z_inv"].shape[0]
+    lo, hi = shard_range(n, rank, ws)
+    M = query.shape[1]
+    dev = codes["z_inv"].device
+    if hi > lo:
+        q = query.expand(n, -1, -1)[lo:hi].contiguous() if query.shape[0] == 1 else query[lo:hi].contiguous()
+        part = {k: v[lo:hi].contiguous() for k, v in codes.items()}
+        sdf = model.decoder(q, None, part, return_sdf=True)
+    else:
+        sdf = torch.zeros(0, M, device=dev)
+    if not gather:
+        return lo, hi, sdf
+    return lo, hi, all_gather_rows(sdf, shard_counts(n, ws))

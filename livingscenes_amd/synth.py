@@ -192,3 +192,25 @@ def make_queries(B, M, seed=0, box=1.1):
     """SDF query points ~ U(-box/2, box/2)^3 (MISE box size 1.1, mesh_extractor2.py:100)."""
     r = _rng(seed, "queries").random((B, M, 3))
     return torch.from_numpy(((r - 0.5) * box).astype(np.float32))
+
+
+def make_raw_scan(shapes, seed, pmin=1024, pmax=60000, device=None):
+    """A 3RScan-like scan for configs[3]: one raw cloud of pmin .. pmax points per instance (re-sampled canonical shape `shapes[i]` under
+    a random rigid motion), zero-padded to the largest with a validity mask -- the dict Shape_Prior.encode_fps / More_Solver._solve_end2end
+    take (eval_3rscan.py:78-95 heterogeneous batching).  -> ({'pc' [n,3,Pmax], 'pc_mask' [n,1,Pmax]}, total points)."""
+    r = np.random.default_rng(seed)
+    clouds = []
+    for s_ in shapes:
+        P = int(np.exp(r.uniform(np.log(pmin), np.log(pmax))))
+        c = torch.as_tensor(canonical_shape(P, int(s_)), dtype=torch.float32)
+        Rm = torch.as_tensor(_rand_rot(r), dtype=torch.float32)
+        clouds.append(c @ Rm.T + torch.as_tensor(r.uniform(-2, 2, 3), dtype=torch.float32))
+    mx = max(c.shape[0] for c in clouds)
+    pc = torch.zeros(len(clouds), 3, mx)
+    mask = torch.zeros(len(clouds), 1, mx, dtype=torch.bool)
+    for i, c in enumerate(clouds):
+        pc[i, :, :c.shape[0]] = c.T
+        mask[i, :, :c.shape[0]] = True
+    if device is not None:
+        pc, mask = pc.to(device), mask.to(device)
+    return {"pc": pc, "pc_mask": mask}, sum(c.shape[0] for c in clouds)

@@ -747,3 +747,91 @@ def test_sharded_encode_world_size_2_on_one_device(tmp_path):
     for r, p in enumerate(procs):
         out, err = p.communicate(timeout=600)
         assert p.returncode == 0 and f"rank {r} ok" in out, err[-3000:]
+
+
+_SHARD_E2E_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from livingscenes_amd import sharding, synth
+from livingscenes_amd.lib_more.more_solver import More_Solver, solve_end2end_batch
+from livingscenes_amd.model_utils import Shape_Prior
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% int(sys.argv[1]), rank=int(sys.argv[2]), world_size=int(sys.argv[3]))
+rank = dist.get_rank()
+dev = torch.device("cuda:0")
+ecfg, dcfg = synth.small_encoder_cfg(), synth.small_decoder_cfg()
+sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 4), synth.make_decoder_weights(dcfg, 4), device=dev, n_pcl=128)
+cfg = {"shape_priors": {"n_input_point": 128}, "fps": {"n_init": 1},
+       "registration": {"step_size": {"so3": 0.01}, "n_steps": 8, "early_stop_threshold": 10},
+       "mesh_extractor": dict(threshold=0.5, resolution0=16, upsampling_steps=1, padding=0.1, points_batch_size=100000)}
+solver = More_Solver(cfg, model=sp)
+rng = np.random.default_rng(2)
+pairs = []
+for s, n in enumerate((3, 1, 4)):                  # 3 scene pairs, 16 instances in all: ragged blocks; 7 matched pairs: 4 + 3
+    shapes = rng.integers(0, 10 ** 6, n)
+    pairs.append((synth.make_raw_scan(shapes, 10 * s, 200, 900, device=dev)[0], synth.make_raw_scan(shapes, 10 * s + 1, 200, 900, device=dev)[0]))
+code0 = sp.encode_fps(pairs[0][0]["pc"][:1], pairs[0][0]["pc_mask"][:1])
+canon = {k: v.clone() for k, v in code0.items()}
+canon["t"], canon["s"] = torch.zeros_like(canon["t"]), torch.ones_like(canon["s"])
+solver.mesh_extractor.threshold = 1.0 / (1.0 + np.exp(-float(np.median(solver.mesh_extractor.eval_grid(canon, sp.decoder)))))
+whole = solve_end2end_batch(solver, pairs, mesh=True)
+part = solve_end2end_batch(solver, pairs, mesh=True, sharded=True)
+n_slots = sum(int((w["matches"] >= 0).sum()) for w in whole)
+lo, hi = sharding.shard_range(n_slots)
+k = 0
+for w, o in zip(whole, part):
+    assert torch.equal(w["matches"], o["matches"])
+    for i, (a, b) in enumerate(zip(w["registration"], o["registration"])):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        assert torch.equal(a, b), "pose: sharded != unsharded"
+        assert all(torch.equal(w["codes"][i][key], o["codes"][i][key]) for key in ("z_so3", "z_inv", "s", "t"))
+        mine = lo <= k < hi                          # meshes live on the rank that owns the pair
+        assert (o["mesh_lst"][i] is not None) == mine, (k, lo, hi)
+        if mine:
+            assert np.array_equal(np.asarray(w["mesh_lst"][i].vertices), np.asarray(o["mesh_lst"][i].vertices))
+            assert np.array_equal(np.asarray(w["mesh_lst"][i].faces), np.asarray(o["mesh_lst"][i].faces))
+        k += 1
+# the optim=True branch (eval_3rscan.py:381): 8 steps, every pair advances exactly as if alone
+wo = solve_end2end_batch(solver, pairs, optim=True)
+po = solve_end2end_batch(solver, pairs, optim=True, sharded=True)
+for w, o in zip(wo, po):
+    for a, b in zip(w["registration"], o["registration"]):
+        assert (a is None) == (b is None) and (a is None or float((a - b).abs().max()) < 1e-5)
+# configs[4]: dense grids by instance block
+x = synth.make_instances(5, 128, seed=3).to(dev)
+codes = sp.encode(x)
+q = synth.make_queries(1, 4096, seed=1).to(dev)
+full = sp.decoder(q.expand(5, -1, -1).contiguous(), None, codes, return_sdf=True)
+b0, b1, loc = sharding.sharded_sdf_grid(sp, codes, q)
+assert torch.equal(loc, full[b0:b1])
+_, _, allg = sharding.sharded_sdf_grid(sp, codes, q, gather=True)
+assert torch.equal(allg, full)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_end2end_and_dense_world_size_2_on_one_device(tmp_path):
+    """configs[3] / configs[4] sharded (eval_3rscan.py:337-463,466-502) with the real kernels: two processes (gloo, both on
+    cuda:0) run solve_end2end_batch(sharded=True) -- block-partitioned FPS + encode, all-gathered codes, replicated matchers,
+    block-partitioned Kabsch + ICP (and the optim refinement), all-gathered (R | t), meshes on the owning rank -- and the dense SDF
+    grids by instance block: every pose, code, mesh and grid equals the unsharded run BIT FOR BIT (optim=True: 1e-5)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "shard_e2e_worker.py"
+    script.write_text(_SHARD_E2E_WORKER % os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(port), str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0 and f"rank {r} ok" in out, err[-3000:]
