@@ -200,9 +200,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from livingscenes_amd import sharding as parallel, synth
+    from livingscenes_amd import ops, sharding as parallel, synth
     from livingscenes_amd.lib_more.matcher_new import sequential_matcher
-    from livingscenes_amd.lib_more.pose_estimation import kabsch_transformation_estimation
     from livingscenes_amd.model_utils import Shape_Prior
 
     if args.inflight > 1:
@@ -234,10 +233,9 @@ def main():
     def step(sp=sp):
         emb = sp.encode(x)
         m = sequential_matcher(emb["z_inv"][:n_obj], emb["z_inv"][n_obj:])
-        j = m["matches0"].clamp(min=0)
-        p1 = emb["z_so3"][:n_obj] + emb["t"][:n_obj]
-        p2 = (emb["z_so3"][n_obj:] + emb["t"][n_obj:]).index_select(0, j)
-        R, t, _, _ = kabsch_transformation_estimation(p1, p2)
+        # kabsch_transformation_estimation(z_so3 + t of the reference objects, z_so3 + t of their matches) (more_solver.py:114-116): the
+        # sums, the gather by matches0 and its clamp happen inside the Kabsch launch (ls_kabsch_codes_f32), no ATen kernel in the step
+        R, t = ops.kabsch_codes(emb["z_so3"][:n_obj], emb["t"][:n_obj], emb["z_so3"][n_obj:], emb["t"][n_obj:], sel2=m["matches0"])
         return emb, m, R, t
 
     def barrier():

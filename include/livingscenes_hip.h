@@ -157,6 +157,12 @@ int ls_greedy_match_f32(float* scores, int n, int m, int64_t* matches0, int64_t*
  *   (only LS_KABSCH_NONFINITE corresponds to the reference's SVD-failure branch at :79-88). */
 int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, unsigned flags, float* R,
                           float* t, float* res, int32_t* flags_out, void* stream);
+/* The same fit on More_Solver's pseudo-points (more_solver.py:114-116: kabsch(code1.z_so3 + code1.t, code2.z_so3 + code2.t)) with the
+ * element-wise work around it inside the launch: set i of side k is x_k[i] + off_k[i] (off_k [*,3] or NULL), problem p reads set
+ * sel_k[p] of side k (sel_k [b] int64 or NULL = p; a negative entry -- an unmatched row of matches0 -- reads set 0, as
+ * matches0.clamp(min=0) does).  Unit weights.  Bit-identical to ls_kabsch_batched_f32 on the materialised sums. */
+int ls_kabsch_codes_f32(const float* x1, const float* off1, const int64_t* sel1, const float* x2, const float* off2, const int64_t* sel2, int b,
+                        int n, float* R, float* t, float* res, int32_t* flags_out, void* stream);
 
 /* mean Kabsch residual of every (src i, tgt j) pair of equivariant codes: res_mat of
  * matcher_new.py:150-156 / :196-202.   src [n,P,3], tgt [m,P,3] -> res [n,m] */
@@ -336,6 +342,22 @@ typedef struct ls_softmin_problem {
     int N, M;
 } ls_softmin_problem;
 int ls_sinkhorn_softmin_multi_f32(const ls_softmin_problem* problems, int count, const float* eps, int average, int P, void* stream);
+/* More_Solver._optimize_code's loss and optimizer on the device (more_solver.py:199-221: MSELoss(sdf, 0), torch.optim.Adam with three
+ * parameter groups -- z_inv 1e-5, t 1e-4, z_so3 5e-4 -- MultiStepLR([160]), best-loss bookkeeping):
+ *   ls_mse_f32: loss[p] = mean_i sdf[p,i]^2, grad_sdf[p,i] = 2 sdf[p,i] / N; min_loss / improved (nullable, [P]): if loss[p] <
+ *               min_loss[p] then min_loss[p] = loss[p], improved[p] = 1 (:219-221);
+ *   ls_adam_step_f32: one Adam step (no weight decay, no amsgrad, torch's operation order) on up to four tensors, each with its own
+ *               learning rate; step = 0-based step count (bias corrections use step + 1). */
+typedef struct ls_adam_group {
+    float* param;
+    const float* grad;
+    float* m;
+    float* v;
+    long long n;
+    float lr;
+} ls_adam_group;
+int ls_mse_f32(const float* sdf, int P, int N, float* loss, float* grad_sdf, float* min_loss, int32_t* improved, void* stream);
+int ls_adam_step_f32(const ls_adam_group* groups, int count, float beta1, float beta2, float adam_eps, int step, void* stream);
 int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float* loss, int P, int N, float lr, float beta1, float beta2,
                          float adam_eps, int step, float stop_angle, float* g, float* m1, float* m2, float* min_loss, float* best_g,
                          const float* init_R, int32_t* active, float* query, void* stream);
@@ -346,7 +368,7 @@ int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float*
  * occnet_utils/utils/libmise/mise.pyx, driven by the loop of occnet_utils/mesh_extractor2.py:116-131:
  *     init;  loop { query -> n points; if n == 0 break; values = decoder(points); update(points, values) };  to_dense
  * `state` is caller-allocated device memory of ls_mise_state_bytes(); lattice index = (x*(R+1) + y)*(R+1) + z.
- * Marching cubes (libmcubes) is not part of this library yet.
+ * (Marching cubes -- libmcubes -- follows below: ls_marching_cubes_*.)
  * ---------------------------------------------------------------------------------------------- */
 size_t ls_mise_state_bytes(int resolution_0, int depth);
 long long ls_mise_lattice_points(int resolution_0, int depth);   /* (R+1)^3: upper bound for a query */

@@ -77,6 +77,12 @@ class SoftminProblem(ctypes.Structure):
                 ("logw", ctypes.c_float), ("N", ctypes.c_int), ("M", ctypes.c_int)]
 
 
+class AdamGroup(ctypes.Structure):
+    """ls_adam_group (include/livingscenes_hip.h)."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("n", ctypes.c_longlong),
+                ("lr", ctypes.c_float)]
+
+
 SIGNATURES = {
     "ls_version": (_I, []),
     "ls_last_error": (ctypes.c_char_p, []),
@@ -95,6 +101,7 @@ SIGNATURES = {
     "ls_cosine_scores_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "ls_greedy_match_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "ls_kabsch_batched_f32": (_I, [_P, _P, _P, _I, _I, _U, _P, _P, _P, _P, _P]),
+    "ls_kabsch_codes_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "ls_kabsch_residual_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "ls_icp_workspace_bytes": (_SZ, [_I, _I]),
     "ls_icp_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _P, _P, _P, _P, _P, _SZ, _P]),
@@ -105,6 +112,8 @@ SIGNATURES = {
     "ls_smooth_l1_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "ls_sinkhorn_softmin_batched_f32": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "ls_sinkhorn_softmin_multi_f32": (_I, [_P, _I, _P, _I, _I, _P]),
+    "ls_mse_f32": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "ls_adam_step_f32": (_I, [ctypes.POINTER(AdamGroup), _I, _F, _F, _F, _I, _P]),
     "ls_se3_adam_step_f32": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ls_encoder_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),

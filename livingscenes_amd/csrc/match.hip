@@ -158,13 +158,25 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
                                                      const float* __restrict__ weights, int nprob, int n, int pair_m,
                                                      int raw_weights, float eps, float* __restrict__ Rout, float* __restrict__ tout,
                                                      float* __restrict__ res, float* __restrict__ res_mean,
-                                                     int32_t* __restrict__ flags) {
+                                                     int32_t* __restrict__ flags, const float* __restrict__ off1, const float* __restrict__ off2,
+                                                     const long long* __restrict__ sel1, const long long* __restrict__ sel2) {
+    // off1 / off2 (nullable) [*,3]: the point sets are x + off (More_Solver's pseudo-points z_so3 + t, more_solver.py:114-116, formed
+    // here instead of by a separate element-wise launch); sel1 / sel2 (nullable) [nprob] int64: problem p reads set sel[p] (a negative
+    // entry -- an unmatched row of matches0 -- reads set 0, as matches0.clamp(min=0) does)
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= nprob) return;
-    const int i1 = pair_m > 0 ? p / pair_m : p, i2 = pair_m > 0 ? p % pair_m : p;
-    const float* a = x1 + (size_t)i1 * n * 3;
-    const float* b = x2 + (size_t)i2 * n * 3;
+    int i1 = pair_m > 0 ? p / pair_m : p, i2 = pair_m > 0 ? p % pair_m : p;
+    if (sel1) i1 = (int)max(sel1[p], 0ll);
+    if (sel2) i2 = (int)max(sel2[p], 0ll);
+    const float* a0 = x1 + (size_t)i1 * n * 3;
+    const float* b0 = x2 + (size_t)i2 * n * 3;
+    const float oa[3] = {off1 ? off1[i1 * 3] : 0.f, off1 ? off1[i1 * 3 + 1] : 0.f, off1 ? off1[i1 * 3 + 2] : 0.f};
+    const float ob[3] = {off2 ? off2[i2 * 3] : 0.f, off2 ? off2[i2 * 3 + 1] : 0.f, off2 ? off2[i2 * 3 + 2] : 0.f};
+    const bool shifted = off1 || off2;
+    // a(i, x) / b(i, x): the point coordinates (x + off rounded to fp32 first, exactly what the separate add produced)
+    auto A_ = [&](int i, int x) { const float v = a0[i * 3 + x]; return shifted ? __fadd_rn(v, oa[x]) : v; };
+    auto B_ = [&](int i, int x) { const float v = b0[i * 3 + x]; return shifted ? __fadd_rn(v, ob[x]) : v; };
     const float* w = weights ? weights + (size_t)p * n : nullptr;
     // weights / (sum + eps)   (pose_estimation.py:52-54); raw_weights: the caller already applied :52-66 (normalisation,
     // best_k selection, w_threshold zeroing WITHOUT renormalising) and the weights are used as they are
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
         const float wi = (w ? w[i] : 1.0f) / sw;
         swn += wi;
 #pragma unroll
-        for (int x = 0; x < 3; ++x) { m1[x] += wi * a[i * 3 + x]; m2[x] += wi * b[i * 3 + x]; }
+        for (int x = 0; x < 3; ++x) { m1[x] += wi * A_(i, x); m2[x] += wi * B_(i, x); }
     }
     swn = wave_sum(swn) + eps;
 #pragma unroll
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
         const float wi = (w ? w[i] : 1.0f) / sw;
         float c1[3], c2[3];
 #pragma unroll
-        for (int x = 0; x < 3; ++x) { c1[x] = a[i * 3 + x] - m1[x]; c2[x] = b[i * 3 + x] - m2[x]; }
+        for (int x = 0; x < 3; ++x) { c1[x] = A_(i, x) - m1[x]; c2[x] = B_(i, x) - m2[x]; }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
         float e2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float d = R[r * 3] * a[i * 3] + R[r * 3 + 1] * a[i * 3 + 1] + R[r * 3 + 2] * a[i * 3 + 2] + t[r] - b[i * 3 + r];
+            const float d = R[r * 3] * A_(i, 0) + R[r * 3 + 1] * A_(i, 1) + R[r * 3 + 2] * A_(i, 2) + t[r] - B_(i, r);
             e2 += d * d;
         }
         const float e = sqrtf(e2);
@@ -245,9 +257,10 @@ int greedy_match_launch(float* S, int n, int m, long long* m0, long long* m1, hi
     return LS_OK;
 }
 int kabsch_launch(const float* x1, const float* x2, const float* w, int nprob, int n, int pair_m, int raw_weights, float* R, float* t,
-                  float* res, float* res_mean, int32_t* flags, hipStream_t st) {
+                  float* res, float* res_mean, int32_t* flags, hipStream_t st, const float* off1, const float* off2, const long long* sel1,
+                  const long long* sel2) {
     hipLaunchKernelGGL(kabsch_kernel, dim3(cdiv(nprob, 4)), dim3(256), 0, st, x1, x2, w, nprob, n, pair_m, raw_weights, 1e-7f, R, t, res,
-                       res_mean, flags);
+                       res_mean, flags, off1, off2, sel1, sel2);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

@@ -71,7 +71,8 @@ int sdf_query_grad_launch(const float*, const float*, const float*, const float*
 int transpose_launch(const float*, int, int, float*, hipStream_t);
 int cosine_scores_launch(const float*, const float*, int, int, int, float*, float*, hipStream_t);
 int greedy_match_launch(float*, int, int, long long*, long long*, hipStream_t);
-int kabsch_launch(const float*, const float*, const float*, int, int, int, int, float*, float*, float*, float*, int32_t*, hipStream_t);
+int kabsch_launch(const float*, const float*, const float*, int, int, int, int, float*, float*, float*, float*, int32_t*, hipStream_t,
+                  const float* off1 = nullptr, const float* off2 = nullptr, const long long* sel1 = nullptr, const long long* sel2 = nullptr);
 size_t icp_workspace_bytes(int b, int n);
 int icp_run(const float*, const float*, const float*, const float*, int, int, int, int, float, unsigned, float*, float*, float*,
             int32_t*, void*, size_t, hipStream_t);
@@ -497,6 +498,13 @@ int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights
     LS_REQUIRE(x1 && x2 && R && t, "kabsch: null argument");
     return kabsch_launch(x1, x2, weights, b, n, 0, (flags & LS_FLAG_KABSCH_RAW_WEIGHTS) ? 1 : 0, R, t, res, nullptr, flags_out,
                          (hipStream_t)stream);
+}
+int ls_kabsch_codes_f32(const float* x1, const float* off1, const int64_t* sel1, const float* x2, const float* off2, const int64_t* sel2, int b,
+                        int n, float* R, float* t, float* res, int32_t* flags_out, void* stream) {
+    LS_REQUIRE(b > 0 && n > 0, "kabsch_codes: empty problem");
+    LS_REQUIRE(x1 && x2 && R && t, "kabsch_codes: null argument");
+    return kabsch_launch(x1, x2, nullptr, b, n, 0, 0, R, t, res, nullptr, flags_out, (hipStream_t)stream, off1, off2, (const long long*)sel1,
+                         (const long long*)sel2);
 }
 int ls_kabsch_residual_matrix_f32(const float* src, const float* tgt, int n, int m, int P, float* res, void* stream) {
     LS_REQUIRE(n > 0 && m > 0 && P > 0, "kabsch_residual_matrix: empty problem");

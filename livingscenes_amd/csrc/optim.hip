@@ -57,6 +57,43 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict_
     if (threadIdx.x == 0) loss[p] = (accumulate ? loss[p] : 0.f) + acc * inv;
 }
 
+// loss[p] = mean_i sdf[p,i]^2 (torch.nn.MSELoss of (sdf, 0), more_solver.py:204,213), grad[p,i] = 2 sdf[p,i] / N; optionally the
+// per-instance best-loss bookkeeping of More_Solver._optimize_code (:219-221: if loss < min_loss: min_loss = loss, a snapshot exists)
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ sdf, int N, float* __restrict__ loss, float* __restrict__ grad,
+                                                  float* __restrict__ min_loss, int32_t* __restrict__ improved) {
+    __shared__ float red[4];
+    const int p = blockIdx.x;
+    const float inv = 1.0f / (float)N;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float x = sdf[(size_t)p * N + i];
+        acc = __builtin_fmaf(x, x, acc);
+        grad[(size_t)p * N + i] = 2.0f * x * inv;
+    }
+    acc = block_sum_256_opt(acc, red);
+    if (threadIdx.x == 0) {
+        const float l = acc * inv;
+        loss[p] = l;
+        if (min_loss && l < min_loss[p]) { min_loss[p] = l; if (improved) improved[p] = 1; }
+    }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad) on up to four parameter tensors in one launch, each with its own learning rate
+// (more_solver.py:199-203: z_inv 1e-5, t 1e-4, z_so3 5e-4), in torch's operation order:
+//   m <- m + (g - m)(1 - b1);  v <- b2 v + (1 - b2) g g;  p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+struct AdamSet { ls_adam_group g[4]; };
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamSet s, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    const ls_adam_group& q = s.g[blockIdx.y];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= q.n) return;
+    const float g = q.grad[i];
+    const float m = __builtin_fmaf(g - q.m[i], 1.0f - b1, q.m[i]);
+    const float v = __builtin_fmaf((1.0f - b2) * g, g, b2 * q.v[i]);
+    q.m[i] = m; q.v[i] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    q.param[i] = __builtin_fmaf(-(q.lr / bc1), m / denom, q.param[i]);
+}
+
 // Batched log-domain softmin of entropic OT with cost |x - y|^2 / 2 (sinkhorn.hip's primitive with a pair index):
 //   v_j    = logw + pot_y[p,j] / eps_p - |x_i - y_j|^2 / (2 eps_p)
 //   out[i] = -eps_p log sum_j exp(v_j)          (averaged with prev[i] when `average`: the symmetric Sinkhorn update)
@@ -285,6 +322,29 @@ int ls_se3_transform_f32(const float* g, const float* src, int P, int N, float* 
 int ls_smooth_l1_f32(const float* sdf, int P, int N, int accumulate, float* loss, float* grad_sdf, void* stream) {
     LS_REQUIRE(sdf && loss && grad_sdf && P > 0 && N > 0, "smooth_l1: null argument or empty problem");
     hipLaunchKernelGGL(smooth_l1_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, sdf, N, accumulate, loss, grad_sdf);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+int ls_mse_f32(const float* sdf, int P, int N, float* loss, float* grad_sdf, float* min_loss, int32_t* improved, void* stream) {
+    LS_REQUIRE(sdf && loss && grad_sdf && P > 0 && N > 0, "mse: null argument or empty problem");
+    hipLaunchKernelGGL(mse_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, sdf, N, loss, grad_sdf, min_loss, improved);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+int ls_adam_step_f32(const ls_adam_group* groups, int count, float beta1, float beta2, float adam_eps, int step, void* stream) {
+    LS_REQUIRE(groups && count >= 1 && count <= 4 && step >= 0, "adam_step: bad arguments (count=%d step=%d)", count, step);
+    AdamSet s;
+    long long nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        LS_REQUIRE(groups[i].param && groups[i].grad && groups[i].m && groups[i].v && groups[i].n > 0, "adam_step: group %d: null argument or empty tensor", i);
+        s.g[i] = groups[i];
+        nmax = std::max(nmax, groups[i].n);
+    }
+    for (int i = count; i < 4; ++i) s.g[i] = s.g[0];
+    const float bc1 = 1.0f - powf(beta1, (float)(step + 1)), bc2 = 1.0f - powf(beta2, (float)(step + 1));
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(cdiv(nmax, 256), count), dim3(256), 0, (hipStream_t)stream, s, beta1, beta2, adam_eps, bc1, sqrtf(bc2));
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

@@ -48,8 +48,7 @@ class More_Solver:
     # -------------------------------------------------------------------------------------------- registration
     def _register_from_codes(self, code1, code2):
         """more_solver.py:114-116: Kabsch on the 256 equivariant pseudo-points z_so3 + t."""
-        R, t, _, _ = kabsch_transformation_estimation(code1["z_so3"] + code1["t"], code2["z_so3"] + code2["t"])
-        return R, t
+        return ops.kabsch_codes(code1["z_so3"], code1["t"], code2["z_so3"], code2["t"])   # z_so3 + t formed inside the launch
 
     def _icp(self, pc1, pc2, R, t):
         """more_solver.py:181-187: ICP refinement from the Kabsch initialisation (row-vector convention inside)."""
@@ -208,30 +207,34 @@ class More_Solver:
         from .. import _lib
         n_in = self.cfg["shape_priors"]["n_input_point"]
         pc = self._sample(pcs, n_in)
-        params = [{"params": code["z_inv"], "lr": 1e-5}, {"params": code["t"], "lr": 1e-4}, {"params": code["z_so3"], "lr": 5e-4}]
-        for p in params:
-            p["params"].requires_grad_(True)
-        optimizer = torch.optim.Adam(params)
-        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[160], gamma=0.1)
         P = pc.shape[0]
-        min_loss = torch.full((P,), 100.0, device=pc.device)
-        improved = torch.zeros(P, dtype=torch.bool, device=pc.device)
+        dev = pc.device
+        # the live parameters (updated in place by the device Adam; written back into the caller's tensors at the end: in the reference
+        # the caller's code tensors ARE the optimizer's parameters, more_solver.py:195-200)
+        z_inv = code["z_inv"].detach().float().contiguous().clone()
+        t = code["t"].detach().float().reshape(P, 3).contiguous().clone()
+        z_so3 = code["z_so3"].detach().float().contiguous().clone()
+        s_ = code["s"].detach().float().contiguous()
+        opt = ops.Adam([(z_inv, 1e-5), (t, 1e-4), (z_so3, 5e-4)])            # more_solver.py:199-203
+        min_loss = torch.full((P,), 100.0, device=dev)                        # :205
+        improved = torch.zeros(P, dtype=torch.int32, device=dev)
         hip = self.model.hip_model()
         prev_split = hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, 0)
         try:
-            for _ in range(n_steps):
-                optimizer.zero_grad()
-                sdf_output = self.model.decoder(pc, None, code, return_sdf=True)
-                per = (sdf_output ** 2).mean(1)                    # MSELoss(sdf, 0) of every instance
-                per.sum().backward()
-                optimizer.step()
-                scheduler.step()
-                better = per.detach() < min_loss                   # (the snapshot is taken AFTER the step, as in the reference)
-                min_loss = torch.where(better, per.detach(), min_loss)
-                improved |= better
-                optimizer.zero_grad()
+            # per step: decoder forward (activations kept), MSE + its gradient + the best-loss bookkeeping, decoder backward w.r.t. the
+            # code, ONE Adam launch for the three tensors -- no autograd graph, no ATen kernel, no host read inside the loop
+            for i in range(n_steps):
+                sdf, saved = hip.sdf_decode_train(pc, z_so3, z_inv, s_, t)
+                _, gsdf = ops.mse(sdf, min_loss, improved)                       # MSELoss(sdf, 0) of every instance (:213), :219-221
+                _, gso3, ginv, _, gt = hip.sdf_backward(saved, gsdf, need_query_grad=False)
+                opt.step([ginv, gt, gso3], lr_scale=0.1 if i >= 160 else 1.0)   # MultiStepLR([160], 0.1) (:204)
         finally:
             hip.set_option(_lib.OPT_SDF_TRAIN_SPLITK, prev_split)
+        with torch.no_grad():
+            code["z_inv"].copy_(z_inv.reshape(code["z_inv"].shape))
+            code["z_so3"].copy_(z_so3.reshape(code["z_so3"].shape))
+            code["t"].copy_(t.reshape(code["t"].shape))
+        improved = improved.bool()
         return {k: code[k].detach() for k in ("z_inv", "z_so3", "s", "t")}, improved
 
     def _mesh_from_latent(self, latent_code):

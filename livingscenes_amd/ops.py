@@ -139,6 +139,26 @@ def kabsch(x1, x2, weights=None, return_flags=False, raw_weights=False):
     return (R, t.unsqueeze(2), res, fl) if return_flags else (R, t.unsqueeze(2), res)
 
 
+def kabsch_codes(z1, t1, z2, t2, sel2=None, sel1=None, want_res=False):
+    """Kabsch on the pseudo-points z + t of two code sets (more_solver.py:114-116) in ONE launch: z [n,c,3], t [n,1,3] or [n,3];
+    sel2 / sel1 (int64 [b], optional): problem p pairs set sel1[p] (default p) of side 1 with set sel2[p] of side 2 -- e.g. matches0
+    (negative = unmatched -> set 0, as matches0.clamp(min=0)).  -> R [b,3,3], t [b,3,1] (, res [b,c])."""
+    z1, z2 = _f32(z1), _f32(z2)
+    t1, t2 = _f32(t1.reshape(-1, 3)), _f32(t2.reshape(-1, 3))
+    b = (sel1 if sel1 is not None else sel2).shape[0] if (sel1 is not None or sel2 is not None) else z1.shape[0]
+    n = z1.shape[1]
+    R = torch.empty(b, 3, 3, dtype=torch.float32, device=z1.device)
+    t = torch.empty(b, 3, dtype=torch.float32, device=z1.device)
+    res = torch.empty(b, n, dtype=torch.float32, device=z1.device) if want_res else None
+    if sel1 is not None:
+        sel1 = sel1.contiguous().long()
+    if sel2 is not None:
+        sel2 = sel2.contiguous().long()
+    call(z1.device, "ls_kabsch_codes_f32", ptr(z1), ptr(t1), ptr(sel1), ptr(z2), ptr(t2), ptr(sel2), b, n, ptr(R), ptr(t), ptr(res), None,
+         stream_ptr(z1.device))
+    return (R, t.unsqueeze(2), res) if want_res else (R, t.unsqueeze(2))
+
+
 def kabsch_residual_matrix(src, tgt):
     """src [n,P,3], tgt [m,P,3] -> mean residual [n,m]."""
     src, tgt = _f32(src), _f32(tgt)
@@ -183,6 +203,42 @@ def smooth_l1(sdf, loss=None):
     grad = torch.empty_like(sdf)
     call(sdf.device, "ls_smooth_l1_f32", ptr(sdf), P, N, int(acc), ptr(loss), ptr(grad), stream_ptr(sdf.device))
     return loss, grad
+
+
+def mse(sdf, min_loss=None, improved=None):
+    """Per-row MSELoss(sdf, 0) of sdf [P,N] -> (loss [P], d loss / d sdf [P,N]); min_loss [P] float / improved [P] int32 (optional) are
+    updated in place where the loss improved (More_Solver._optimize_code's bookkeeping, more_solver.py:219-221)."""
+    sdf = _f32(sdf)
+    P, N = sdf.shape
+    loss = torch.empty(P, dtype=torch.float32, device=sdf.device)
+    grad = torch.empty_like(sdf)
+    call(sdf.device, "ls_mse_f32", ptr(sdf), P, N, ptr(loss), ptr(grad), ptr(min_loss), ptr(improved), stream_ptr(sdf.device))
+    return loss, grad
+
+
+class Adam:
+    """torch.optim.Adam(params with per-group lr) on the device: ONE launch per step for up to four tensors (csrc/optim.hip:
+    adam_multi_kernel, torch's operation order).  params: list of (tensor updated in place, lr)."""
+
+    def __init__(self, params, betas=(0.9, 0.999), eps=1e-8):
+        assert 1 <= len(params) <= 4
+        self.params = [(p, float(lr)) for p, lr in params]
+        for p, _ in self.params:
+            assert p.is_contiguous() and p.dtype == torch.float32
+        self.m = [torch.zeros_like(p) for p, _ in self.params]
+        self.v = [torch.zeros_like(p) for p, _ in self.params]
+        self.betas, self.eps, self.step_no = betas, eps, 0
+
+    def step(self, grads, lr_scale=1.0):
+        groups = (_lib.AdamGroup * len(self.params))()
+        keep = []
+        for i, ((p, lr), g) in enumerate(zip(self.params, grads)):
+            g = _f32(g.reshape(p.shape))
+            keep.append(g)
+            groups[i] = _lib.AdamGroup(p.data_ptr(), g.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel(), lr * lr_scale)
+        call(self.params[0][0].device, "ls_adam_step_f32", groups, len(self.params), self.betas[0], self.betas[1], self.eps, self.step_no,
+             stream_ptr(self.params[0][0].device))
+        self.step_no += 1
 
 
 class Se3Adam:

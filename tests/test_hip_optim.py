@@ -175,3 +175,38 @@ def test_refinement_trajectory_vs_oracle_released_settings():
         assert relerr(gd, gr) < 1e-4, f"step {i}: pose"
         assert relerr(ld, lr_) < 1e-4, f"step {i}: loss"
     assert relerr(opt.best_g, st.best_g) < 1e-4
+
+
+def test_device_adam_and_mse_vs_torch():
+    """ls_adam_step_f32 (one launch, three tensors with their own learning rates, more_solver.py:199-203) against torch.optim.Adam on
+    the CPU over 30 steps incl. the MultiStepLR drop, and ls_mse_f32 (loss, gradient, best-loss bookkeeping of :219-221) against
+    torch.nn.functional.mse_loss + autograd."""
+    from livingscenes_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    shapes, lrs = [(5, 64), (5, 3), (5, 64, 3)], [1e-5, 1e-4, 5e-4]
+    ps = [torch.randn(s, generator=gen) * 0.1 for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt_ref = torch.optim.Adam([{"params": r, "lr": lr} for r, lr in zip(ref, lrs)])
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt_ref, milestones=[20], gamma=0.1)
+    dev = [p.clone().to(_dev()) for p in ps]
+    opt = ops.Adam(list(zip(dev, lrs)))
+    for i in range(30):
+        gs = [torch.randn(s, generator=gen) * (1e-3 if i % 7 else 1.0) for s in shapes]      # gradients of very different size
+        for r, g in zip(ref, gs):
+            r.grad = g.clone()
+        opt_ref.step()
+        sched.step()
+        opt.step([g.to(_dev()) for g in gs], lr_scale=0.1 if i >= 20 else 1.0)
+    for d, r, p0 in zip(dev, ref, ps):
+        moved = float((r.detach() - p0).abs().max())
+        assert float((d.cpu() - r.detach()).abs().max()) < 1e-4 * moved + 1e-9
+    sdf = torch.randn(4, 1000, generator=gen) * 0.3
+    x = sdf.clone().requires_grad_(True)
+    per = (x ** 2).mean(1)
+    per.sum().backward()
+    min_loss = torch.tensor([100.0, 0.0, 100.0, float(per[3]) * 2]).to(_dev())
+    improved = torch.zeros(4, dtype=torch.int32, device=_dev())
+    loss, grad = ops.mse(sdf.to(_dev()), min_loss, improved)
+    assert relerr(loss, per.detach()) < 1e-6 and relerr(grad, x.grad) < 1e-6
+    assert improved.cpu().tolist() == [1, 0, 1, 1]
+    assert relerr(min_loss, torch.tensor([float(per[0]), 0.0, float(per[2]), float(per[3])])) < 1e-6

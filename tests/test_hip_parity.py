@@ -609,6 +609,31 @@ def test_kabsch_vs_golden(golden):
     assert relerr(Rh, Rr) < TOL and relerr(th, tr) < TOL
 
 
+def test_kabsch_codes_equals_kabsch_on_materialised_pseudo_points():
+    """ls_kabsch_codes_f32 (z_so3 + t, the gather by matches0 and its clamp inside the launch: more_solver.py:114-116 as bench.py and
+    More_Solver._register_from_codes drive it) == ls_kabsch_batched_f32 on the sums torch materialises, BIT FOR BIT; negative
+    (unmatched) entries read set 0."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(12)
+    n, c = 40, 256
+    z1, z2 = torch.randn(n, c, 3, generator=g) * 0.03, torch.randn(n, c, 3, generator=g) * 0.03
+    t1, t2 = torch.randn(n, 1, 3, generator=g), torch.randn(n, 1, 3, generator=g)
+    d = _dev()
+    R0, tt0, res0 = ops.kabsch((z1 + t1).to(d), (z2 + t2).to(d))
+    R1, tt1, res1 = ops.kabsch_codes(z1.to(d), t1.to(d), z2.to(d), t2.to(d), want_res=True)
+    assert torch.equal(R0, R1) and torch.equal(tt0, tt1) and torch.equal(res0, res1)
+    m0 = torch.randperm(n, generator=g)
+    m0[[3, 17]] = -1
+    R2, tt2 = ops.kabsch_codes(z1.to(d), t1.to(d), z2.to(d), t2.to(d), sel2=m0.to(d))
+    j = m0.clamp(min=0)
+    R3, tt3, _ = ops.kabsch((z1 + t1).to(d), (z2 + t2).index_select(0, j).to(d))
+    assert torch.equal(R2, R3) and torch.equal(tt2, tt3)
+    sel1 = torch.tensor([5, 5, 0, 39])
+    R4, tt4 = ops.kabsch_codes(z1.to(d), t1.to(d), z2.to(d), t2.to(d), sel1=sel1.to(d), sel2=torch.tensor([1, 2, 3, 4]).to(d))
+    R5, tt5, _ = ops.kabsch((z1 + t1)[sel1].to(d), (z2 + t2)[[1, 2, 3, 4]].to(d))
+    assert torch.equal(R4, R5) and torch.equal(tt4, tt5)
+
+
 def test_residual_matrix_and_eq_matchers(golden):
     from livingscenes_amd import ops
     from oracle import more
