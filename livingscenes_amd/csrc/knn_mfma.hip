@@ -131,11 +131,16 @@ __device__ __forceinline__ float quad_pair_distance(const QuadRow<CC>& q0, const
 int row_norms_launch(const float* f, int row_f, long long npts, float* norms, hipStream_t st);
 
 // ---- 1. seeds.  One wave per four queries (row r of the wave = query 4*wave_id + r), four quad-steps of four hints.
-template <int CC, bool FMA>
+// AUTO (round 3): the hints are not read from seed_idx but SELECTED here from the class winners of knn_sweep_winners_kernel (win_val /
+// win_idx [query][W], W = 32 or 64): the 16 lanes of a query row take W / 16 winners each as (descending value, index) keys and
+// merge_keys keeps the row's 16 best -- the same 16, in the same order, as the separate knn_autohint_select_kernel launch produced.
+template <int CC, bool FMA, bool AUTO = false>
 __global__ __launch_bounds__(256, CC == 32 ? 6 : 4) void knn_seed_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                           const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
                                                           const int32_t* __restrict__ seed_idx, int seed_n, int seed_by_row,
-                                                          u64* __restrict__ seedkeys, int groups_per_inst, int total_groups) {
+                                                          u64* __restrict__ seedkeys, int groups_per_inst, int total_groups,
+                                                          const float* __restrict__ win_val = nullptr, const int32_t* __restrict__ win_idx = nullptr,
+                                                          int W = 0) {
     constexpr int RF = 3 * CC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware order: consecutive logical workgroups (= the queries of one instance) share an XCD, so the instance's
@@ -150,12 +155,41 @@ __global__ __launch_bounds__(256, CC == 32 ? 6 : 4) void knn_seed_kernel(const f
     const int r = live ? (dst_rows ? dst_rows[(size_t)b * Nd + q] : q) : -1;
     const int quad = (lane >> 2) & 3;
     const bool qlast = (lane & 3) == 3;
-    const int32_t* hp = seed_idx + ((size_t)b * seed_n + (seed_by_row ? max(r, 0) : min(q, seed_n - 1))) * 16;
     int sidx[4];
+    if constexpr (AUTO) {
+        // the wave's four queries one after the other: W <= 64 winners, one per lane, through the 64-lane sorting network (the
+        // insertion-based merge_keys took ~40 ballot rounds for this: +17 us on the layer-3 seed launch)
+        int my_hint = -1;                                                // hint number (lane & 15) of this lane's row
+        const int q0 = (wg % groups_per_inst) * 4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int si = hp[u * 4 + quad];
-        sidx[u] = (r >= 0 && si >= 0 && si < Ns) ? si : -1;
+        for (int g = 0; g < 4; ++g) {
+            const size_t qg = (size_t)b * Nd + min(q0 + g, Nd - 1);
+            u64 k = ~0ull;
+            if (lane < W) {
+                const int idx = win_idx[qg * W + lane];
+                if (idx >= 0) {
+                    unsigned u = __float_as_uint(win_val[qg * W + lane]);
+                    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;       // monotone in the float value
+                    k = ((u64)(~u) << 32) | (unsigned)idx;             // ascending key order = descending value
+                }
+            }
+            LS_SORT64(cx64, k, lane)
+            const int hsel = (k == ~0ull) ? -1 : (int)(unsigned)k;
+            const int got = __shfl(hsel, lane & 15, 64);
+            my_hint = ((lane >> 4) == g) ? got : my_hint;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int si = __shfl(my_hint, (lane & 48) + u * 4 + quad, 64);
+            sidx[u] = (r >= 0 && si >= 0 && si < Ns) ? si : -1;
+        }
+    } else {
+        const int32_t* hp = seed_idx + ((size_t)b * seed_n + (seed_by_row ? max(r, 0) : min(q, seed_n - 1))) * 16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int si = hp[u * 4 + quad];
+            sidx[u] = (r >= 0 && si >= 0 && si < Ns) ? si : -1;
+        }
     }
     const float* qrow = dbase + (size_t)max(r, 0) * RF;
     QuadRow<CC> qv;
@@ -472,9 +506,15 @@ __global__ __launch_bounds__(1024) void knn_mean_rows_kernel(const float* __rest
 
 // one wave per 32-row tile: lane (h, j) walks row j in 16-dim steps (dims kk*16 + h*8 .. +7: two float4 in, one 16-byte store
 // into the step's 1 KB fragment block), accumulating the centred row's squared norm on the way
-__global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restrict__ f, const float* __restrict__ mu, int N, int Npad, int D,
+// The centre of the instance is computed HERE (round 3: the separate knn_mean_rows_kernel launch is gone from the encoder's path): every
+// wave sums the first min(Nc, 16) rows of the centre source `fc` (the candidate set: queries and candidates of a call share one centre)
+// into its own LDS slot -- lane l takes dims l, l + 64, l + 128, coalesced row reads out of L2.  Any centre is valid (header comment of
+// knn_mean_rows_kernel); 16 FPS-ordered rows instead of 64 widen the filter's margin by ~5 %.
+constexpr int KNN_CENTRE_ROWS = 16;
+__global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restrict__ f, const float* __restrict__ fc, int Nc, int N, int Npad, int D,
                                                             int tiles_total, unsigned short* __restrict__ out, float* __restrict__ norms,
                                                             int32_t* __restrict__ zero_buf, long long zero_n) {
+    __shared__ __attribute__((aligned(16))) float lmu[4][192];
     // the sweep's per-query survivor counters are cleared here (a separate memset launch cost 5 - 7 us per layer)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_buf[i] = 0;
     const int tg = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -483,8 +523,23 @@ __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restr
     const int tpi = Npad >> 5, b = tg / tpi, tile = tg % tpi, r = tile * 32 + j;
     const int KK = D >> 4;
     const bool live = r < N;
+    {
+        const int nc = min(Nc, KNN_CENTRE_ROWS);
+        const float* cp = fc + (size_t)b * Nc * D;
+        float* mw = lmu[threadIdx.x >> 6];
+        for (int d = lane; d < D; d += 64) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four independent chains: the 16 loads of a dim are in flight together
+            for (int rr = 0; rr + 3 < nc; rr += 4) {
+                s0 += cp[(size_t)rr * D + d]; s1 += cp[(size_t)(rr + 1) * D + d]; s2 += cp[(size_t)(rr + 2) * D + d]; s3 += cp[(size_t)(rr + 3) * D + d];
+            }
+            for (int rr = nc & ~3; rr < nc; ++rr) s0 += cp[(size_t)rr * D + d];
+            mw[d] = ((s0 + s1) + (s2 + s3)) / (float)nc;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the slot is wave-private, LDS ops of a wave complete in order
+        __builtin_amdgcn_wave_barrier();
+    }
     const float* rp = f + ((size_t)b * N + (live ? r : 0)) * D + h * 8;
-    const float* mp = mu + (size_t)b * D + h * 8;
+    const float* mp = lmu[threadIdx.x >> 6] + h * 8;
     unsigned short* op = out + (((size_t)b * tpi + tile) * KK * 64 + lane) * 8;
     float s = 0.f;
 #pragma unroll 3
@@ -755,32 +810,39 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     unsigned short* dq = sq;
     if (dst != src) dq = sq + (size_t)B * ns_pad * D;
     int rc;
+    float* win_val = nullptr;      // auto hints: class winners of the first sweep (selected inside the seed kernel)
+    int32_t* win_idx = nullptr;
+    int win_w = 0;
     if (bf16) {
-        hipLaunchKernelGGL(knn_mean_rows_kernel, dim3(B, cdiv(D, 64)), dim3(1024), 0, st, src, Ns, D, mu);
-        LS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, mu, Ns, ns_pad, D,
+        static_assert(D <= 192, "knn_prep_bf16_kernel keeps the centre in a 192-float LDS slot per wave");
+        (void)mu;
+        hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, src, Ns, Ns, ns_pad, D,
                            B * (ns_pad / 32), sq, nsrc, surv_cnt, (long long)nq);
         LS_LAUNCH_CHECK();
-        if (dst != src) {   // same centre for both sets
-            hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, mu, dst_n, dst_npad, D,
+        if (dst != src) {   // same centre for both sets: the candidates' first rows
+            hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, src, Ns, dst_n, dst_npad, D,
                                B * (dst_npad / 32), dq, ndst, (int32_t*)nullptr, 0LL);
             LS_LAUNCH_CHECK();
         }
-        if (!seed_idx) {   // un-seeded call: hints from a first sweep (class winners -> 16 best)
+        if (!seed_idx) {   // un-seeded call: hints from a first sweep (class winners; the 16 best are picked inside the seed kernel)
             unsigned short* img_end = dq + (size_t)B * dst_npad * D;
-            float* win_val = (float*)(((uintptr_t)img_end + 255) & ~(uintptr_t)255);
-            int32_t* win_idx = (int32_t*)(win_val + nq * 64);
-            int32_t* hints = win_idx + nq * 64;
+            win_val = (float*)(((uintptr_t)img_end + 255) & ~(uintptr_t)255);
+            win_idx = (int32_t*)(win_val + nq * 64);
             const int qgroups = cdiv(Nd, 32);
             const int nsplit = ((long long)B * qgroups < 4096 && ns_pad / 32 >= 16) ? 2 : 1;   // W = 32 nsplit <= 64 winners per query
             const int total_waves = B * qgroups * nsplit;
+            win_w = 32 * nsplit;
             hipLaunchKernelGGL(knn_sweep_winners_kernel<D>, dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, Nd, dst_npad,
                                Ns, ns_pad, qgroups, nsplit, total_waves, win_val, win_idx);
             LS_LAUNCH_CHECK();
-            hipLaunchKernelGGL(knn_autohint_select_kernel, dim3(cdiv((long long)nq, 4)), dim3(256), 0, st, win_val, win_idx, 32 * nsplit, (int)nq,
-                               hints);
-            LS_LAUNCH_CHECK();
-            seed_idx = hints;
+            static const bool sel_launch = getenv("LS_KNN_SELECT_LAUNCH") && atoi(getenv("LS_KNN_SELECT_LAUNCH")) != 0;   // A/B: the separate select launch
+            if (sel_launch) {
+                int32_t* hints = win_idx + nq * 64;
+                hipLaunchKernelGGL(knn_autohint_select_kernel, dim3(cdiv((long long)nq, 4)), dim3(256), 0, st, win_val, win_idx, win_w, (int)nq, hints);
+                LS_LAUNCH_CHECK();
+                seed_idx = hints;
+                win_w = 0;
+            }
             seed_n = Nd;
             seed_by_row = 0;
         }
@@ -798,12 +860,19 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     const int gblocks = cdiv((long long)B * groups, 4);
     const int qtiles = cdiv(Nd, KNN_TQ);
     const float epsE = 6.0f * (float)(3 * C + 4) * 5.9604645e-8f;
-    if (fma)
+    if (win_w) {
+        if (fma)
+            hipLaunchKernelGGL((knn_seed_kernel<CC, true, true>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
+                               seed_by_row, seedkeys, groups, B * groups, win_val, win_idx, win_w);
+        else
+            hipLaunchKernelGGL((knn_seed_kernel<CC, false, true>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
+                               seed_by_row, seedkeys, groups, B * groups, win_val, win_idx, win_w);
+    } else if (fma)
         hipLaunchKernelGGL((knn_seed_kernel<CC, true>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
-                           seed_by_row, seedkeys, groups, B * groups);
+                           seed_by_row, seedkeys, groups, B * groups, (const float*)nullptr, (const int32_t*)nullptr, 0);
     else
         hipLaunchKernelGGL((knn_seed_kernel<CC, false>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
-                           seed_by_row, seedkeys, groups, B * groups);
+                           seed_by_row, seedkeys, groups, B * groups, (const float*)nullptr, (const int32_t*)nullptr, 0);
     LS_LAUNCH_CHECK();
     if (bf16) {
         const int qgroups = cdiv(Nd, 32);
