@@ -50,6 +50,7 @@ int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipS
 size_t prologue_scratch_floats(int B);
 int transpose_cloud_launch(const float*, int, int, float*, hipStream_t);
 int mean_points_launch(const float*, int, int, int, float*, hipStream_t);
+int glob_mean_gemv_launch(const float*, int, int, int, const float*, int, int, float*, int, hipStream_t);
 int vn_act_rows_launch(const float*, int, const float*, int, int, int, int, float, float*, hipStream_t);
 int tail_launch(const float*, int, int, int, int, const float*, const float*, const float*, float, float, int, int, const float*,
                 const float*, float*, float*, float*, float*, hipStream_t);
@@ -97,6 +98,8 @@ struct ls_model {
     hipStream_t side = nullptr;    // FPS chain
     hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fps[LS_MAX_LAYERS] = {};   // one per FPS level: a down-sampling layer waits for ITS level only (round 3: waiting for the whole chain
+                                             // kept layer 2 idle for ~100 us while levels 1 and 2 were still running)
     hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
     bool knn_filter = true;        // LS_KNN_FILTER=0: all-VALU k-NN kernel on the seeded C == 32 layers too (A/B timing)
     bool train_splitk = true;      // ls_model_set_option(LS_OPT_SDF_TRAIN_SPLITK): split-K in the decoder's TRAINING-path GEMMs (under-filled
@@ -365,6 +368,19 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
     const float* Wg = m->blob + d.off_glob[i];
     if (rm_written) *rm_written = false;
     int rc;
+    static const bool mean_fused = !(getenv("LS_GLOB_MEAN_FUSE") && atoi(getenv("LS_GLOB_MEAN_FUSE")) == 0);   // A/B: mean + 192-row GEMM (+ split-K reduce) launches
+    if (gemm_vn_supported(B * Nd * 3, Co, Co) && mean_fused) {
+        // per-instance part: mean over the points and its contraction with the W_b / Wd W_b rows in ONE launch (pointwise.hip) ...
+        { PROF(LS_K_MEAN, i, st); rc = glob_mean_gemv_launch(msg, B, Nd, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st); }
+        if (rc != LS_OK) return rc;
+        // ... then ONE launch for the per-point contraction + the VN activation (gemm.hip: gemm_vn_kernel)
+        PROF(LS_K_GEMM_GLOB, i, st);
+        GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
+        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? 1 : 0;
+        ax.out_rowmax = rm_out;
+        if (rm_written) *rm_written = rm_out != nullptr;
+        return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st, ax);
+    }
     { PROF(LS_K_MEAN, i, st); rc = mean_points_launch(msg, B, Nd, Co, g, st); }
     if (rc != LS_OK) return rc;
     if (gemm_vn_supported(B * Nd * 3, Co, Co)) {
@@ -544,6 +560,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side2, hipStreamNonBlocking);
     for (int i = 0; i < LS_MAX_LAYERS && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&m->ev_feat[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fps[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_tab[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
@@ -592,6 +609,7 @@ void ls_model_destroy(ls_model_t* m) {
     if (m->side2) (void)hipStreamDestroy(m->side2);
     for (int i = 0; i < LS_MAX_LAYERS; ++i) {
         if (m->ev_feat[i]) (void)hipEventDestroy(m->ev_feat[i]);
+        if (m->ev_fps[i]) (void)hipEventDestroy(m->ev_fps[i]);
         if (m->ev_tab[i]) (void)hipEventDestroy(m->ev_tab[i]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
@@ -660,6 +678,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 rc = (skip & SK_FPS) ? LS_OK : fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), nullptr, 0, fs);
             }
             if (rc != LS_OK) return rc;
+            if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_fps[l], fs));
         }
         if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_join, fs));
     }
@@ -688,7 +707,8 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
         const int Ns = p.Ns[i], Nd = p.Nd[i], Co = p.Co[i];
         const int32_t* dst_rows = nullptr;
         if (p.level[i] >= 0) {
-            if (!joined) { if (m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0)); joined = true; }
+            if (m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_fps[p.level[i]], 0));   // this layer's level only
+            joined = p.level[i] == p.nlevels - 1;                                            // the last level joins the whole side chain
             dst_rows = trace_fps ? trace_fps + fps_off : I(p.o_fps[p.level[i] + 1]);
             fps_off += (size_t)B * Nd;
         }

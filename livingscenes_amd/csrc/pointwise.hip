@@ -164,6 +164,80 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------- mean over points + its VecLinear
+// The per-instance half of the residual global conv (vec_dgcnn_atten.py:222-225: VecLNA_G(cat(f, mean_n f))): the part of the
+// contraction that multiplies the MEAN feature is the same for every point of an instance,
+//     G[b][x][n] = sum_k mean_n f[b][n][x][k] * W[n][k]        n in [col0, col0 + ncols)  (the W_b / Wd W_b rows of the folded matrix)
+// Until round 3 this took three launches (mean_points_kernel, a 192-row fp32-MFMA GEMM split along K, its reduce) of 5 - 14 us each on
+// the critical path of every layer >= 2; here a workgroup computes the instance's mean rows into LDS (same summation order as
+// mean_points_kernel where the layer is narrow) and then its block of columns, one column per lane, k ascending.
+__global__ __launch_bounds__(256) void glob_mean_gemv_kernel(const float* __restrict__ f, int N, int C, const float* __restrict__ W, int col0,
+                                                             int cols_per_block, int ncols, float* __restrict__ G, int ldg) {
+    extern __shared__ float lmean[];           // [3][C]
+    __shared__ float4 part[16][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = 3 * C;
+    const int cg = tid & 15, rs = tid >> 4;
+    const float inv = 1.0f / (float)N;
+    if (row >= 512) {
+        // wide rows, few points (layers 5, 6: 32 points x 768 / 1536 floats): a thread owns float4 columns and walks all N rows (eight
+        // loads in flight); no LDS combine, no barrier per 64-column chunk (24 chunks x 2 barriers of pure latency at layer 6)
+        for (int c4 = tid; c4 < row / 4; c4 += 256) {
+            const float* p = f + (size_t)b * N * row + c4 * 4;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int n = 0; n < N; ++n) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)n * row);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4*>(&lmean[c4 * 4]) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+        }
+        __syncthreads();
+    } else
+    for (int cb = 0; cb < row; cb += 64) {     // 64 columns of the [N, 3C] matrix at a time: 16 float4 groups x 16 row slices
+        const int col = cb + cg * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < row) {
+            const float* p = f + (size_t)b * N * row + col;
+#pragma unroll 8
+            for (int n = rs; n < N; n += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)n * row);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        part[rs][cg] = s;
+        __syncthreads();
+        if (rs == 0 && col < row) {
+            float4 t = part[0][cg];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) { const float4 v = part[r][cg]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(&lmean[col]) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+        }
+        __syncthreads();
+    }
+    // columns: a LANE owns a column (64 per wave pass), k ascending in 16-byte steps -- the lanes of a wave read 64 different weight rows
+    // (one cache line each per 16 k, fully used over the next three steps out of the L1), the mean values are LDS broadcasts; no reduction
+    const int j0 = blockIdx.y * cols_per_block, j1 = min(ncols, j0 + cols_per_block);
+    for (int jb = j0 + wave * 64; jb < j1; jb += 256) {
+        const int j = jb + lane;
+        const float* wr = W + (size_t)(col0 + min(j, j1 - 1)) * C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < C; k += 4) {
+            const float4 w = *reinterpret_cast<const float4*>(wr + k);
+            const float4 m0 = *reinterpret_cast<const float4*>(&lmean[k]), m1 = *reinterpret_cast<const float4*>(&lmean[C + k]),
+                         m2 = *reinterpret_cast<const float4*>(&lmean[2 * C + k]);
+            a0 = __builtin_fmaf(m0.x, w.x, a0); a0 = __builtin_fmaf(m0.y, w.y, a0); a0 = __builtin_fmaf(m0.z, w.z, a0); a0 = __builtin_fmaf(m0.w, w.w, a0);
+            a1 = __builtin_fmaf(m1.x, w.x, a1); a1 = __builtin_fmaf(m1.y, w.y, a1); a1 = __builtin_fmaf(m1.z, w.z, a1); a1 = __builtin_fmaf(m1.w, w.w, a1);
+            a2 = __builtin_fmaf(m2.x, w.x, a2); a2 = __builtin_fmaf(m2.y, w.y, a2); a2 = __builtin_fmaf(m2.z, w.z, a2); a2 = __builtin_fmaf(m2.w, w.w, a2);
+        }
+        if (j < j1) {
+            float* gp = G + (size_t)b * 3 * ldg + col0 + j;
+            gp[0] = a0; gp[ldg] = a1; gp[2 * ldg] = a2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- point-wise VN activation
 // global_conv VecLNA of vec_dgcnn_atten.py:222-225 after the GEMMs:
 //   y  = T[p][x][0:C]   + G[b][x][2C:3C]      (W_a f[n]      + W_b mean_n f)
@@ -349,6 +423,16 @@ int mean_points_launch(const float* f, int B, int N, int C, float* out, hipStrea
     const int row = 3 * C;
     LS_REQUIRE(row % 4 == 0, "mean_points: 3*C must be a multiple of 4");
     hipLaunchKernelGGL(mean_points_kernel, dim3(cdiv(row, 64), B), dim3(256), 0, st, f, N, row, out);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+// G[b][x][col0 + j] = <mean_n f[b][n][x][:], W[col0 + j][:]>, j < ncols   (f [B,N,3,C], W [*, C], G [B*3, ldg])
+int glob_mean_gemv_launch(const float* f, int B, int N, int C, const float* W, int col0, int ncols, float* G, int ldg, hipStream_t st) {
+    LS_REQUIRE(C % 4 == 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024, "glob_mean_gemv: C=%d unsupported", C);
+    int nblk = 1;
+    while (B * nblk < 512 && ncols / (nblk * 2) >= 64) nblk *= 2;     // ~two workgroups per CU; at least 64 columns (one wave pass) each
+    const int cpb = cdiv(ncols, nblk);
+    hipLaunchKernelGGL(glob_mean_gemv_kernel, dim3(B, cdiv(ncols, cpb)), dim3(256), (size_t)3 * C * sizeof(float), st, f, N, C, W, col0, cpb, ncols, G, ldg);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
