@@ -264,6 +264,10 @@ __device__ __forceinline__ float group_max(float v) {  // all-reduce (max) over 
 }
 __device__ __forceinline__ float amax_f4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
+// 1 / max(sqrt(ss), 1e-12) (channel_equi_vec_normalize's Frobenius norm, vec_layers.py:24-31) as ONE v_rsq_f32 on the clamped square
+// instead of a correctly rounded sqrt + IEEE division (~18 issue slots per neighbour in the K branch); 1 ulp, far inside the tolerance
+__device__ __forceinline__ float inv_fro(float ss) { return __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)); }
+
 struct F43 { float4 x, y, z; };  // one xyz triple for four channels
 __device__ __forceinline__ F43 ld43(const float* p, int ldt) {
     F43 r;
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
         act43(qf[ch], kd, oms);
         ssq += dot43(qf[ch], qf[ch]);
     }
-    const float inv_q = 1.0f / fmaxf(sqrtf(group_sum<LPP>(ssq)), 1e-12f);
+    const float inv_q = inv_fro(group_sum<LPP>(ssq));
 
     // ---- B: K branch -> per-head scores for the 16 neighbours, Frobenius norms of k
     // (rolled loops, two neighbours of loads per iteration: the software-pipelined form of edge_attn_fq_kernel was measured here too --
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
     for (int ch = 0; ch < NCH; ++ch) { mx[ch] = -INFINITY; sum[ch] = 0.f; }
 #pragma unroll 4
     for (int k = 0; k < EK; ++k) {
-        const float invk = 1.0f / fmaxf(sqrtf(group_sum<LPP>(l_ssk[k][tid])), 1e-12f);
+        const float invk = inv_fro(group_sum<LPP>(l_ssk[k][tid]));
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const float v = l_score[ch][k][tid] * inv_q * invk * inv_sqrt_dk;
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         const F43 kd = lds43(Co);
         act43(qf, kd, oms);
     }
-    const float inv_q = 1.0f / fmaxf(sqrtf(group_sum<LPP>(dot43(qf, qf))), 1e-12f);
+    const float inv_q = inv_fro(group_sum<LPP>(dot43(qf, qf)));
     __syncthreads();   // every wave has its q: the slab may be overwritten
 
     // ---- B: K branch -> per-head scores for the 16 neighbours, normalised by the Frobenius norm of k
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
             y = add43(y, ql);
             kd = add43(kd, qd);
             act43(y, kd, oms);
-            const float invk = 1.0f / fmaxf(sqrtf(group_sum<LPP>(dot43(y, y))), 1e-12f);
+            const float invk = inv_fro(group_sum<LPP>(dot43(y, y)));
             l_score[k][tid] = quad_sum(dot43(y, qf)) * inv_q * invk * inv_sqrt_dk;
             __builtin_amdgcn_sched_barrier(0);
         }
