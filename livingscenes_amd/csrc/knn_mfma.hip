@@ -562,7 +562,10 @@ __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restr
     if (h == 0 && live) norms[(size_t)b * N + r] = s;
 }
 
-template <int D>
+// QG (round 3, A/B only -- LS_KNN_SWEEP_QG=2): a wave sweeps QG groups of 32 queries against every candidate fragment it loads, which
+// halves the L2 -> CU stream of the candidate image (layer 1: 2 048 waves x 196 KB = 403 MB per launch with one group).  Measured slower
+// (see knn_sweep_launch_t): the kernel is latency-, not stream-bound.  One group is the default.
+template <int D, int QG>
 __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
                                                              const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
                                                              const float* __restrict__ nrm_src, int Nd, int dst_n, int dst_npad, int Ns,
@@ -570,65 +573,73 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
                                                              const u64* __restrict__ seedkeys, int32_t* __restrict__ surv_cnt,
                                                              unsigned short* __restrict__ surv) {
     constexpr int KK = D / 16;
-    // dynamic LDS, per wave: hint bitmap 32 x (ns_pad / 32) words | survivor counters [32] | survivor lists [32][KB_CAPW] u16
+    constexpr int CAPW = KB_CAPW / QG;   // survivor slots per (wave, query) in LDS
+    constexpr int NQW = 32 * QG;         // queries per wave
+    // dynamic LDS, per wave: hint bitmap NQW x (ns_pad / 32) words | survivor counters [NQW] | survivor lists [NQW][CAPW] u16
     extern __shared__ __attribute__((aligned(16))) unsigned lds_dyn[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // consecutive waves (one instance) share an XCD's L2
     if (wg >= total_waves) return;                                // (no workgroup barrier in this kernel)
     const int sp = wg % nsplit, g = (wg / nsplit) % qgroups, b = wg / (nsplit * qgroups);
-    const int q0 = g * 32, l31 = lane & 31, lh = lane >> 5;
+    const int q0 = g * NQW, l31 = lane & 31, lh = lane >> 5;
     const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
     const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
     const float* nsb = nrm_src + (size_t)b * Ns;
     const float om = 1.0f - epsB;
     const int words = ns_pad >> 5;
-    const int per_wave = 32 * words + 32 + 32 * KB_CAPW / 2;   // 32-bit words
+    const int per_wave = NQW * words + NQW + NQW * CAPW / 2;   // 32-bit words
     unsigned* bits = lds_dyn + (size_t)wave * per_wave;
-    int* lcnt = reinterpret_cast<int*>(bits + 32 * words);
-    unsigned short* llist = reinterpret_cast<unsigned short*>(lcnt + 32);
+    int* lcnt = reinterpret_cast<int*>(bits + NQW * words);
+    unsigned short* llist = reinterpret_cast<unsigned short*>(lcnt + NQW);
 
-    // A fragments: query row q0 + l31 (padding queries: row 0; their threshold drops everything)
-    bf16x8 a[KK];
-    {
-        const int qi = q0 + l31;
+    // A fragments: query row q0 + 32 u + l31 (padding queries: row 0; their threshold drops everything)
+    bf16x8 a[QG][KK];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int qi = q0 + 32 * u + l31;
         const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
         const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
     // drop  <=>  d^ - eps nn > kth  <=>  S~ < ((1-eps)(nq + ns) - kth) / 2 = A[row] + Bc[candidate]
-    float A[16];
+    float A[QG][16];
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const int q = q0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-        float v = INFINITY;                                        // padding query: S < inf, always dropped
-        if (q < Nd) {
-            const int row = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
-            const unsigned hi = (unsigned)(seedkeys[((size_t)b * Nd + q) * 16 + (K - 1)] >> 32);
-            const float kth = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);   // fewer than K distinct hints: nothing is dropped
-            v = 0.5f * (om * nrm_dst[(size_t)b * dst_n + row] - kth);
+    for (int u = 0; u < QG; ++u)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int q = q0 + 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            float v = INFINITY;                                        // padding query: S < inf, always dropped
+            if (q < Nd) {
+                const int row = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
+                const unsigned hi = (unsigned)(seedkeys[((size_t)b * Nd + q) * 16 + (K - 1)] >> 32);
+                const float kth = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);   // fewer than K distinct hints: nothing is dropped
+                v = 0.5f * (om * nrm_dst[(size_t)b * dst_n + row] - kth);
+            }
+            A[u][rr] = v;
         }
-        A[rr] = v;
-    }
-    // hint bitmap of the wave's 32 queries.  The keys are loaded BEFORE the LDS clear (the wave barriers are scheduling fences: the
+    // hint bitmap of the wave's queries.  The keys are loaded BEFORE the LDS clear (the wave barriers are scheduling fences: the
     // loads would otherwise be issued only after the clear, one more exposed memory round trip per wave)
-    uint4 hk[4];
-    {
-        const int qh = min(q0 + l31, Nd - 1);
+    uint4 hk[QG][4];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int qh = min(q0 + 32 * u + l31, Nd - 1);
         const uint4* kp = reinterpret_cast<const uint4*>(seedkeys + ((size_t)b * Nd + qh) * 16 + lh * 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hk[e] = kp[e];
+        for (int e = 0; e < 4; ++e) hk[u][e] = kp[e];
     }
-    for (int i = lane; i < 32 * words + 32; i += 64) bits[i] = 0u;   // bitmap and counters
+    for (int i = lane; i < NQW * words + NQW; i += 64) bits[i] = 0u;   // bitmap and counters
     __builtin_amdgcn_wave_barrier();
-    if (q0 + l31 < Nd) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (hk[e].y != 0xFFFFFFFFu) atomicOr(&bits[l31 * words + (hk[e].x >> 5)], 1u << (hk[e].x & 31));
-            if (hk[e].w != 0xFFFFFFFFu) atomicOr(&bits[l31 * words + (hk[e].z >> 5)], 1u << (hk[e].z & 31));
+    for (int u = 0; u < QG; ++u)
+        if (q0 + 32 * u + l31 < Nd) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (hk[u][e].y != 0xFFFFFFFFu) atomicOr(&bits[(32 * u + l31) * words + (hk[u][e].x >> 5)], 1u << (hk[u][e].x & 31));
+                if (hk[u][e].w != 0xFFFFFFFFu) atomicOr(&bits[(32 * u + l31) * words + (hk[u][e].z >> 5)], 1u << (hk[u][e].z & 31));
+            }
         }
-    }
     __builtin_amdgcn_wave_barrier();
 
     const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
@@ -641,43 +652,49 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
         for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = t * 32 + l31;
         const float Bc = 0.5f * om * nsb[min(cg, Ns - 1)];
-        f32x16 S;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+        for (int u = 0; u < QG; ++u) {
+            f32x16 S;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bf[kk], S, 0, 0, 0);
-        unsigned mask = 0;
+            for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mask |= (S[r] < A[r] + Bc) ? 0u : (1u << r);
-        if (cg >= Ns) mask = 0;
-        while (mask) {
-            const int r = __builtin_ctz(mask);
-            mask &= mask - 1;
-            const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh, q = q0 + qr;
-            if (q < Nd && !((bits[qr * words + (cg >> 5)] >> (cg & 31)) & 1u)) {   // a hint's key is in the seeded list already
-                // wave-private list first (an LDS atomic returns in ~100 cycles; a returning global atomic per survivor inside
-                // this per-lane serial loop costs a memory round trip each); a full list spills to the global path directly
-                const int lp = atomicAdd(&lcnt[qr], 1);
-                if (lp < KB_CAPW) {
-                    llist[qr * KB_CAPW + lp] = (unsigned short)cg;
-                } else {
-                    const size_t qg = (size_t)b * Nd + q;
-                    const int pos = atomicAdd(&surv_cnt[qg], 1);
-                    if (pos < KS_CAP) surv[qg * KS_CAP + pos] = (unsigned short)cg;
+            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][kk], bf[kk], S, 0, 0, 0);
+            unsigned mask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mask |= (S[r] < A[u][r] + Bc) ? 0u : (1u << r);
+            if (cg >= Ns) mask = 0;
+            while (mask) {
+                const int r = __builtin_ctz(mask);
+                mask &= mask - 1;
+                const int qr = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh, q = q0 + qr;
+                if (q < Nd && !((bits[qr * words + (cg >> 5)] >> (cg & 31)) & 1u)) {   // a hint's key is in the seeded list already
+                    // wave-private list first (an LDS atomic returns in ~100 cycles; a returning global atomic per survivor inside
+                    // this per-lane serial loop costs a memory round trip each); a full list spills to the global path directly
+                    const int lp = atomicAdd(&lcnt[qr], 1);
+                    if (lp < CAPW) {
+                        llist[qr * CAPW + lp] = (unsigned short)cg;
+                    } else {
+                        const size_t qg = (size_t)b * Nd + q;
+                        const int pos = atomicAdd(&surv_cnt[qg], 1);
+                        if (pos < KS_CAP) surv[qg * KS_CAP + pos] = (unsigned short)cg;
+                    }
                 }
             }
         }
     }
     // flush: one global atomic per query reserves the wave's slots
     __builtin_amdgcn_wave_barrier();
-    if (lh == 0 && q0 + l31 < Nd) {
-        const int n = min(lcnt[l31], KB_CAPW);
-        if (n > 0) {
-            const size_t qg = (size_t)b * Nd + q0 + l31;
-            const int base = atomicAdd(&surv_cnt[qg], n);
-            for (int i = 0; i < n && base + i < KS_CAP; ++i) surv[qg * KS_CAP + base + i] = llist[l31 * KB_CAPW + i];
+#pragma unroll
+    for (int u = 0; u < QG; ++u)
+        if (lh == 0 && q0 + 32 * u + l31 < Nd) {
+            const int qr = 32 * u + l31;
+            const int n = min(lcnt[qr], CAPW);
+            if (n > 0) {
+                const size_t qg = (size_t)b * Nd + q0 + qr;
+                const int base = atomicAdd(&surv_cnt[qg], n);
+                for (int i = 0; i < n && base + i < KS_CAP; ++i) surv[qg * KS_CAP + base + i] = llist[qr * CAPW + i];
+            }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -687,7 +704,7 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
 // knn_autohint_select_kernel keeps the 16 best of them by approximate distance.  A true neighbour is missed only if a better
 // one shares its class (~2 of 16 with 64 classes), so the K-th exact distance among these hints is close to the final one and
 // the seeded pipeline above runs unchanged.  Hints never influence the result.
-template <int D>
+template <int D, int QG>
 __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
                                                                 const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_src,
                                                                 int Nd, int dst_npad, int Ns, int ns_pad, int qgroups, int nsplit,
@@ -698,22 +715,25 @@ __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned s
     const int wg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (wg >= total_waves) return;
     const int sp = wg % nsplit, g = (wg / nsplit) % qgroups, b = wg / (nsplit * qgroups);
-    const int q0 = g * 32, l31 = lane & 31, lh = lane >> 5;
+    const int q0 = g * 32 * QG, l31 = lane & 31, lh = lane >> 5;
     const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
     const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
     const float* nsb = nrm_src + (size_t)b * Ns;
-    bf16x8 a[KK];
-    {
-        const int qi = q0 + l31;
+    bf16x8 a[QG][KK];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const int qi = q0 + 32 * u + l31;
         const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
         const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
-    float best[16];
-    int bt[16];
+    float best[QG][16];
+    int bt[QG][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { best[r] = -INFINITY; bt[r] = -1; }
+    for (int u = 0; u < QG; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { best[u][r] = -INFINITY; bt[u][r] = -1; }
     const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
     const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
 #pragma unroll 2
@@ -724,27 +744,32 @@ __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned s
         for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = t * 32 + l31;
         const float hb = cg < Ns ? 0.5f * nsb[min(cg, Ns - 1)] : INFINITY;   // padding columns can never win
-        f32x16 S;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = -hb;                              // S - |s|^2 / 2: largest = nearest (|q|^2 is per query)
+        for (int u = 0; u < QG; ++u) {
+            f32x16 S;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bf[kk], S, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) S[r] = -hb;                          // S - |s|^2 / 2: largest = nearest (|q|^2 is per query)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][kk], bf[kk], S, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool better = S[r] > best[u][r];
+                best[u][r] = better ? S[r] : best[u][r];
+                bt[u][r] = better ? t : bt[u][r];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QG; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool better = S[r] > best[r];
-            best[r] = better ? S[r] : best[r];
-            bt[r] = better ? t : bt[r];
+            const int q = q0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < Nd) {
+                const size_t o = (((size_t)b * Nd + q) * nsplit + sp) * 32 + l31;
+                win_val[o] = best[u][r];
+                win_idx[o] = bt[u][r] >= 0 ? bt[u][r] * 32 + l31 : -1;
+            }
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (q < Nd) {
-            const size_t o = (((size_t)b * Nd + q) * nsplit + sp) * 32 + l31;
-            win_val[o] = best[r];
-            win_idx[o] = bt[r] >= 0 ? bt[r] * 32 + l31 : -1;
-        }
-    }
 }
 // one wave per query: the 16 best of its W = 32 * nsplit <= 64 class winners -> hints[q][16]
 __global__ __launch_bounds__(256) void knn_autohint_select_kernel(const float* __restrict__ win_val, const int32_t* __restrict__ win_idx, int W,
@@ -810,6 +835,11 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     unsigned short* dq = sq;
     if (dst != src) dq = sq + (size_t)B * ns_pad * D;
     int rc;
+    // query groups per sweep wave (knn_sweep_bf16_kernel): LS_KNN_SWEEP_QG=2 halves the candidate stream per query (A/B; measured SLOWER in
+    // round 3 -- k-NN build 138 / 102 / 148 / 92 us at layers 1 - 4 with one group, 161 / 133 / 152 / 97 us with two: the sweep is bound by
+    // the latency of its fragment loads at 2 - 3 waves per SIMD, not by the L2 stream -- so one group stays the default)
+    static const int qg_env = getenv("LS_KNN_SWEEP_QG") ? atoi(getenv("LS_KNN_SWEEP_QG")) : 0;
+    const int qg = (qg_env == 2 && Nd >= 64) ? 2 : 1;
     float* win_val = nullptr;      // auto hints: class winners of the first sweep (selected inside the seed kernel)
     int32_t* win_idx = nullptr;
     int win_w = 0;
@@ -828,12 +858,17 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
             unsigned short* img_end = dq + (size_t)B * dst_npad * D;
             win_val = (float*)(((uintptr_t)img_end + 255) & ~(uintptr_t)255);
             win_idx = (int32_t*)(win_val + nq * 64);
-            const int qgroups = cdiv(Nd, 32);
-            const int nsplit = ((long long)B * qgroups < 4096 && ns_pad / 32 >= 16) ? 2 : 1;   // W = 32 nsplit <= 64 winners per query
-            const int total_waves = B * qgroups * nsplit;
+            const int nsplit = ((long long)B * cdiv(Nd, 32) < 4096 && ns_pad / 32 >= 16) ? 2 : 1;   // W = 32 nsplit <= 64 winners per query
             win_w = 32 * nsplit;
-            hipLaunchKernelGGL(knn_sweep_winners_kernel<D>, dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, Nd, dst_npad,
-                               Ns, ns_pad, qgroups, nsplit, total_waves, win_val, win_idx);
+            if (qg == 2) {
+                const int qgroups = cdiv(Nd, 64), total_waves = B * qgroups * nsplit;
+                hipLaunchKernelGGL((knn_sweep_winners_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, Nd, dst_npad,
+                                   Ns, ns_pad, qgroups, nsplit, total_waves, win_val, win_idx);
+            } else {
+                const int qgroups = cdiv(Nd, 32), total_waves = B * qgroups * nsplit;
+                hipLaunchKernelGGL((knn_sweep_winners_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, Nd, dst_npad,
+                                   Ns, ns_pad, qgroups, nsplit, total_waves, win_val, win_idx);
+            }
             LS_LAUNCH_CHECK();
             static const bool sel_launch = getenv("LS_KNN_SELECT_LAUNCH") && atoi(getenv("LS_KNN_SELECT_LAUNCH")) != 0;   // A/B: the separate select launch
             if (sel_launch) {
@@ -875,14 +910,19 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
                            seed_by_row, seedkeys, groups, B * groups, (const float*)nullptr, (const int32_t*)nullptr, 0);
     LS_LAUNCH_CHECK();
     if (bf16) {
-        const int qgroups = cdiv(Nd, 32);
+        const int nqw = 32 * qg;                    // queries per wave
+        const int qgroups = cdiv(Nd, nqw);
         int nsplit = 1;   // >= ~4 waves per SIMD over the chip (4096 waves) when the query grid alone is smaller
         while ((long long)B * qgroups * nsplit < 4096 && nsplit * 8 <= ns_pad / 32 && nsplit < 16) nsplit *= 2;   // >= 4 tiles per wave
         const int total_waves = B * qgroups * nsplit;
         const float epsB = 1.02f * 0.0078125f + epsE;
-        const size_t lds = (size_t)4 * (32 * (ns_pad / 32) + 32 + 32 * KB_CAPW / 2) * sizeof(unsigned);   // <= 52 KB
-        hipLaunchKernelGGL(knn_sweep_bf16_kernel<D>, dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, Nd, dst_n,
-                           dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
+        const size_t lds = (size_t)4 * (nqw * (ns_pad / 32) + nqw + nqw * (KB_CAPW / qg) / 2) * sizeof(unsigned);   // <= 52 KB (QG = 2: <= 50 KB)
+        if (qg == 2)
+            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, Nd, dst_n,
+                               dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
+        else
+            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, Nd, dst_n,
+                               dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
     } else {
         hipLaunchKernelGGL(knn_sweep_kernel<CC>, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles,
                            epsE, seedkeys, surv_cnt, surv);
