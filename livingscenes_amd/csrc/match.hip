@@ -109,6 +109,28 @@ __global__ __launch_bounds__(1024) void greedy_match_kernel(float* __restrict__ 
 // n * m <= 1024 (the reference's scenes: up to 32 x 32): the WHOLE loop in one wave, the matrix in registers (16 entries per lane,
 // entry e = lane + 64 k), wave reductions on the DPP network, no LDS and no barrier: 3 barrier-separated block reductions per
 // iteration made the 1024-thread kernel above cost 2.4 us per assignment (77 us for 32 x 32).  Same arithmetic, same tie rule.
+// wave reductions on the DPP network with the result broadcast through lane 63 (v_readlane): the __shfl_xor forms go through the LDS
+// crossbar (ds_bpermute, ~100 cycles each; 18 of them per assignment made the 32 x 32 loop cost 56 us of pure latency)
+template <int CTRL, int RM>
+__device__ __forceinline__ int gm_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false); }
+__device__ __forceinline__ float gm_wave_max(float v) {
+    v = fmaxf(v, __int_as_float(gm_dpp<0xB1, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(gm_dpp<0x4E, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(gm_dpp<0x141, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(gm_dpp<0x140, 0xF>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(gm_dpp<0x142, 0xA>(__float_as_int(v))));   // row_bcast15 -> rows 1, 3
+    v = fmaxf(v, __int_as_float(gm_dpp<0x143, 0xC>(__float_as_int(v))));   // row_bcast31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int gm_wave_min(int v) {
+    v = min(v, gm_dpp<0xB1, 0xF>(v));
+    v = min(v, gm_dpp<0x4E, 0xF>(v));
+    v = min(v, gm_dpp<0x141, 0xF>(v));
+    v = min(v, gm_dpp<0x140, 0xF>(v));
+    v = min(v, gm_dpp<0x142, 0xA>(v));
+    v = min(v, gm_dpp<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __global__ __launch_bounds__(64) void greedy_match_wave_kernel(const float* __restrict__ S, int n, int m, long long* __restrict__ m0,
                                                               long long* __restrict__ m1) {
     const int lane = threadIdx.x;
@@ -132,17 +154,16 @@ __global__ __launch_bounds__(64) void greedy_match_wave_kernel(const float* __re
         float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 16; ++k) if (alive >> k & 1) mx = fmaxf(mx, v[k]);
-        mx = wave_max(mx);
+        mx = gm_wave_max(mx);
         const float denom = mx + 1e-5f;            // S /= (max + 1e-5)   (matcher_new.py:123)
         float mx2 = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 16; ++k) if (alive >> k & 1) { v[k] = v[k] / denom; mx2 = fmaxf(mx2, v[k]); }
-        mx2 = wave_max(mx2);
+        mx2 = gm_wave_max(mx2);
         int pos = INT_MAX;                         // first row-major position holding the maximum: smallest e
 #pragma unroll
         for (int k = 15; k >= 0; --k) if ((alive >> k & 1) && v[k] == mx2) pos = lane + 64 * k;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) pos = min(pos, __shfl_xor(pos, o, 64));
+        pos = gm_wave_min(pos);
         if (pos == INT_MAX) break;                 // NaN scores: the reference would raise here
         const int r = pos / m, c = pos - r * m;
         if (lane == 0) { m0[r] = c; m1[c] = r; }
