@@ -109,7 +109,9 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     if kind == "vn_act":
         return B * Nd * 3 * 3 * Co * f4, 30.0 * B * Nd * Co, FP32_PEAK_TFLOPS, "fp32 VALU flops"
     if kind == "mean":
-        return B * Nd * 3 * Co * f4, 1.0 * B * Nd * 3 * Co, FP32_PEAK_TFLOPS, "fp32 VALU flops"
+        # mean over the points + the per-instance half of the global conv's VecLinear in one launch (pointwise.hip: glob_mean_gemv_kernel)
+        return (B * Nd * 3 * Co * f4 + 2 * Co * Co * f4 + B * 3 * 2 * Co * f4, 1.0 * B * Nd * 3 * Co + 2.0 * B * 3 * Co * 2 * Co, FP32_PEAK_TFLOPS,
+                "fp32 VALU flops (mean over the points + the [3, C] x [C, 2C] contraction of the mean rows)")
     if kind == "fps":
         n = [N] + [p["Nd"] for p in pl if p["Nd"] != p["Ns"]]
         return B * n[min(layer, len(n) - 1)] * 12, 0.0, FP32_PEAK_TFLOPS, "latency-bound (dependent arg-max steps)"
@@ -347,7 +349,7 @@ def main():
         dom = max((q for q in prof if q["kind"] == dom_kind), key=lambda q: q["total_ms"])
         roof = roofline_entry(dom["kind"], dom["layer"], dom["total_ms"] / dom["launches"] * 1e-3, ecfg, B, N, bf16x3)
         if dom["kind"] == "knn":
-            roof["note"] = ("one k-NN graph build = the launch sequence of that layer (centre / bf16 image / hints / seed / sweep / finish); "
+            roof["note"] = ("one k-NN graph build = the launch sequence of that layer (bf16 image incl. centre / [class-winner sweep] / seed incl. hint selection / sweep / finish: 4 - 5 launches); "
                             "bound by fp32 VALU issue on the direct-difference-equivalent count -- see `basis`")
         roof["timing"] = f"hipEvent pair per launch on the launching stream, separate profiled pass of {prof_steps} steps (one step in flight)"
         roof["share_of_device_time"] = dom["total_ms"] / max(tot, 1e-9)
