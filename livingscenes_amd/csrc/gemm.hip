@@ -63,8 +63,8 @@ __device__ __forceinline__ void split3_bf16(const float4& v, uint2& p1, uint2& p
 // three-piece bf16 split (scripts/gemm_microbench.py --check: 6.5 - 7.3 vs 5.9 - 8.4 units of 2^-24 sum|a||w| at K = 32 .. 768 --
 // both are the fp32 accumulation error any fp32 GEMM carries; the split error itself is 8e-8 of the largest output) at half the
 // matrix-pipe time and three VALU instructions per split value (v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add, v_pk_mul,
-// v_cvt_pk_f16_f32 per PAIR) instead of 5.5.  Precondition: |a| < 65 504 (f16 range); the encoder's normalised features and the
-// decoder's activations are O(1 - 100).  LS_GEMM_MODE=bf16x3 keeps the six-MFMA split (any fp32 range).
+// v_cvt_pk_f16_f32 per PAIR) instead of 5.5.  The f16 range (|a| < 65 504, 22 bits only above 2^-13) is made to follow every operand ROW
+// by an exact power-of-two scale: "operand range of the f16 split" below.  LS_GEMM_MODE=bf16x3 keeps the six-MFMA split.
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split2_f16_pair(f32x2_t v, unsigned& h, unsigned& l) {
@@ -1190,6 +1190,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_vn_kernel for K = 32 / 64 (the residual global conv of encoder layers 2 / 3: 98 304 rows, 128 tile columns, TWO 32-k slabs),
+// PERSISTENT over the M-tiles of one channel block like gemm_h2_smallk_kernel (round 3).  In the tiled kernel such a problem is all
+// prologue and epilogue -- load, split, barrier, 48 MFMAs, stage, activate, store, one after the other with two workgroups per CU:
+// 34 us for 50 MB of compulsory traffic.  Here the weight tile is split once per workgroup, the whole-K A tile of M-tile t+1 is in flight
+// (registers) under the MFMAs, the activation and the stores of tile t.  Same row / column maps, same products, same accumulation order
+// and the same epilogue as gemm_vn_kernel: bit-identical results.
+template <int KK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_vn_smallk_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ G, int ldg, float* __restrict__ out,
+    int M, int C, int npts, float oms, int ntiles_m, int per_n, int ntiles_n, GemmAux aux) {
+    constexpr int TR = 30;
+    constexpr int STG = 32 * 68;
+    constexpr int NSL = KK / 32;
+    constexpr int PLANE = GM * 64;
+    constexpr int OPER = 2 * NSL * PLANE;
+    constexpr int ABYTES = (OPER > 4 * STG * 4) ? OPER : 4 * STG * 4;   // the A planes double as the epilogue staging area
+    __shared__ __attribute__((aligned(16))) char smem[ABYTES + OPER];
+    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];
+    char* Ap = smem;
+    char* Bp = smem + ABYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tn = blockIdx.x / per_n, slot = blockIdx.x % per_n;
+    const int c0 = tn * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int sr0 = tid >> 3, sk = (tid & 7) * 4;
+    int swz[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = sr0 + h * 32;
+        swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
+    }
+    auto lstore2 = [&](char* base, int slab, const float4& v, float sc, int off) {
+        uint2 ph, pl;
+        split2_f16s<0>(v, sc, ph, pl);
+        *reinterpret_cast<uint2*>(base + (2 * slab) * PLANE + off) = ph;
+        *reinterpret_cast<uint2*>(base + (2 * slab + 1) * PLANE + off) = pl;
+    };
+    const bool scaled = !aux.noscale;
+    if (!scaled) rsc[tid] = 1.f;
+    // W tile, once: staged row sr0 + 32 h = tile column (wn = h >> 1, lin | dir = h & 1, channel sr0)
+    {
+        float4 rw[NSL][4];
+        int wrow[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            wrow[h] = (h & 1) * C + c0 + 32 * (h >> 1) + sr0;
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) rw[sl][h] = *reinterpret_cast<const float4*>(W + (size_t)wrow[h] * ldw + sl * 32 + sk);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float sw = 1.f;
+            if (scaled) {
+                float mw = 0.f, iw;
+                if (aux.w_rowmax) mw = aux.w_rowmax[wrow[h]];
+                else {
+#pragma unroll
+                    for (int sl = 0; sl < NSL; ++sl) mw = amax4(mw, rw[sl][h]);
+                    mw = max8(mw);
+                }
+                pow2_scale(mw, sw, iw);
+                if ((tid & 7) == 0) rsc[GM + sr0 + h * 32] = iw;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) lstore2(Bp, sl, rw[sl][h], sw, swz[h]);
+        }
+    }
+    const int lr = lane & 31;
+    int offa[2], offb[2], xa[2], xb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra_ = wm * 64 + i * 32 + lr, rb_ = wn * 64 + i * 32 + lr;
+        offa[i] = ra_ * 64; offb[i] = rb_ * 64; xa[i] = (ra_ >> 2) & 3; xb[i] = (rb_ >> 2) & 3;
+    }
+    float4 ra[NSL][4];
+    int arow[4];   // source row of this thread's four staged rows (staged row sr0 + 32 h = row sr0 of M-tile h; rows past the tile / past M: clamped)
+    auto load_tile = [&](int tmx) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            arow[h] = min(tmx * 4 * TR + h * TR + min(sr0, TR - 1), M - 1);
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) ra[sl][h] = *reinterpret_cast<const float4*>(A + (size_t)arow[h] * lda + sl * 32 + sk);
+        }
+    };
+    int tm = slot;
+    load_tile(min(tm, ntiles_m - 1));
+    for (; tm < ntiles_m; tm += per_n) {
+        const int m0 = tm * 4 * TR;
+        __syncthreads();                               // previous tile's staging and scale reads are done (and the W planes are written)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float sa = 1.f;
+            if (scaled) {
+                float ma = 0.f, ia;
+                if (aux.a_rowmax) {
+                    for (int q = 0; q < aux.a_parts; ++q) ma = fmaxf(ma, aux.a_rowmax[(size_t)arow[h] * aux.a_parts + q]);
+                } else {
+#pragma unroll
+                    for (int sl = 0; sl < NSL; ++sl) ma = amax4(ma, ra[sl][h]);
+                    ma = max8(ma);
+                }
+                pow2_scale(ma, sa, ia);
+                if ((tid & 7) == 0) rsc[sr0 + h * 32] = ia;
+            }
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) lstore2(Ap, sl, ra[sl][h], sa, swz[h]);
+        }
+        __syncthreads();
+        load_tile(min(tm + per_n, ntiles_m - 1));      // next A tile in flight under the MFMAs, the activation and the stores
+
+        f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int q = s2 * 2 + (lane >> 5);
+                f16x8_t a[2][2], b[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ap + (2 * sl + pc) * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
+                        b[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bp + (2 * sl + pc) * PLANE + offb[i] + ((q ^ xb[i]) << 4)));
+                    }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+            }
+        __syncthreads();                               // every wave is done with the A planes: they become the staging area
+        float* stg = reinterpret_cast<float*>(Ap) + wave * STG;
+        const int col_l = lane & 31, rowh = (lane >> 5) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                    const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                    for (int rl = 0; rl < 4; ++rl) {
+                        const int r = r4 * 4 + rl;
+                        stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs);
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            const int row0 = m0 + (wm * 2 + i) * TR;       // first row of this M-tile
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int item = it * 64 + lane, pl = item >> 5, c = item & 31;   // point 0..9 of the tile, channel
+                const int grow = row0 + 3 * pl;
+                float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+                if (grow < M) {
+                    const int ch = c0 + 32 * wn + c;
+                    const float* g = G + (size_t)((grow / 3) / npts) * 3 * ldg + 2 * C + ch;
+                    const float* sp = stg + 3 * pl * 68 + c;
+                    y0 = sp[0] + g[0]; y1 = sp[68] + g[ldg]; y2 = sp[136] + g[2 * ldg];
+                    const float k0 = sp[32] + g[C], k1 = sp[68 + 32] + g[ldg + C], k2 = sp[136 + 32] + g[2 * ldg + C];
+                    vn_act(y0, y1, y2, k0, k1, k2, oms);
+                    float* op = out + (size_t)grow * C + ch;
+                    op[0] = y0; op[C] = y1; op[2 * C] = y2;
+                }
+                if (aux.out_rowmax) {   // wave-uniform; [M][C / 32]
+                    float m0_ = max16(fabsf(y0)), m1_ = max16(fabsf(y1)), m2_ = max16(fabsf(y2));
+                    m0_ = fmaxf(m0_, __shfl_xor(m0_, 16, 64)); m1_ = fmaxf(m1_, __shfl_xor(m1_, 16, 64)); m2_ = fmaxf(m2_, __shfl_xor(m2_, 16, 64));
+                    if (c == 0 && grow < M) {
+                        float* rp = aux.out_rowmax + (size_t)grow * (2 * ntiles_n) + 2 * tn + wn;
+                        rp[0] = m0_; rp[2 * ntiles_n] = m1_; rp[4 * ntiles_n] = m2_;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // split-K combine: out[m][n] = act(sum_s slab[s][m][n] + bias[n]), slices summed in ascending order (deterministic)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ out, int ldc,
@@ -1356,6 +1551,15 @@ int gemm_vn_dispatch(const float* A, int lda, const float* W, int ldw, const flo
     if (range_off) aux.noscale = 1;
     LS_REQUIRE(gemm_vn_supported(M, C, K) && lda % 4 == 0 && ldw % 4 == 0, "gemm_vn: unsupported shape (M=%d C=%d K=%d)", M, C, K);
     const int tm = cdiv(M, 120), tn = C / 64;
+    static const bool persist = !(getenv("LS_GLOB_PERSIST") && atoi(getenv("LS_GLOB_PERSIST")) == 0);   // A/B: K = 32 / 64 on the tiled kernel
+    if (persist && (K == 32 || K == 64) && tm >= 16 && lda == K) {
+        int per_n = cdiv(512, tn);   // two resident workgroups per CU
+        if (per_n > tm) per_n = tm;
+        if (K == 32) hipLaunchKernelGGL(gemm_vn_smallk_kernel<32>, dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, npts, oms, tm, per_n, tn, aux);
+        else hipLaunchKernelGGL(gemm_vn_smallk_kernel<64>, dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, npts, oms, tm, per_n, tn, aux);
+        LS_LAUNCH_CHECK();
+        return LS_OK;
+    }
     if (K % 32 == 0) hipLaunchKernelGGL(gemm_vn_kernel<true>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn, aux);
     else hipLaunchKernelGGL(gemm_vn_kernel<false>, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, K, npts, oms, tn, aux);
     LS_LAUNCH_CHECK();
