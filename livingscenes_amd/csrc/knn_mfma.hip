@@ -913,7 +913,8 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         const int nqw = 32 * qg;                    // queries per wave
         const int qgroups = cdiv(Nd, nqw);
         int nsplit = 1;   // >= ~4 waves per SIMD over the chip (4096 waves) when the query grid alone is smaller
-        while ((long long)B * qgroups * nsplit < 4096 && nsplit * 8 <= ns_pad / 32 && nsplit < 16) nsplit *= 2;   // >= 4 tiles per wave
+        static const int wave_target = getenv("LS_KNN_SWEEP_WAVES") ? atoi(getenv("LS_KNN_SWEEP_WAVES")) : 4096;   // A/B
+        while ((long long)B * qgroups * nsplit < wave_target && nsplit * 8 <= ns_pad / 32 && nsplit < 16) nsplit *= 2;   // >= 4 tiles per wave
         const int total_waves = B * qgroups * nsplit;
         const float epsB = 1.02f * 0.0078125f + epsE;
         const size_t lds = (size_t)4 * (nqw * (ns_pad / 32) + nqw + nqw * (KB_CAPW / qg) / 2) * sizeof(unsigned);   // <= 52 KB (QG = 2: <= 50 KB)

@@ -101,6 +101,24 @@ def test_hint_policy_never_changes_the_codes(tmp_path):
             assert np.array_equal(outs[pol][k], outs["mixed"][k]), (pol, k)
 
 
+def test_use_double_returns_float64_codes_of_the_fp32_path(small_prior):
+    """Shape_Prior(use_double=True) (model_utils.py:148-152,166: fp64 encoder in the reference): the fp32 HIP encoder runs and the codes
+    are float64 -- equal to the fp32 codes, and within 1e-4 of the oracle evaluated in fp64."""
+    from oracle import net
+    sp, (ecfg, dcfg, ew, dw) = small_prior
+    x = synth.make_instances(3, 128, seed=12)
+    emb32 = sp.encode(x.to(_dev()))
+    sp.use_double = True
+    try:
+        emb64 = sp.encode(x.to(_dev()))
+    finally:
+        sp.use_double = False
+    ref = net.shape_prior_encode({k: v.double() for k, v in ew.items()}, ecfg, x.double())
+    for k in ("z_so3", "z_inv", "s", "t"):
+        assert emb64[k].dtype == torch.float64 and torch.equal(emb64[k], emb32[k].double())
+        assert relerr(emb64[k], ref[k]) < TOL, k
+
+
 def test_encode_fps_ragged_matches_reference_loop(small_prior):
     """encode_fps (model_utils.py:199-215): mask-select, FPS to n_pcl, encode -- vs the oracle run instance by instance."""
     from oracle import net

@@ -102,9 +102,10 @@ def test_shape_prior_checkpoint_roundtrip(tmp_path):
         assert torch.equal(sp.encoder.state_dict()[k], v)
     for k, v in dw.items():
         assert torch.equal(sp.decoder.F.state_dict()[k], v)
-    with pytest.raises(NotImplementedError):
-        Shape_Prior({"working_dir": "/", "field_cfg": str(tmp_path / "files_backup" / "model_config.yaml"),
-                     "field_pt": str(tmp_path / "checkpoint" / "x_latest.pt")}, "chair", use_double=True)
+    # use_double (model_utils.py:148-152): accepted -- the fp32 kernels run and the codes come back as float64 (tests/test_hip_surface.py)
+    spd = Shape_Prior({"working_dir": "/", "field_cfg": str(tmp_path / "files_backup" / "model_config.yaml"),
+                       "field_pt": str(tmp_path / "checkpoint" / "x_latest.pt")}, "chair", use_double=True)
+    assert spd.use_double is True and sp.use_double is False
     room = tmp_path / "room.yaml"
     room.write_text(yaml.safe_dump({"shape_priors": {"chair": {}}, "solver_global": {"use_double": False}}))
     if not torch.cuda.is_available():
