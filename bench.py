@@ -277,6 +277,9 @@ def main():
     # a straggling step that the K-step mean hides (the driver's 20-step region is ~35 ms)
     done_ms = sorted(ev0.elapsed_time(e) for e in step_done)
     gaps = sorted(b - a for a, b in zip([0.0] + done_ms[:-1], done_ms))
+    if os.environ.get("LS_BENCH_DUMP_STEPS") and rank == 0:      # dev: the completion time of every timed step (ramp / drain shape)
+        print("step completion ms:", " ".join(f"{v:.2f}" for v in done_ms), f"| host enqueue {dt_host * 1e3:.2f} ms | total {dt * 1e3:.2f} ms",
+              file=sys.stderr)
     step_stats = {"inter_completion_ms_min": round(gaps[0], 4), "inter_completion_ms_median": round(gaps[len(gaps) // 2], 4),
                   "inter_completion_ms_p90": round(gaps[int(0.9 * (len(gaps) - 1))], 4), "inter_completion_ms_max": round(gaps[-1], 4),
                   "last_step_done_ms": round(done_ms[-1], 3)}

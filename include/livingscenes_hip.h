@@ -130,6 +130,18 @@ int ls_gemm_f32_ex(const float* A, int lda, const float* W, int ldw, const float
                    size_t workspace_bytes, void* stream);
 /* out[r] = max_k |X[r * ld + k]|, k < K  (X [rows, K]) */
 int ls_rowmax_f32(const float* X, int rows, int K, int ld, float* out, void* stream);
+/* A weight matrix that many GEMMs read can be split ONCE: planes = both f16 pieces of its range-scaled rows (4 * N * K bytes; row n =
+ * K / 32 lines of [hi: 32 f16 | lo: 32 f16] of s_n W[n, :], s_n the power of two of w_rowmax[n], which must be the same array later
+ * calls pass).  The
+ * K >= 512 kernels then stage W with 16-byte copies instead of re-splitting it in every workgroup (decoder shape: -5 % time).
+ * ls_gemm_w_planes_bytes = 0 -> no kernel reads planes at this K (K < 512 or K % 32 != 0): use ls_gemm_f32_ex.
+ * ls_gemm_f32_planes: ls_gemm_f32_ex with the planes (W itself is still passed: same result, bit for bit, as without them);
+ * never splits K.  F.linear of the reference (vec_layers.py:134, deepsdf_decoder.py:98-121) with a fixed weight. */
+size_t ls_gemm_w_planes_bytes(int N, int K);
+int ls_gemm_presplit_w_f32(const float* W, int ldw, int N, int K, const float* w_rowmax, void* planes, size_t planes_bytes, void* stream);
+int ls_gemm_f32_planes(const float* A, int lda, const float* W, int ldw, const void* w_planes, const float* bias, float* out, int ldc,
+                       int M, int N, int K, int relu, const float* a_rowmax, int a_parts, const float* w_rowmax, float* out_rowmax,
+                       void* stream);
 
 /* Shape_Prior.encode prologue, model_utils.py:166-177: centroid, scale_0 = mean of the 5 largest
  * entries of the N x N distance matrix, normalised cloud.

@@ -96,6 +96,9 @@ SIGNATURES = {
     "ls_gemm_rowmax_parts": (_I, [_I]),
     "ls_gemm_f32_ex": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "ls_rowmax_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "ls_gemm_w_planes_bytes": (_SZ, [_I, _I]),
+    "ls_gemm_presplit_w_f32": (_I, [_P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "ls_gemm_f32_planes": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "ls_encode_prologue_f32": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "ls_cosine_scores_workspace_bytes": (_SZ, [_I, _I]),
     "ls_cosine_scores_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),

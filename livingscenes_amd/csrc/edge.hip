@@ -443,7 +443,7 @@ typedef float ef2_t __attribute__((ext_vector_type(2)));
 typedef float ef16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void esplit_pair(ef2_t v, unsigned& h, unsigned& l) {
     const eh2_t hv = __builtin_convertvector(v, eh2_t);
-    const eh2_t lv = __builtin_convertvector((v - __builtin_convertvector(hv, ef2_t)) * 1024.f, eh2_t);
+    const eh2_t lv = __builtin_convertvector(v - __builtin_convertvector(hv, ef2_t), eh2_t);
     h = __builtin_bit_cast(unsigned, hv);
     l = __builtin_bit_cast(unsigned, lv);
 }
@@ -559,18 +559,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         for (int u = 0; u < 2; ++u) {
             const int mt = MT == 2 ? u : 0, nt = MT == 2 ? wave : wave + 4 * u;
             const int aoff = (32 * mt + (lane & 31)) * ASTR + (lane >> 5) * 16;
-            ef16_t acc, acx;
+            ef16_t acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const eh8_t ah = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(&a_pl[0][aoff + ks * 32]));
                 const eh8_t al = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(&a_pl[1][aoff + ks * 32]));
                 const eh8_t bh = __builtin_bit_cast(eh8_t, wt[((size_t)(nt * KS + ks) * 2) * 64]);
                 const eh8_t bl = __builtin_bit_cast(eh8_t, wt[((size_t)(nt * KS + ks) * 2 + 1) * 64]);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acx, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acx, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
             }
             // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); rows past the workgroup's points: dropped
             const int row0 = 32 * mt + 4 * (lane >> 5);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
-                if (row0 + dr < ROWS) sp[dr * SLD] = fmaf(acx[r], 0.0009765625f, acc[r]) * (a_inv[row0 + dr] * cs);
+                if (row0 + dr < ROWS) sp[dr * SLD] = acc[r] * (a_inv[row0 + dr] * cs);
             }
         }
     };

@@ -69,7 +69,7 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split2_f16_pair(f32x2_t v, unsigned& h, unsigned& l) {
     const f16x2_t hv = __builtin_convertvector(v, f16x2_t);
-    const f16x2_t lv = __builtin_convertvector((v - __builtin_convertvector(hv, f32x2_t)) * 1024.f, f16x2_t);
+    const f16x2_t lv = __builtin_convertvector(v - __builtin_convertvector(hv, f32x2_t), f16x2_t);
     h = __builtin_bit_cast(unsigned, hv);
     l = __builtin_bit_cast(unsigned, lv);
 }
@@ -224,13 +224,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     out += (size_t)blockIdx.y * slab_stride;
 
     constexpr bool H2 = PIECES == 22;   // two f16 pieces, scaled residual (see split2_f16)
-    f32x16 acc[2][2], acx[H2 ? 2 : 1][H2 ? 2 : 1];   // acx: the cross terms (x 1024) of the f16 split
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; if constexpr (H2) acx[i][j][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // staging map.  fp32 path: 128 rows x 4 float4 per operand slab, two per thread (rows sr0, sr0 + 64).  SPLIT: 128 rows x 8
     // float4 (32 k), four per thread (rows sr0 + 32 u)
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
                     continue;
                 }
                 bf16x8_t a[2][3], b[2][3];
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r];
-                if constexpr (H2) v = fmaf(acx[i][j][r], 0.0009765625f, v) * (rsc[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rowh] * cs);
+                if constexpr (H2) v = v * (rsc[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rowh] * cs);
                 v += bv;
                 if (relu) v = fmaxf(v, 0.0f);
                 stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
@@ -457,7 +457,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 // buffer t & 1, the same wave splits the global data of slab t+1 (already in registers) into buffer (t+1) & 1 and issues the loads
 // of slab t+2 -- VALU, LDS stores and global loads interleaved with the matrix instructions in one basic block, one barrier per slab.
 // Same arithmetic as gemm_f32_kernel<true, 22> (same products, same accumulation order per accumulator): bit-identical results.
-template <bool KAL>   // K range of this launch is a whole number of 32-k slabs
+// WPL: the W operand arrives PRE-SPLIT (GemmAux::w_planes: both f16 pieces of the scaled rows, written once per weight matrix by
+// gemm_presplit_w_kernel with the same split function): 16-byte loads straight into the LDS planes' layout, no VALU work for W in the
+// loop -- every W element used to be split again by each of the M / 128 workgroups that read it (measured at the decoder shape: the
+// kernel issues VALU instructions 56 % of the time, two thirds of them the split).  Bit-identical to the in-kernel split.
+template <bool KAL, bool WPL = false>   // KAL: the K range of this launch is a whole number of 32-k slabs
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_h2_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc,
     int M, int N, int K, int relu, int ntiles_n, const int32_t* __restrict__ a_rows, int gNd, int gNs, int kchunk, size_t slab_stride,
@@ -476,13 +480,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
     out += (size_t)blockIdx.y * slab_stride;
 
-    f32x16 acc[2][2], acx[2][2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // staging map: 128 rows x 8 float4 (32 k) per operand slab, four per thread (rows sr0 + 32 h).  Rows past M / N are clamped
     // (computed, never stored) and so is k past the end (KAL: whole slabs, the data is never used; otherwise per float4, zeroed by
@@ -502,6 +506,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
         arow[h] = A + r * lda;
         brow[h] = W + (size_t)gn * ldw;
+#if defined(LS_VAR_H2_SAMEA)       // dev timing variant: every workgroup reads the first A tile (all L2 hits)
+        arow[h] = A + (size_t)(sr0 + h * 32) * lda;
+#endif
+#if defined(LS_VAR_H2_SAMEA8)      // dev timing variant: the A tiles of 8 M-tiles only
+        arow[h] = A + (size_t)((tm & 7) * GM + sr0 + h * 32) * lda;
+#endif
     }
     auto kof = [&](int k0) { return KAL ? min(k0, kend - 32) + sk : min(k0 + sk, kend - 4); };
     auto gload_a = [&](int k0) {
@@ -512,7 +522,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             if (!KAL && k0 + sk >= kend) ra[h] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // WPL staging map: a row's slab is ONE 128-byte line [hi: 32 k | lo: 32 k]; thread -> 16-byte chunk tid & 7 of rows (tid >> 3) + 32 u
+    // (a wave load = eight whole lines, as with the fp32 rows; the first layout -- the two pieces K f16 apart, 64 useful bytes per
+    // line and load -- cost +50 %: the kernel is as much L1-fill-bound as anything else)
+    const int pr0 = tid >> 3, pc8 = tid & 7;
+    const char* prow[4];
+    int pswz[4];
+    float4 pb0, pb1, pb2, pb3;
+    if constexpr (WPL) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = pr0 + 32 * u;
+            prow[u] = static_cast<const char*>(aux.w_planes) + (size_t)min(n0 + r, N - 1) * ((size_t)K * 4) + pc8 * 16;
+            pswz[u] = (pc8 >> 2) * PLANE + r * 64 + (((pc8 & 3) ^ ((r >> 2) & 3)) << 4);
+        }
+    }
     auto gload_b = [&](int k0) {
+        if constexpr (WPL) {
+            const int kb = min(k0, kend - 32) * 4;     // slab k0 / 32 at byte (k0 / 32) * 128
+            pb0 = *reinterpret_cast<const float4*>(prow[0] + kb); pb1 = *reinterpret_cast<const float4*>(prow[1] + kb);
+            pb2 = *reinterpret_cast<const float4*>(prow[2] + kb); pb3 = *reinterpret_cast<const float4*>(prow[3] + kb);
+            return;
+        }
         const int ko = kof(k0);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -527,6 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int r = sr0 + h * 32;
         swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
     }
+    float sa[4] = {1.f, 1.f, 1.f, 1.f}, sw[4] = {1.f, 1.f, 1.f, 1.f};   // operand range: one exact power of two per staged row (GemmAux), set below
     auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {   // A rows
         uint2 ph, pl;
         split2_f16s<0>(v, sc, ph, pl);
@@ -539,8 +571,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         *reinterpret_cast<uint2*>(plane_hi + off) = ph;
         *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
     };
+    // the W half of a slab into LDS, in two parts (part 0 / 1 sit between the MFMA groups of the slab's second half)
+    auto stage_w = [&](char* Bp, int part) {
+        if constexpr (WPL) {   // (named registers: as an array these four went to scratch)
+            if (part == 0) { *reinterpret_cast<float4*>(Bp + pswz[0]) = pb0; *reinterpret_cast<float4*>(Bp + pswz[1]) = pb1; }
+            else { *reinterpret_cast<float4*>(Bp + pswz[2]) = pb2; *reinterpret_cast<float4*>(Bp + pswz[3]) = pb3; }
+        } else {
+            lstore2w(Bp, rb[2 * part], sw[2 * part], swz[2 * part]);
+            lstore2w(Bp, rb[2 * part + 1], sw[2 * part + 1], swz[2 * part + 1]);
+        }
+    };
     // operand range: one exact power of two per staged row (GemmAux), from the caller's row maxima or a pre-pass over the rows
-    float sa[4] = {1.f, 1.f, 1.f, 1.f}, sw[4] = {1.f, 1.f, 1.f, 1.f};
     if (aux.noscale) rsc[tid] = 1.f;
     else {
         float ma[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f};
@@ -562,7 +603,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         if (aux.w_rowmax) {
 #pragma unroll
             for (int h = 0; h < 4; ++h) mw[h] = aux.w_rowmax[(brow[h] - W) / ldw];
-        } else {
+        } else if constexpr (!WPL) {
             for (int k0 = kbeg; k0 < kend; k0 += 32) {
                 gload_b(k0);
 #pragma unroll
@@ -587,7 +628,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 
     gload_a(kbeg); gload_b(kbeg);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); lstore2w(smem + 2 * PLANE, rb[h], sw[h], swz[h]); }
+    for (int h = 0; h < 4; ++h) lstore2(smem, ra[h], sa[h], swz[h]);
+    stage_w(smem + 2 * PLANE, 0); stage_w(smem + 2 * PLANE, 1);
     gload_a(kbeg + 32); gload_b(kbeg + 32);
     __syncthreads();
 
@@ -605,6 +647,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc) {
+#if defined(LS_VAR_H2_NOLO_READ)   // dev timing variant: half of the LDS operand reads
+                    if (pc == 1) { a[i][1] = a[i][0]; b[i][1] = b[i][0]; continue; }
+#endif
                     a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
                     b[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + offb[i] + ((q ^ xb[i]) << 4)));
                 }
@@ -613,20 +658,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2w(Bn, rb[0], sw[0], swz[0]); lstore2w(Bn, rb[1], sw[1], swz[1]); }
+                for (int j = 0; j < 2; ++j) {
+#if defined(LS_VAR_H2_NOX_MFMA)   // dev timing variant: a third of the MFMAs, every LDS read kept alive
+                    asm volatile("" :: "v"(a[i][1]), "v"(b[j][1]));
+                    continue;
+#endif
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                }
+#if !defined(LS_VAR_H2_NOSTAGE)
+            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else stage_w(Bn, 0);
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#if defined(LS_VAR_H2_NOSTAGE)     // dev timing variant: no split, no LDS stores (the loads stay)
+            if (s2 == 0) { for (int h = 0; h < 4; ++h) asm volatile("" :: "v"(ra[h].x), "v"(ra[h].y), "v"(ra[h].z), "v"(ra[h].w)); gload_a(k0 + 64); }
+            else { for (int h = 0; h < 4; ++h) asm volatile("" :: "v"(rb[h].x), "v"(rb[h].y), "v"(rb[h].z), "v"(rb[h].w)); gload_b(k0 + 64); }
+#elif defined(LS_VAR_H2_NOGLOAD)   // dev timing variant: no global loads in the loop
+            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); }
+            else stage_w(Bn, 1);
+#else
             if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
-            else { lstore2w(Bn, rb[2], sw[2], swz[2]); lstore2w(Bn, rb[3], sw[3], swz[3]); gload_b(k0 + 64); }
+            else { stage_w(Bn, 1); gload_b(k0 + 64); }
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+#if defined(LS_VAR_H2_NOX_MFMA)
+                    continue;
+#endif
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                }
         }
+#if !defined(LS_VAR_H2_NOBARRIER)  // dev timing variant (racy)
         __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
+#endif
     }
 
     // epilogue: as gemm_f32_kernel (each wave transposes its 64x64 sub-tile through LDS in two 32-row halves)
@@ -648,7 +716,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int rl = 0; rl < 4; ++rl) {
                     const int r = r4 * 4 + rl;
-                    float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs) + bv;
+                    float v = acc[i][j][r] * (rsv[rl] * cs) + bv;
                     if (relu) v = fmaxf(v, 0.0f);
                     stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
                 }
@@ -658,6 +726,217 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         __builtin_amdgcn_wave_barrier();
         store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, mask,
                         gridDim.y == 1 ? aux.out_rowmax : nullptr, 2 * ntiles_n, 2 * tn + wn);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The wide form of gemm_h2_kernel for the long GEMMs of the decoder (M >= thousands of rows, N and K in the hundreds): 256 x 256
+// workgroup tiles, EIGHT waves as 2 (M) x 4 (N), a wave owns 128 x 64 = 4 x 2 MFMA tiles.  Why: at 128 x 128 the pipelined kernel is
+// bound by everything at once (measured at the decoder shape, scripts/diag/gemm_decoder_pmc.sh + the timing variants of
+// scripts/dev/build_variants.py): matrix pipe 45 % busy, VALU issue 56 % (two thirds of it the operand split, which every workgroup
+// redoes on data that 2 047 / 5 other workgroups also split), 32 KB of L1 fill and 96 KB of LDS traffic per 96 MFMAs.  A 256 x 256
+// tile halves the global bytes, the LDS writes and the split work per MFMA, the 4 x 2 wave tile takes a quarter off the LDS operand
+// reads.  The accumulators of a 4 x 2 wave tile fit only if the main and the cross terms share them: 128 VGPRs.
+template <bool MASKED, bool WPL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_w2_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc,
+    int M, int N, int K, int relu, int ntiles_n, const float* __restrict__ mask, GemmAux aux) {
+    constexpr int TM = 256, TN = 256;
+    constexpr int STG = 32 * 68;
+    constexpr int PLANE = TM * 64;         // one f16 plane: 256 rows x 32 k
+    constexpr int BUF = 4 * PLANE;         // A hi, A lo, W hi, W lo
+    static_assert(2 * BUF >= 8 * STG * 4, "epilogue staging aliases the operand buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * BUF + (TM + TN) * 4 bytes
+    float* rsc = reinterpret_cast<float*>(smem + 2 * BUF);        // inverse power-of-two scales: the tile's A rows, then its W rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = logical / ntiles_n, tn = logical % ntiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // staging map: 256 rows x 8 float4 (32 k) per operand slab over 512 threads: four per thread (rows sr0 + 64 h)
+    const int sr0 = tid >> 3, sk = (tid & 7) * 4;
+    float4 ra[4], rb[4];
+    const float* arow[4];
+    const float* brow[4];
+    float sa[4] = {1.f, 1.f, 1.f, 1.f}, sw[4] = {1.f, 1.f, 1.f, 1.f};
+    int swz[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = sr0 + h * 64;
+        swz[h] = r * 64 + (((sk >> 3) ^ ((r >> 2) & 3)) << 4) + ((sk >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        arow[h] = A + (size_t)min(m0 + sr0 + h * 64, M - 1) * lda + sk;
+        brow[h] = W + (size_t)min(n0 + sr0 + h * 64, N - 1) * ldw + sk;
+    }
+    auto gload_a = [&](int k0) {
+        const int ko = min(k0, K - 32);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ra[h] = *reinterpret_cast<const float4*>(arow[h] + ko);
+    };
+    // WPL (GemmAux::w_planes): a W row's slab is one 128-byte line [hi | lo]; thread -> chunk tid & 7 of rows (tid >> 3) + 64 u
+    const char* prow[4];
+    int pswz[4];
+    float4 pb0, pb1, pb2, pb3;
+    if constexpr (WPL) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = sr0 + 64 * u, c8 = tid & 7;
+            prow[u] = static_cast<const char*>(aux.w_planes) + (size_t)min(n0 + r, N - 1) * ((size_t)K * 4) + c8 * 16;
+            pswz[u] = (c8 >> 2) * PLANE + r * 64 + (((c8 & 3) ^ ((r >> 2) & 3)) << 4);
+        }
+    }
+    auto gload_b = [&](int k0) {
+        const int ko = min(k0, K - 32);
+        if constexpr (WPL) {
+            pb0 = *reinterpret_cast<const float4*>(prow[0] + ko * 4); pb1 = *reinterpret_cast<const float4*>(prow[1] + ko * 4);
+            pb2 = *reinterpret_cast<const float4*>(prow[2] + ko * 4); pb3 = *reinterpret_cast<const float4*>(prow[3] + ko * 4);
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) rb[h] = *reinterpret_cast<const float4*>(brow[h] + ko);
+    };
+    auto stage_w = [&](char* Bp, int h) {
+        if constexpr (WPL) *reinterpret_cast<float4*>(Bp + pswz[h]) = h == 0 ? pb0 : (h == 1 ? pb1 : (h == 2 ? pb2 : pb3));   // (named registers: as an array these went to scratch)
+        else { uint2 ph, pl; split2_f16s<1>(rb[h], sw[h], ph, pl); *reinterpret_cast<uint2*>(Bp + swz[h]) = ph; *reinterpret_cast<uint2*>(Bp + PLANE + swz[h]) = pl; }
+    };
+    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {
+        uint2 ph, pl;
+        split2_f16s<0>(v, sc, ph, pl);
+        *reinterpret_cast<uint2*>(plane_hi + off) = ph;
+        *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
+    };
+    if (aux.noscale) rsc[tid] = 1.f;
+    else {
+        float ma[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f};
+        if (aux.a_rowmax) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float* rp = aux.a_rowmax + (size_t)min(m0 + sr0 + h * 64, M - 1) * aux.a_parts;
+                for (int q = 0; q < aux.a_parts; ++q) ma[h] = fmaxf(ma[h], rp[q]);
+            }
+        } else {
+            for (int k0 = 0; k0 < K; k0 += 32) {
+                gload_a(k0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) ma[h] = amax4(ma[h], ra[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) ma[h] = max8(ma[h]);
+        }
+        if (aux.w_rowmax) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) mw[h] = aux.w_rowmax[min(n0 + sr0 + h * 64, N - 1)];
+        } else if constexpr (!WPL) {
+            for (int k0 = 0; k0 < K; k0 += 32) {
+                gload_b(k0);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) mw[h] = amax4(mw[h], rb[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) mw[h] = max8(mw[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float ia, iw;
+            pow2_scale(ma[h], sa[h], ia);
+            pow2_scale(mw[h], sw[h], iw);
+            if ((tid & 7) == 0) { rsc[sr0 + h * 64] = ia; rsc[TM + sr0 + h * 64] = iw; }
+        }
+    }
+    const int lr = lane & 31;
+    int offa[4], offb[2], xa[4], xb[2];   // byte offset of this lane's operand row inside a plane per 32-row MFMA tile, and its slot XOR
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + lr; offa[i] = r * 64; xa[i] = (r >> 2) & 3; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; offb[j] = r * 64; xb[j] = (r >> 2) & 3; }
+
+    gload_a(0); gload_b(0);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); stage_w(smem + 2 * PLANE, h); }
+    gload_a(32); gload_b(32);
+    __syncthreads();
+
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += 32, cur ^= 1) {
+        const char* Ac = smem + cur * BUF;
+        const char* Bc = Ac + 2 * PLANE;
+        char* An = smem + (cur ^ 1) * BUF;
+        char* Bn = An + 2 * PLANE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {   // the slab's two 16-k halves
+            const int q = s2 * 2 + (lane >> 5);
+            f16x8_t a[4][2], b[2][2];
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + offb[j] + ((q ^ xb[j]) << 4)));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
+            }
+            // per accumulator and 16-k step: lo(a) hi(w), hi(a) hi(w), hi(a) lo(w) -- the order every unified-accumulator kernel uses
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); }
+            else { stage_w(Bn, 0); stage_w(Bn, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
+            else { stage_w(Bn, 2); stage_w(Bn, 3); gload_b(k0 + 64); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
+    }
+
+    // epilogue: each wave transposes its 128 x 64 sub-tile through LDS in four 32-row pieces
+    float* stg = reinterpret_cast<float*>(smem) + wave * STG;
+    const int col_l = lane & 31, rowh = (lane >> 5) * 4;
+    const bool vec_ok = (ldc % 4 == 0) && (((uintptr_t)out & 15) == 0);
+    const bool full_tile = vec_ok && (m0 + TM <= M) && (n0 + TN <= N);
+    const int rm_parts = 2 * ((N + GN - 1) / GN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + wn * 64 + j * 32 + col_l;
+            const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
+            const float cs = rsc[TM + wn * 64 + j * 32 + col_l];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 128 + i * 32 + 8 * r4 + rowh]);
+                const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+                for (int rl = 0; rl < 4; ++rl) {
+                    const int r = r4 * 4 + rl;
+                    float v = acc[i][j][r] * (rsv[rl] * cs) + bv;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const int gn0 = n0 + wn * 64;
+        store_half_tile(stg, out, ldc, M, N, m0 + wm * 128 + i * 32, gn0, lane, full_tile, vec_ok, MASKED ? mask : nullptr,
+                        4 * tn + wn < rm_parts ? aux.out_rowmax : nullptr, rm_parts, 4 * tn + wn);   // (a part without valid columns receives 0)
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -689,13 +968,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int wm = wave >> 1, wn = wave & 1;
     const int kbeg = 0, kend = K;
 
-    f32x16 acc[2][2], acx[2][2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // staging map: 128 rows x 8 float4 (32 k) per operand slab, four per thread (rows sr0 + 32 h).  Rows past M / N are clamped
     // (computed, never stored) and so is k past the end (KAL: whole slabs, the data is never used; otherwise per float4, zeroed by
@@ -821,7 +1100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
             if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else { lstore2w(Bn, rb[0], sw[0], swz[0]); lstore2w(Bn, rb[1], sw[1], swz[1]); }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -832,7 +1111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
         }
         __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
     }
@@ -852,7 +1131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int rl = 0; rl < 4; ++rl) {
                     const int r = r4 * 4 + rl;
-                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs);
+                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = acc[i][j][r] * (rsv[rl] * cs);
                 }
             }
         }
@@ -1125,13 +1404,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         __syncthreads();
         load_tile(min(tm + per_n, ntiles_m - 1));      // next A tile in flight under the MFMAs and the stores (last iteration: re-reads its own)
 
-        f32x16 acc[2][2], acx[2][2];
+        f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
@@ -1148,7 +1427,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1156,7 +1435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
             }
         __syncthreads();                               // every wave is done with the A planes: they become the staging area
         float* stg = reinterpret_cast<float*>(Ap) + wave * STG;
@@ -1176,7 +1455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                     for (int rl = 0; rl < 4; ++rl) {
                         const int r = r4 * 4 + rl;
-                        float v = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs) + bv[j];
+                        float v = acc[i][j][r] * (rsv[rl] * cs) + bv[j];
                         if (relu) v = fmaxf(v, 0.0f);
                         stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
                     }
@@ -1301,13 +1580,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         __syncthreads();
         load_tile(min(tm + per_n, ntiles_m - 1));      // next A tile in flight under the MFMAs, the activation and the stores
 
-        f32x16 acc[2][2], acx[2][2];
+        f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; acx[i][j][r] = 0.0f; }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
@@ -1324,7 +1603,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acx[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1332,7 +1611,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acx[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
             }
         __syncthreads();                               // every wave is done with the A planes: they become the staging area
         float* stg = reinterpret_cast<float*>(Ap) + wave * STG;
@@ -1349,7 +1628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                     for (int rl = 0; rl < 4; ++rl) {
                         const int r = r4 * 4 + rl;
-                        stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = fmaf(acx[i][j][r], 0.0009765625f, acc[i][j][r]) * (rsv[rl] * cs);
+                        stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = acc[i][j][r] * (rsv[rl] * cs);
                     }
                 }
             }
@@ -1420,6 +1699,35 @@ int gemm_rowmax_launch(const float* W, int rows, int K, int ldw, float* out, hip
 }
 int gemm_rowmax_parts(int N) { return 2 * cdiv(N, GN); }   // parts per row of GemmAux::out_rowmax for an N-column output
 
+// GemmAux::w_planes of a weight matrix: row n = K / 32 lines of 128 bytes, line t = [hi piece of k = 32 t .. 32 t + 31 | lo piece of the
+// same k] of s_n W[n, :] -- the split every workgroup would otherwise redo on its W slab, done once (same split2_f16s, same scale:
+// bit-identical operands), laid out so that a staged slab row is one cache line
+__global__ __launch_bounds__(256) void gemm_presplit_w_kernel(const float* __restrict__ W, int rows, int K, int ldw, const float* __restrict__ rowmax,
+                                                              char* __restrict__ planes) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one float4 of W
+    const int k4 = K / 4;
+    if (i >= (long long)rows * k4) return;
+    const int r = (int)(i / k4), k = (int)(i % k4) * 4;
+    float sc, inv;
+    pow2_scale(rowmax[r], sc, inv);
+    uint2 ph, pl;
+    split2_f16s<1>(*reinterpret_cast<const float4*>(W + (size_t)r * ldw + k), sc, ph, pl);
+    char* line = planes + (size_t)r * ((size_t)K * 4) + (size_t)(k >> 5) * 128 + (k & 31) * 2;
+    *reinterpret_cast<uint2*>(line) = ph;
+    *reinterpret_cast<uint2*>(line + 64) = pl;
+}
+size_t gemm_w_planes_bytes(size_t rows, int K) { return rows * (size_t)K * 4; }
+// the kernels that read planes: gemm_h2_kernel<true, true>, gemm_w2_kernel<., true>.  Measured (scripts/diag/gemm_wide_probe.py): -5 % at
+// the decoder shape (992 -> 941 us wide, 1198 -> 1128 us narrow), neutral at K = 512, +8 .. 15 % on the K = 128 / 256 tables: K >= 512 only
+bool gemm_w_planes_useful(int K) { return K >= 512 && K % 32 == 0; }
+int gemm_presplit_w_launch(const float* W, int rows, int K, int ldw, const float* rowmax, void* planes, hipStream_t st) {
+    LS_REQUIRE(K % 8 == 0 && ((uintptr_t)planes % 16) == 0, "gemm_presplit_w: K must be a multiple of 8 and the planes 16-byte aligned (K=%d)", K);
+    hipLaunchKernelGGL(gemm_presplit_w_kernel, dim3(cdiv((long long)rows * (K / 4), 256)), dim3(256), 0, st, W, rows, K, ldw, rowmax,
+                       static_cast<char*>(planes));
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
 // Under-filled grids with a long K loop (the per-instance "mean" rows of the residual global conv: M = 3B rows against
 // K = C up to 512; conv_c) are pure latency: 32 workgroups x 16 dependent k-steps = 44 us for 0.2 GFLOP.  They are split
 // along K into slices written as partial slabs and combined by a second launch.
@@ -1469,7 +1777,9 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     // how an fp32 product is formed on the 16-bit matrix cores: 22 = two f16 pieces with a scaled residual (three MFMAs per 16 k, the
     // default), 3 = three bf16 pieces (six MFMAs, any fp32 range: LS_GEMM_MODE=bf16x3), 2 = two bf16 pieces (opt-in decode mode)
     static const bool h2_unpipelined = getenv("LS_GEMM_H2_SIMPLE") && atoi(getenv("LS_GEMM_H2_SIMPLE")) != 0;   // A/B: the two-barrier kernel
-#define LS_H2_KERNEL ((h2_unpipelined || K <= 64) ? gemm_f32_kernel<true, 22> : (K % 32 == 0 ? gemm_h2_kernel<true> : gemm_h2_kernel<false>))
+    static const bool planes_off = getenv("LS_GEMM_WPLANES") && atoi(getenv("LS_GEMM_WPLANES")) == 0;   // A/B: split W inside the kernel
+    const bool wpl = aux.w_planes && aux.w_rowmax && !aux.noscale && !planes_off && K % 32 == 0 && K > 64 && !h2_unpipelined;
+#define LS_H2_KERNEL ((h2_unpipelined || K <= 64) ? gemm_f32_kernel<true, 22> : (K % 32 == 0 ? (wpl ? gemm_h2_kernel<true, true> : gemm_h2_kernel<true, false>) : gemm_h2_kernel<false, false>))
     static const int default_pieces = (getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) ? 3 : 22;
     if (pieces == 3) pieces = default_pieces;
     const int nsplit = (scratch && !mask) ? gemm_choose_splits(M, N, K) : 1;   // (a split launch writes no out_rowmax: callers check gemm_scratch_floats)
@@ -1494,6 +1804,12 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         return LS_OK;
     }
     static const bool persist = !(getenv("LS_GEMM_PERSIST") && atoi(getenv("LS_GEMM_PERSIST")) == 0);   // A/B: K = 32 / 64 on the tiled kernel
+    // 256 x 256 tiles once they fill the chip (LS_GEMM_WIDE=0 / 1: never / always -- same arithmetic, bit-identical results)
+    static const int wide_mode = getenv("LS_GEMM_WIDE") ? atoi(getenv("LS_GEMM_WIDE")) : -1;
+    // measured (scripts/diag/gemm_wide_probe.py): the wide kernel wins when its grid fills whole rounds of the 256 CUs (one workgroup per
+    // CU): 480 tiles 88 -> 73 us, 768 tiles 355 -> 280 us, 3072 tiles 1186 -> 1002 us; ties at 384 tiles, loses below one round
+    const long long wtiles = (long long)cdiv(M, 256) * cdiv(N, 256);
+    const bool wide_on = wide_mode >= 0 ? wide_mode != 0 : (wtiles >= 1024 || (wtiles >= 256 && wtiles * 100 >= 85 * 256 * cdiv(wtiles, 256)));
     if (split && pieces == 22 && persist && !mask && (K == 32 || K == 64) && tm >= 16 && !h2_unpipelined && !aux.out_rowmax) {
         int per_n = cdiv(512, tn);   // two resident workgroups per CU (registers), spread evenly over the N-tiles
         if (per_n > tm) per_n = tm;
@@ -1501,6 +1817,21 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         if (K == 32) { if (a_rows) LS_H2SK(32, true); else LS_H2SK(32, false); }
         else { if (a_rows) LS_H2SK(64, true); else LS_H2SK(64, false); }
 #undef LS_H2SK
+    } else if (split && pieces == 22 && wide_on && !a_rows && K % 32 == 0 && K >= 128) {
+        const int wtm = cdiv(M, 256), wtn = cdiv(N, 256);
+        const size_t lds = 2 * 4 * 256 * 64 + 512 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+#define LS_W2(MK, PL) hipLaunchKernelGGL((gemm_w2_kernel<MK, PL>), dim3(wtm * wtn), dim3(512), lds, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, wtn, mask, aux)
+        if (mask) { if (wpl) LS_W2(true, true); else LS_W2(true, false); }
+        else { if (wpl) LS_W2(false, true); else LS_W2(false, false); }
+#undef LS_W2
     } else if (split && pieces == 22)
         hipLaunchKernelGGL(LS_H2_KERNEL, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
                            gNd, gNs, K, (size_t)0, mask, aux);

@@ -113,6 +113,7 @@ struct GemmAux {
     const float* a_rowmax = nullptr;   // [rows of A][a_parts]: max over the parts bounds max|A[row, :]|; indexed by the SOURCE row when a_rows gathers
     int a_parts = 0;
     const float* w_rowmax = nullptr;   // [N]
+    const void* w_planes = nullptr;    // pre-split W (gemm_presplit_w_launch): row n = K / 32 lines [hi: 32 f16 | lo: 32 f16] of s_n W[n, :], s_n from w_rowmax (required)
     float* out_rowmax = nullptr;       // [M][2 * cdiv(N, 128)]: max|out[row, 64-column block]| written by the epilogue (un-split launches only)
     int noscale = 0;                   // LS_GEMM_RANGE=0: the round-2 arithmetic (no row scaling; |a| < 65504 required), A/B timing
 };

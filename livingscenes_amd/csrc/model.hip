@@ -29,6 +29,9 @@ size_t fps_scratch_bytes_per_cloud(int N);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t, GemmAux aux = GemmAux());
 int gemm_rowmax_launch(const float* W, int rows, int K, int ldw, float* out, hipStream_t st);
 int gemm_rowmax_parts(int N);
+size_t gemm_w_planes_bytes(size_t rows, int K);
+bool gemm_w_planes_useful(int K);
+int gemm_presplit_w_launch(const float* W, int rows, int K, int ldw, const float* rowmax, void* planes, hipStream_t st);
 int sdf_affine_rowmax_parts(int out_dim);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
 int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
@@ -91,10 +94,12 @@ struct ls_model {
     float* dec_wt = nullptr;            // transposed decoder weights [kin_l][out_l], built by the first backward call
     size_t dec_wt_off[12] = {};
     // max|row| of every weight matrix a GEMM reads (gemm.hip, GemmAux::w_rowmax): saves the kernels their pre-pass over W
-    struct WMax { const float* base; size_t rows; int K; const float* wmax; };
+    struct WMax { const float* base; size_t rows; int K; const float* wmax; const char* planes; };   // planes: pre-split rows (GemmAux::w_planes) or null
     std::vector<WMax> wreg;
     float* wmax_pool = nullptr;         // blob matrices (ls_model_create)
     float* wmax_pool_t = nullptr;       // transposed decoder weights (first backward call)
+    char* wplanes_pool = nullptr;       // pre-split f16 pieces of the K >= 128 matrices of the blob
+    char* wplanes_pool_t = nullptr;     // ... of the transposed decoder weights
     hipStream_t side = nullptr;    // FPS chain
     hipStream_t side2 = nullptr;   // per-layer table GEMMs, concurrent with the k-NN of the same layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -251,30 +256,44 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
 static int dec_out(const ls_model_desc& d, int l);
 // ------------------------------------------------------------------------------------------------ weight row maxima
 // rows [W, W + N*K) of a registered matrix with the same K -> their maxima; nullptr = not registered (the GEMM then scans W itself)
-static const float* wmax_for(const ls_model* m, const float* W, int N, int K) {
+static const float* wmax_for(const ls_model* m, const float* W, int N, int K, const void** planes = nullptr) {
     for (const auto& e : m->wreg) {
         if (e.K != K || W < e.base) continue;
         const size_t off = (size_t)(W - e.base);
-        if (off % K == 0 && off / K + (size_t)N <= e.rows) return e.wmax + off / K;
+        if (off % K == 0 && off / K + (size_t)N <= e.rows) {
+            if (planes) *planes = e.planes ? e.planes + gemm_w_planes_bytes(off / K, K) : nullptr;
+            return e.wmax + off / K;
+        }
     }
     return nullptr;
 }
 static GemmAux aux_w(const ls_model* m, const float* W, int N, int K) {
     GemmAux a;
-    a.w_rowmax = wmax_for(m, W, N, K);
+    a.w_rowmax = wmax_for(m, W, N, K, &a.w_planes);
     return a;
 }
 struct WSpec { const float* base; size_t rows; int K; };
-static int wmax_register(ls_model* m, const std::vector<WSpec>& specs, float** pool, hipStream_t st) {
-    size_t total = 0;
-    for (const auto& sp : specs) total += sp.rows;
+static int wmax_register(ls_model* m, const std::vector<WSpec>& specs, float** pool, char** planes_pool, hipStream_t st) {
+    size_t total = 0, pbytes = 0;
+    for (const auto& sp : specs) {
+        total += sp.rows;
+        if (gemm_w_planes_useful(sp.K)) pbytes += gemm_w_planes_bytes(sp.rows, sp.K);
+    }
     if (!total) return LS_OK;
     LS_HIP_CHECK(hipMalloc((void**)pool, total * sizeof(float)));
-    size_t off = 0;
+    if (pbytes) LS_HIP_CHECK(hipMalloc((void**)planes_pool, pbytes));
+    size_t off = 0, poff = 0;
     for (const auto& sp : specs) {
-        const int rc = gemm_rowmax_launch(sp.base, (int)sp.rows, sp.K, sp.K, *pool + off, st);
+        int rc = gemm_rowmax_launch(sp.base, (int)sp.rows, sp.K, sp.K, *pool + off, st);
         if (rc != LS_OK) return rc;
-        m->wreg.push_back({sp.base, sp.rows, sp.K, *pool + off});
+        const char* planes = nullptr;
+        if (gemm_w_planes_useful(sp.K)) {
+            planes = *planes_pool + poff;
+            rc = gemm_presplit_w_launch(sp.base, (int)sp.rows, sp.K, sp.K, *pool + off, *planes_pool + poff, st);
+            if (rc != LS_OK) return rc;
+            poff += gemm_w_planes_bytes(sp.rows, sp.K);
+        }
+        m->wreg.push_back({sp.base, sp.rows, sp.K, *pool + off, planes});
         off += sp.rows;
     }
     return LS_OK;
@@ -329,6 +348,7 @@ static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_
         int rc = gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs, ax);
         GemmAux aq = ax;
         if (aq.w_rowmax) aq.w_rowmax += pc;
+        if (aq.w_planes) aq.w_planes = static_cast<const char*>(aq.w_planes) + gemm_w_planes_bytes((size_t)pc, Cin);   // rows pc.. of the same matrix
         if (rc == LS_OK) rc = gemm_dispatch_gather(cur, Cin, W + (size_t)pc * Cin, Cin, nullptr, const_cast<float*>(et.Tq), qc, B * Nd * 3, qc, Cin, 0, dst_rows, Nd, Ns, gs, aq);
         return rc;
     }
@@ -489,6 +509,22 @@ int ls_rowmax_f32(const float* X, int rows, int K, int ld, float* out, void* str
     LS_REQUIRE(X && out && rows > 0 && K > 0 && ld >= K, "rowmax: bad argument");
     return gemm_rowmax_launch(X, rows, K, ld, out, (hipStream_t)stream);
 }
+size_t ls_gemm_w_planes_bytes(int N, int K) { return (N > 0 && K > 0 && gemm_w_planes_useful(K)) ? gemm_w_planes_bytes((size_t)N, K) : 0; }
+int ls_gemm_presplit_w_f32(const float* W, int ldw, int N, int K, const float* w_rowmax, void* planes, size_t planes_bytes, void* stream) {
+    LS_REQUIRE(W && w_rowmax && planes && N > 0 && K > 0 && ldw >= K && ldw % 4 == 0, "gemm_presplit_w: bad argument");
+    LS_REQUIRE(gemm_w_planes_useful(K), "gemm_presplit_w: no kernel reads planes at K = %d (ls_gemm_w_planes_bytes returns 0)", K);
+    if (planes_bytes < gemm_w_planes_bytes((size_t)N, K)) { set_error("gemm_presplit_w: planes %zu < required %zu (ls_gemm_w_planes_bytes)", planes_bytes, gemm_w_planes_bytes((size_t)N, K)); return LS_ERR_WORKSPACE; }
+    return gemm_presplit_w_launch(W, N, K, ldw, w_rowmax, planes, (hipStream_t)stream);
+}
+int ls_gemm_f32_planes(const float* A, int lda, const float* W, int ldw, const void* w_planes, const float* bias, float* out, int ldc, int M, int N,
+                       int K, int relu, const float* a_rowmax, int a_parts, const float* w_rowmax, float* out_rowmax, void* stream) {
+    LS_REQUIRE(w_planes && w_rowmax, "gemm_planes: w_planes and w_rowmax are required (ls_gemm_presplit_w_f32)");
+    LS_REQUIRE(!a_rowmax || a_parts >= 1, "gemm_planes: a_rowmax needs a_parts >= 1");
+    LS_REQUIRE(gemm_w_planes_useful(K), "gemm_planes: no kernel reads planes at K = %d", K);
+    GemmAux ax;
+    ax.a_rowmax = a_rowmax; ax.a_parts = a_rowmax ? a_parts : 0; ax.w_rowmax = w_rowmax; ax.out_rowmax = out_rowmax; ax.w_planes = w_planes;
+    return gemm_dispatch(A, lda, W, ldw, bias, out, ldc, M, N, K, relu, (hipStream_t)stream, ax);
+}
 int ls_encode_prologue_f32(const float* x, int B, int N, float* pts_out, float* centroid_out, float* scale0_out, void* stream) {
     LS_REQUIRE(B > 0, "prologue: empty batch");
     return prologue_launch(x, B, N, pts_out, centroid_out, scale0_out, nullptr, (hipStream_t)stream);
@@ -590,7 +626,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
             }
             specs.push_back({m->blob + d.off_dec_w[d.dec_num_linear - 1], 1, kin});
         }
-        const int rc = wmax_register(m, specs, &m->wmax_pool, nullptr);
+        const int rc = wmax_register(m, specs, &m->wmax_pool, &m->wplanes_pool, nullptr);
         if (rc != LS_OK || hipDeviceSynchronize() != hipSuccess) { ls_model_destroy(m); return LS_ERR_HIP; }
     }
     *out = m;
@@ -603,6 +639,8 @@ void ls_model_destroy(ls_model_t* m) {
     if (m->dec_wt) (void)hipFree(m->dec_wt);
     if (m->wmax_pool) (void)hipFree(m->wmax_pool);
     if (m->wmax_pool_t) (void)hipFree(m->wmax_pool_t);
+    if (m->wplanes_pool) (void)hipFree(m->wplanes_pool);
+    if (m->wplanes_pool_t) (void)hipFree(m->wplanes_pool_t);
     for (int i = 0; i < LS_MAX_LAYERS; ++i)
         if (m->wq_planes[i]) (void)hipFree(m->wq_planes[i]);
     if (m->side) (void)hipStreamDestroy(m->side);
@@ -1168,7 +1206,7 @@ static int build_dec_wt(ls_model_t* m, hipStream_t st) {   // transposed main we
     std::vector<WSpec> specs;
     kin = w;
     for (int l = 1; l < nl - 1; ++l) { const int outw = dec_out(d, l); specs.push_back({m->dec_wt + m->dec_wt_off[l], (size_t)kin, outw}); kin = outw; }
-    return wmax_register(m, specs, &m->wmax_pool_t, st);
+    return wmax_register(m, specs, &m->wmax_pool_t, &m->wplanes_pool_t, st);
 }
 
 // Gradients of sum(grad_sdf * sdf) w.r.t. the code and the query points, after ls_sdf_decode_train on the SAME arguments and

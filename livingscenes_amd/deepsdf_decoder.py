@@ -71,11 +71,14 @@ class DeepSDF_Decoder(nn.Module):
         fold = self._folded()
         if getattr(self, "_wmax", None) is None or self._wmax[0].device != x0.device:
             self._wmax = [ops.rowmax(W.to(x0.device)) for W, _ in fold]        # operand range of the weights, once (ls_gemm_f32_ex)
+            # ... and their f16 pieces, once (ls_gemm_presplit_w_f32; None where no kernel reads planes)
+            self._wplanes = [ops.presplit_w(W.to(x0.device), wm) for (W, _), wm in zip(fold, self._wmax)]
         rm = None                                       # row maxima of x, chained from GEMM to GEMM (None: the kernel scans x itself)
         for layer, (W, b) in enumerate(fold):
             if layer in self.latent_in:
                 x, rm = torch.cat([x, x0], 1), None
             if x.shape[1] != W.shape[1]:
                 x, rm = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1])), rm
-            x, rm = ops.gemm_chain(x.contiguous(), W, b, relu=layer < last, a_rowmax=rm, w_rowmax=self._wmax[layer], want_rowmax=layer < last)
+            x, rm = ops.gemm_chain(x.contiguous(), W, b, relu=layer < last, a_rowmax=rm, w_rowmax=self._wmax[layer], want_rowmax=layer < last,
+                                   w_planes=self._wplanes[layer])
         return torch.tanh(x).view(B, N)

@@ -72,10 +72,24 @@ def rowmax(X):
     return out
 
 
-def gemm_chain(A, W, bias=None, relu=False, a_rowmax=None, w_rowmax=None, want_rowmax=True):
+def presplit_w(W, w_rowmax):
+    """ls_gemm_presplit_w_f32: both f16 pieces of the range-scaled rows of a weight matrix, for ``gemm_chain(..., w_planes=)``.  None when
+    no kernel reads planes at this K (K < 512 or K % 32 != 0)."""
+    W = _f32(W)
+    N, K = W.shape
+    nb = load().ls_gemm_w_planes_bytes(N, K)
+    if nb == 0:
+        return None
+    planes = torch.empty(nb, dtype=torch.uint8, device=W.device)
+    call(W.device, "ls_gemm_presplit_w_f32", ptr(W), K, N, K, ptr(w_rowmax), ptr(planes), nb, stream_ptr(W.device))
+    return planes
+
+
+def gemm_chain(A, W, bias=None, relu=False, a_rowmax=None, w_rowmax=None, want_rowmax=True, w_planes=None):
     """ls_gemm_f32_ex: the GEMM of ``gemm`` for a chain of layers -- takes the row maxima of its operands (``a_rowmax`` [M, parts] from
     the previous call, ``w_rowmax`` [N] from ``rowmax(W)``) and returns (out, out_rowmax [M, parts']) for the next one.  Never splits
-    K (a row's result does not depend on the other rows of the call)."""
+    K (a row's result does not depend on the other rows of the call).  ``w_planes`` (``presplit_w(W, w_rowmax)``): ls_gemm_f32_planes,
+    the same result without re-splitting W in every workgroup."""
     A, W = _f32(A), _f32(W)
     M, K = A.shape
     N = W.shape[0]
@@ -83,6 +97,10 @@ def gemm_chain(A, W, bias=None, relu=False, a_rowmax=None, w_rowmax=None, want_r
     parts = load().ls_gemm_rowmax_parts(N)
     orm = torch.empty(M, parts, dtype=torch.float32, device=A.device) if want_rowmax else None
     a_parts = 0 if a_rowmax is None else (1 if a_rowmax.dim() == 1 else a_rowmax.shape[1])
+    if w_planes is not None:
+        call(A.device, "ls_gemm_f32_planes", ptr(A), K, ptr(W), K, ptr(w_planes), ptr(bias), ptr(out), N, M, N, K, int(relu), ptr(a_rowmax),
+             a_parts, ptr(w_rowmax), ptr(orm), stream_ptr(A.device))
+        return out, orm
     call(A.device, "ls_gemm_f32_ex", ptr(A), K, ptr(W), K, ptr(bias), ptr(out), N, M, N, K, int(relu), ptr(a_rowmax), a_parts, ptr(w_rowmax),
          ptr(orm), None, 0, stream_ptr(A.device))
     return out, orm

@@ -36,9 +36,15 @@ for name, M, N, K in shapes:
     am, wm = ops.rowmax(A), ops.rowmax(W)
     forms = [lambda: ops.gemm(A, W), lambda: ops.gemm_chain(A, W, a_rowmax=am, w_rowmax=wm, want_rowmax=False),
              lambda: ops.gemm_chain(A, W, a_rowmax=am, w_rowmax=wm, want_rowmax=True)]
+    planes = ops.presplit_w(W, wm)     # the weight's f16 pieces, split once (K >= 128)
+    if planes is not None:
+        forms.append(lambda: ops.gemm_chain(A, W, a_rowmax=am, w_rowmax=wm, want_rowmax=True, w_planes=planes))
+        assert torch.equal(forms[2]()[0], forms[3]()[0]), "planes path differs"
     if ops.load().ls_gemm_workspace_bytes(M, N, K):   # split-K shape: the chained forms never split
         forms = forms[:1]
     ms = [min(timed(f), timed(f)) for f in forms]
     wr = M * N * 4 / ms[0] / 1e9; fl = 2.0 * M * N * K / ms[0] / 1e9
     extra = "" if len(ms) == 1 else f"   maxima given {ms[1]*1e3:8.1f} us   + emitted {ms[2]*1e3:8.1f} us"
+    if len(ms) == 4:
+        extra += f"   + W pre-split {ms[3]*1e3:8.1f} us"
     print(f"{name:12s} M={M:7d} N={N:5d} K={K:4d}: {ms[0]*1e3:8.1f} us   write {wr:6.2f} TB/s   {fl:6.1f} TFLOP/s{extra}")

@@ -44,6 +44,36 @@ def _hip(cfg, w, dcfg=None, dw=None):
     return ops.HipModel(desc, blob, _dev())
 
 
+# ------------------------------------------------------------------------------------------------ pre-split weights
+@pytest.mark.parametrize("M,N,K", [(640, 768, 768), (1000, 200, 512), (77, 257, 1024), (3000, 384, 512), (130, 130, 544), (70000, 520, 512)])
+def test_gemm_with_presplit_weight_planes_is_bit_identical(M, N, K):
+    """ls_gemm_f32_planes (W split once by ls_gemm_presplit_w_f32) == ls_gemm_f32_ex (W split inside every workgroup) BIT FOR BIT: same
+    split function, same scales; rows of W spread over 60 binades, ragged tiles, bias + ReLU, row maxima emitted."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(_dev())
+    W = (torch.randn(N, K, generator=g) * torch.exp2(torch.randint(-30, 30, (N, 1), generator=g).float())).to(_dev())
+    b = torch.randn(N, generator=g).to(_dev())
+    am, wm = ops.rowmax(A), ops.rowmax(W)
+    planes = ops.presplit_w(W, wm)
+    assert planes is not None and planes.numel() == 4 * N * K
+    for relu in (False, True):
+        o0, r0 = ops.gemm_chain(A, W, b, relu=relu, a_rowmax=am, w_rowmax=wm)
+        o1, r1 = ops.gemm_chain(A, W, b, relu=relu, a_rowmax=am, w_rowmax=wm, w_planes=planes)
+        assert torch.equal(o0, o1) and torch.equal(r0, r1)
+    ref = A.double() @ W.double().T + b.double()
+    bound = (A.double().abs() @ W.double().abs().T + b.double().abs()) * 2.0 ** -24 * (K / 2 + 8)
+    out = ops.gemm_chain(A, W, b, a_rowmax=am, w_rowmax=wm, w_planes=planes)[0]
+    assert bool(((out.double() - ref).abs() <= bound).all())
+
+
+def test_presplit_planes_are_refused_where_no_kernel_reads_them():
+    from livingscenes_amd import ops
+    W = torch.randn(64, 64, device=_dev())
+    assert ops.presplit_w(W, ops.rowmax(W)) is None            # K < 512: ls_gemm_w_planes_bytes == 0
+    assert ops.load().ls_gemm_w_planes_bytes(64, 520) == 0     # K % 32 != 0
+
+
 # ------------------------------------------------------------------------------------------------ GEMM level
 # shapes chosen to reach every f16-split kernel of gemm.hip: the persistent K = 32 / 64 kernels (M >= 2048), the two-barrier tiled
 # kernel (K <= 64, few tiles), the pipelined kernel (K >= 128; 136 = ragged last slab), split-K (few tiles, long K, workspace)
