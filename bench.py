@@ -78,7 +78,7 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     elif os.environ.get("LS_GEMM_MODE") == "bf16x3":
         mm_peak, mm_what, mm_mult = BF16_PEAK_TFLOPS, "bf16 MFMA flops as executed (fp32 products = 6 bf16 MFMAs)", 6.0
     else:
-        mm_peak, mm_what, mm_mult = BF16_PEAK_TFLOPS, "f16 MFMA flops as executed (an fp32 product = 3 f16 MFMAs: two-piece split with a scaled residual)", 3.0
+        mm_peak, mm_what, mm_mult = BF16_PEAK_TFLOPS, "f16 MFMA flops as executed (an fp32 product = 3 f16 MFMAs: two-piece split)", 3.0
     nc = (10 if L["attn"] else 4) * Co
     pc = (4 if L["attn"] else 2) * Co
     down = Nd != Ns   # neighbour-side columns on the Ns source points, destination-side columns on the Nd selected points
@@ -430,7 +430,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" + ((" (GEMM products as three-piece bf16 splits on the bf16 matrix cores, fp32 accumulate: as accurate as an fp32 FMA chain)"
                               if os.environ.get("LS_GEMM_MODE") == "bf16x3" else
-                              " (GEMM products as two-piece f16 splits with a scaled residual on the f16 matrix cores, fp32 accumulate: as accurate against fp64 as an fp32 FMA chain)")
+                              " (GEMM products as two-piece f16 splits on the f16 matrix cores, fp32 accumulate: as accurate against fp64 as an fp32 FMA chain)")
                              if bf16x3 else ""),
             "data": "synthetic (seeded chair-like clouds; deterministic random-init weights of the released architecture)",
             "config": {"workload": f"BASELINE configs[1]+[2]: batch={B} instances x N={N} pts per GPU = {n_obj}-object scene + rescan; "

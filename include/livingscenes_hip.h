@@ -99,18 +99,19 @@ int ls_fps_f32(const float* pts, const int32_t* lengths, int B, int N, int K, un
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) -- the VecLinear channel contraction
  * (vec_layers.py:121-136, F.linear at :134) on x-major rows, and the DeepSDF linears
  * (lib_shape_prior/core/lib/implicit_func/deepsdf_decoder.py:98-121).  fp32 in, fp32 out; the products run on the f16
- * matrix cores as TWO-PIECE splits with a scaled residual (a = h + l/1024, h = f16(a), l = f16((a - h) * 1024): 2^-22 |a|; three
- * v_mfma_f32_32x32x16_f16 per 16 k, main and cross terms in separate fp32 accumulators): measured against fp64 this is as accurate
- * as an fp32 FMA chain (the fp32 accumulation error dominates both) and exact on integer-valued operands below 2^22.
+ * matrix cores as TWO-PIECE splits (a = h + l, h = f16(a), l = f16(a - h): 2^-22 |a|; three v_mfma_f32_32x32x16_f16 per 16 k into
+ * one fp32 accumulator): measured against fp64 this is as accurate as an fp32 FMA chain (the fp32 accumulation error dominates
+ * both) and exact on integer-valued operands below 2^22.
  * RANGE: any finite fp32 operands.  Every row of A and every row of W is multiplied by its own exact power of two before the split
  * (row maximum -> [2^14, 2^15)) and the accumulators by the inverse afterwards, so the f16 window follows each row: elements down to
- * 2^-27 of their row's maximum keep the full 22 bits, the absolute floor is 2^-49 of the row maximum, nothing overflows; rows that hold
+ * 2^-17 of their row's maximum keep the full 22 bits, smaller ones an absolute error of at most 2^-39 of the row maximum (2^-15 of
+ * the fp32 rounding of the row's largest term), nothing overflows; rows that hold
  * Inf / NaN give non-finite results in that row only.  A row's result depends on that row of A and on W only -- not on the other rows of
  * the call -- as long as the launch does not split K (split-K: M * N < 192 tiles of 128 x 128 and K >= 128 and a workspace is given;
  * it changes the fp32 summation order with M; ls_gemm_f32_ex with workspace = NULL never splits).
  * LS_GEMM_MODE=bf16x3 in the environment selects three-piece bf16 splits instead (six v_mfma_f32_32x32x16_bf16 per 16 k, ~1.5x the
- * time); LS_GEMM_BF16X3=0 the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains); LS_GEMM_RANGE=0 the un-scaled
- * round-2 split (A/B timing only: |a|, |w| < 65 504 required, small operands lose bits).
+ * time); LS_GEMM_BF16X3=0 the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains); LS_GEMM_RANGE=0 the split
+ * without the row scaling (A/B TIMING only: |a|, |w| < 65 504 required, operands below ~0.1 lose bits).
  * K % 4 == 0, lda/ldw/ldc % 4 == 0; bias may be NULL; relu in {0,1}.  workspace: ls_gemm_workspace_bytes(M, N, K) bytes
  * (split-K slabs of under-filled long-K problems; 0 -> may be NULL). */
 size_t ls_gemm_workspace_bytes(int M, int N, int K);
@@ -119,7 +120,7 @@ int ls_gemm_f32(const float* A, int lda, const float* W, int ldw, const float* b
 /* The same GEMM for callers that chain several of them (an MLP): the row maxima the range scaling needs can be handed over instead
  * of being re-derived by a pre-pass over the operands (which costs ~30 % at K >= 128):
  *   a_rowmax [M][a_parts] or NULL: max over the parts >= max|A[row, :]| (any upper bound serves; a factor of two of slack costs one
- *                                  bit at the bottom of the 27-binade window);   w_rowmax [N] or NULL: likewise for W (ls_rowmax_f32 once
+ *                                  bit at the bottom of the 17-binade window);   w_rowmax [N] or NULL: likewise for W (ls_rowmax_f32 once
  *                                  per weight matrix);
  *   out_rowmax [M][ls_gemm_rowmax_parts(N)] or NULL: receives max|out[row, 64-column block]| -- the next layer's a_rowmax.  Not
  *                                  written by a launch that splits K: pass workspace = NULL when chaining.

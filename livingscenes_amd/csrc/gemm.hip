@@ -3,8 +3,9 @@
 // Kernels in this file (all 128 x 128 workgroup tiles, four waves as 2 x 2, 32 x 32 MFMA tiles):
 //   gemm_f32_kernel<false>          v_mfma_f32_32x32x2_f32, exact fp32 FMA chains (LS_GEMM_BF16X3=0, and the caller-designated latency GEMMs)
 //   gemm_f32_kernel<true, 3 | 2>    fp32 products as three (two) bf16 pieces, six (three) v_mfma_f32_32x32x16_bf16 per 16 k (LS_GEMM_MODE=bf16x3)
-//   gemm_f32_kernel<true, 22>       fp32 products as two f16 pieces with a scaled residual, three v_mfma_f32_32x32x16_f16: the DEFAULT arithmetic
+//   gemm_f32_kernel<true, 22>       fp32 products as two f16 pieces (h + residual), three v_mfma_f32_32x32x16_f16 into one accumulator: the DEFAULT arithmetic
 //   gemm_h2_kernel                  the same arithmetic as a double-buffered software pipeline (K >= 128)
+//   gemm_w2_kernel                  the same again on 256 x 256 tiles, eight waves of 4 x 2 MFMA tiles (chip-filling K >= 128 problems: the decoder)
 //   gemm_h2_smallk_kernel           the same arithmetic, persistent over the M-tiles of an N-tile (K = 32 / 64 table GEMMs)
 //   gemm_vn_kernel                  gemm_h2_kernel with the VN activation of the residual global conv as its epilogue
 //   gemm_smallk_kernel              fp32-MFMA persistent small-K kernel (fp32 mode only)
@@ -54,17 +55,17 @@ __device__ __forceinline__ void split3_bf16(const float4& v, uint2& p1, uint2& p
 }
 
 
-// ---- fp32 GEMM on the f16 matrix cores ("2 x f16 split, scaled residual", PIECES = 22).  a = h + l / 1024 with h = f16(a) (11
-// significant bits) and l = f16((a - h) * 1024) (the residual is exact in fp32; scaled, it keeps 11 more bits and stays clear of
-// the f16 subnormal range for |a| >= 2^-13): |a - (h + l/1024)| <= 2^-22 |a|.  The matrix core takes f16 subnormals as they are
-// (scripts/ubench/f16_denorm.hip), so small |a| degrade gracefully: the absolute error never exceeds 2^-35.
-// a b = h_a h_b + (h_a l_b + l_a h_b) / 1024 + O(2^-21 |a b|): THREE v_mfma_f32_32x32x16_f16 per 16 k, the main term and the two
-// cross terms in separate fp32 accumulators that meet in the epilogue.  Against fp64 the result is as close as with the
-// three-piece bf16 split (scripts/gemm_microbench.py --check: 6.5 - 7.3 vs 5.9 - 8.4 units of 2^-24 sum|a||w| at K = 32 .. 768 --
-// both are the fp32 accumulation error any fp32 GEMM carries; the split error itself is 8e-8 of the largest output) at half the
-// matrix-pipe time and three VALU instructions per split value (v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add, v_pk_mul,
-// v_cvt_pk_f16_f32 per PAIR) instead of 5.5.  The f16 range (|a| < 65 504, 22 bits only above 2^-13) is made to follow every operand ROW
-// by an exact power-of-two scale: "operand range of the f16 split" below.  LS_GEMM_MODE=bf16x3 keeps the six-MFMA split.
+// ---- fp32 GEMM on the f16 matrix cores ("2 x f16 split", PIECES = 22).  a = h + l with h = f16(a) (11 significant bits) and
+// l = f16(a - h) (the residual is exact in fp32 and keeps 11 more bits while it is a normal f16): |a - (h + l)| <= 2^-22 |a|.  The
+// matrix core takes f16 subnormals as they are (scripts/ubench/f16_denorm.hip), so a residual below 2^-14 degrades gracefully: its
+// absolute error never exceeds 2^-25.  a b = h_a h_b + h_a l_b + l_a h_b + O(2^-21 |a b|): THREE v_mfma_f32_32x32x16_f16 per 16 k,
+// accumulated -- in the order l_a h_b, h_a h_b, h_a l_b, in every kernel of this file and in the fused attention kernel, which is what
+// keeps their results bit-identical to each other -- into ONE fp32 accumulator.  (Rounds 1-2 scaled the residual by 1024 and kept the
+// cross terms in a second accumulator set: 64 more VGPRs per wave, which capped the wave tile at 2 x 2 MFMA tiles.)  Against fp64 the
+// result is as close as an fp32 FMA chain's (scripts/gemm_microbench.py --check on badly scaled operands: 6.6 - 9.6 units of
+// 2^-24 sum|a||w| at K = 32 .. 768; an fp32 FMA chain: 8 - 13 -- the fp32 accumulation error any fp32 GEMM carries) at half the
+// matrix-pipe time of the three-piece bf16 split and three VALU instructions per split value.  The f16 range is made to follow every
+// operand ROW by an exact power-of-two scale: "operand range of the f16 split" below.  LS_GEMM_MODE=bf16x3 keeps the six-MFMA split.
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split2_f16_pair(f32x2_t v, unsigned& h, unsigned& l) {
@@ -80,13 +81,14 @@ __device__ __forceinline__ void split2_f16(const float4& v, uint2& h, uint2& l) 
 // ---- operand range of the f16 split.  f16 covers 2^-14 .. 65504, fp32 features and gradients do not stay there (a trained encoder's
 // conv_c outputs sit at ~1.5e-5 because the heads multiply by scale_factor = 64000, vec_dgcnn_atten.py:234-250; the gradients of the
 // pose refinement at 1e-6 .. 1e-8).  So every ROW of A and every row of W is multiplied by its own exact power of two before the split --
-// s = 2^(14 - floor(log2 max|row|)): the row's largest element lands in [2^14, 2^15), elements down to 2^-27 of it keep the full 22
-// bits, the absolute floor is 2^-49 of the row maximum -- and the product of the two inverse scales multiplies the fp32 accumulators in
+// s = 2^(14 - floor(log2 max|row|)): the row's largest element lands in [2^14, 2^15), elements down to 2^-17 of it keep the full 22
+// bits (their residual is still a normal f16), below that the absolute error is at most 2^-39 of the row maximum -- 2^-15 of the
+// fp32 rounding of the row's largest term -- and the product of the two inverse scales multiplies the fp32 accumulators in
 // the epilogue.  Powers of two commute with every rounding in between, so for data that was in range before the result is
 // BIT-IDENTICAL to the unscaled split, any finite fp32 input is handled, and a row's result depends on that row's data only.
 // The row maxima come from (a) a pre-pass of the kernel over its own operand rows (default), or (b) caller-supplied arrays
 // (GemmAux: the decoder chains them from the previous layer's epilogue, weights carry theirs from ls_model_create), which may be
-// any upper bound: each factor of two of slack costs one bit at the bottom of the 27-binade window.
+// any upper bound: each factor of two of slack costs one bit at the bottom of the 17-binade window.
 // (struct GemmAux: ls_common.h)
 __device__ __forceinline__ float amax4(float m, const float4& v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
     out += (size_t)blockIdx.y * slab_stride;
 
-    constexpr bool H2 = PIECES == 22;   // two f16 pieces, scaled residual (see split2_f16)
+    constexpr bool H2 = PIECES == 22;   // two f16 pieces (see split2_f16)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -905,6 +907,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
         __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
     }
+
+    // (Not kept: the operand fragments as an explicit four-sub-phase software pipeline -- every LDS read batch one sub-phase ahead of its
+    // MFMAs, the barrier in front of the last sub-phase.  Unfenced, the scheduler sinks the loads back to their uses: same time; fenced
+    // with sched_barrier: 256 VGPRs + spills, 1010 -> 1110 us at the decoder shape.)
 
     // epilogue: each wave transposes its 128 x 64 sub-tile through LDS in four 32-row pieces
     float* stg = reinterpret_cast<float*>(smem) + wave * STG;
@@ -1774,7 +1780,7 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     // conv, M = 3B), where the fp32 kernel's shorter slab (16 k, no split arithmetic before the first MFMA) wins: 44 vs 112 us
     // at M = 192, N = 1024, K = 512
     const bool split = split_on && !latency_path;
-    // how an fp32 product is formed on the 16-bit matrix cores: 22 = two f16 pieces with a scaled residual (three MFMAs per 16 k, the
+    // how an fp32 product is formed on the 16-bit matrix cores: 22 = two f16 pieces (three MFMAs per 16 k, the
     // default), 3 = three bf16 pieces (six MFMAs, any fp32 range: LS_GEMM_MODE=bf16x3), 2 = two bf16 pieces (opt-in decode mode)
     static const bool h2_unpipelined = getenv("LS_GEMM_H2_SIMPLE") && atoi(getenv("LS_GEMM_H2_SIMPLE")) != 0;   // A/B: the two-barrier kernel
     static const bool planes_off = getenv("LS_GEMM_WPLANES") && atoi(getenv("LS_GEMM_WPLANES")) == 0;   // A/B: split W inside the kernel
@@ -1811,7 +1817,9 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     const long long wtiles = (long long)cdiv(M, 256) * cdiv(N, 256);
     const bool wide_on = wide_mode >= 0 ? wide_mode != 0 : (wtiles >= 1024 || (wtiles >= 256 && wtiles * 100 >= 85 * 256 * cdiv(wtiles, 256)));
     if (split && pieces == 22 && persist && !mask && (K == 32 || K == 64) && tm >= 16 && !h2_unpipelined && !aux.out_rowmax) {
-        int per_n = cdiv(512, tn);   // two resident workgroups per CU (registers), spread evenly over the N-tiles
+        static const int sk_wgs32 = getenv("LS_GEMM_PERSIST_WGS32") ? atoi(getenv("LS_GEMM_PERSIST_WGS32")) : 512;   // A/B
+        static const int sk_wgs64 = getenv("LS_GEMM_PERSIST_WGS64") ? atoi(getenv("LS_GEMM_PERSIST_WGS64")) : 512;
+        int per_n = cdiv(K == 32 ? sk_wgs32 : sk_wgs64, tn);   // resident workgroups per CU x 256, spread evenly over the N-tiles
         if (per_n > tm) per_n = tm;
 #define LS_H2SK(KK, G) hipLaunchKernelGGL((gemm_h2_smallk_kernel<KK, G>), dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, relu, tm, per_n, a_rows, gNd, gNs, aux)
         if (K == 32) { if (a_rows) LS_H2SK(32, true); else LS_H2SK(32, false); }
@@ -1884,7 +1892,8 @@ int gemm_vn_dispatch(const float* A, int lda, const float* W, int ldw, const flo
     const int tm = cdiv(M, 120), tn = C / 64;
     static const bool persist = !(getenv("LS_GLOB_PERSIST") && atoi(getenv("LS_GLOB_PERSIST")) == 0);   // A/B: K = 32 / 64 on the tiled kernel
     if (persist && (K == 32 || K == 64) && tm >= 16 && lda == K) {
-        int per_n = cdiv(512, tn);   // two resident workgroups per CU
+        static const int vn_wgs32 = getenv("LS_GLOB_PERSIST_WGS32") ? atoi(getenv("LS_GLOB_PERSIST_WGS32")) : 512;   // A/B
+        int per_n = cdiv(K == 32 ? vn_wgs32 : 512, tn);   // resident workgroups per CU x 256
         if (per_n > tm) per_n = tm;
         if (K == 32) hipLaunchKernelGGL(gemm_vn_smallk_kernel<32>, dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, npts, oms, tm, per_n, tn, aux);
         else hipLaunchKernelGGL(gemm_vn_smallk_kernel<64>, dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, npts, oms, tm, per_n, tn, aux);

@@ -296,7 +296,7 @@ def test_gemm(M, N, K):
 
 
 def test_gemm_split_is_as_accurate_as_the_fp32_chain_and_row_invariant():
-    """The default GEMM forms every fp32 product from two f16 pieces with a scaled residual on the f16 matrix cores (gemm.hip;
+    """The default GEMM forms every fp32 product from two f16 pieces on the f16 matrix cores (gemm.hip;
     LS_GEMM_MODE=bf16x3: three bf16 pieces -- test_gemm_mode_switches).  Componentwise error against
     fp64 must stay within the fp32 FMA chain's own bound (in units of 2^-24 sum|a||w|: measured 6-9 vs 11-13 for the chain) on
     badly scaled operands, and the kernel's arithmetic must not depend on M: a row's result is the same whatever other rows the call
