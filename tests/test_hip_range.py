@@ -67,6 +67,24 @@ def test_gemm_with_presplit_weight_planes_is_bit_identical(M, N, K):
     assert bool(((out.double() - ref).abs() <= bound).all())
 
 
+@pytest.mark.parametrize("N,K", [(768, 768), (520, 256), (300, 128)])
+def test_gemm_tile_shape_does_not_change_a_bit(N, K):
+    """The dispatcher picks the 256 x 256-tile kernel (gemm_w2_kernel) or the 128 x 128 one by how well M fills the chip, so a row must
+    come out the same from both: M = 65 536 rows in one call (wide tiles) against slices of the same rows (too few tiles: narrow
+    kernel), with bias + ReLU and the emitted row maxima, ragged N included."""
+    from livingscenes_amd import ops
+    g = torch.Generator().manual_seed(N * K)
+    M = 65536 if N >= 512 else 2 * 65536
+    A = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-12, 12, (M, 1), generator=g).float())).to(_dev())
+    W = torch.randn(N, K, generator=g).to(_dev())
+    b = torch.randn(N, generator=g).to(_dev())
+    am, wm = ops.rowmax(A), ops.rowmax(W)
+    big, big_rm = ops.gemm_chain(A, W, b, relu=True, a_rowmax=am, w_rowmax=wm)
+    for lo, hi in ((0, 1000), (31337, 31337 + 4097), (M - 513, M)):
+        part, part_rm = ops.gemm_chain(A[lo:hi].contiguous(), W, b, relu=True, a_rowmax=am[lo:hi].contiguous(), w_rowmax=wm)
+        assert torch.equal(part, big[lo:hi]) and torch.equal(part_rm, big_rm[lo:hi]), (lo, hi)
+
+
 def test_presplit_planes_are_refused_where_no_kernel_reads_them():
     from livingscenes_amd import ops
     W = torch.randn(64, 64, device=_dev())
