@@ -168,13 +168,18 @@ def main():
                          "2x64-core host (0.65 inst/s at 16 vs 0.25 at 128 vs 0.07 at 256; tests/tools/cpu_threads_probe.py)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fma-variant", action="store_true", help="skip the secondary fused-multiply-add k-NN timing")
-    ap.add_argument("--inflight", type=int, default=12,
-                    help="independent steps kept in flight on separate HIP streams (each with its own model handle and "
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="0 = auto (12, or 8 when fewer than 48 steps are timed).  Independent steps kept in flight on separate HIP streams (each with its own model handle and "
                          "workspace): one step's low-occupancy kernels (FPS, heads, matcher) overlap another's big ones.  "
                          "Measured with 16 hardware queues (round 2, after the fusions): 4 -> 37.4k, 8 -> 43.6k, 10 -> 44.6k, "
                          "12 -> 45.6 - 46.4k, 14 -> 45.5k, 16 -> 41.3k obj/s; more hardware queues are worse (12 in flight: 20 queues "
                          "44.8k, 24: 42.6k, 32: 34.6k)")
     args = ap.parse_args()
+    if args.inflight <= 0:
+        # 12 in the steady state (480 steps: 8 -> 45.9k, 12 -> 47.5k); a short timed region is mostly ramp and drain of that pipeline and
+        # the shallower one wastes less of it (20 steps, three repetitions each: 8 -> 44.2 - 44.9k, 10 -> 42.8 - 43.3k, 12 -> 43.9 - 44.1k,
+        # 20 -> 42.8 - 43.0k)
+        args.inflight = 12 if args.steps >= 48 else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # LS_BENCH_FORCE_DIST=1: run the collective code path (RCCL init, weight broadcast, barriers, all-reduce / all-gather) even with
