@@ -135,7 +135,7 @@ def test_config3_scene_pair_at_released_settings(released_prior):
 
 def test_config3_scene_pair_optim_registration_at_released_settings(released_prior):
     """configs[3] with the branch eval_3rscan.py:381 actually runs -- registration.optim true, step_size.so3 0.05, early_stop_threshold
-    10 (/root/reference/configs/more_3rscan.yaml:12-17; n_steps capped at 24 of the 400 for test time, same code path): raw clouds of
+    10 (/root/reference/configs/more_3rscan.yaml:12-17; n_steps capped at 16 of the 400 for test time, same code path): raw clouds of
     10 - 25 k points, ragged FPS to 1 024, released encoder / decoder widths, all matched pairs refined in lock-step.  Checked against
     the oracle twin of the loop (oracle/optim.py, PARITY UNPINNED for torchlie / geomloss / roma) started from the same codes:
     the choice of the shared code, the refined pose before ICP, the best loss; then _solve_end2end(optim=True) end to end."""
@@ -145,7 +145,7 @@ def test_config3_scene_pair_optim_registration_at_released_settings(released_pri
     from oracle import optim as oo
     sp, (ecfg, dcfg, ew, dw) = released_prior
     dev = _dev()
-    steps = 24
+    steps = 16
     cfg = {"shape_priors": {"n_input_point": 1024}, "fps": {"n_init": 1, "random_start": False},
            "registration": {"optim": True, "step_size": {"so3": 0.05}, "n_steps": steps, "early_stop_threshold": 10}}
     solver = More_Solver(cfg, model=sp)
