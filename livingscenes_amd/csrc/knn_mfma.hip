@@ -473,7 +473,9 @@ __global__ __launch_bounds__(256, 3) void knn_finish_wave_kernel(const float* __
 // per MFMA, no LDS staging, no workgroup barriers; the waves are independent (32 queries x a candidate range each) and any
 // (queries x splits) grid fills the chip.  Per-query hints live in a wave-private LDS bitmap (a pass that is a hint is not
 // recorded), survivors are appended through global counters.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (the sweep image is f16 since round 3: see knn_prep_bf16_kernel)
+typedef _Float16 kh2_t __attribute__((ext_vector_type(2)));
+typedef float kf2_t __attribute__((ext_vector_type(2)));
 constexpr int KB_MAXNS = 2048;   // bitmap words per query = Ns / 32 <= 64
 constexpr int KB_CAPW = 64;      // survivor slots per (wave, query) in LDS
 
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(1024) void knn_mean_rows_kernel(const float* __rest
 constexpr int KNN_CENTRE_ROWS = 16;
 __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restrict__ f, const float* __restrict__ fc, int Nc, int N, int Npad, int D,
                                                             int tiles_total, unsigned short* __restrict__ out, float* __restrict__ norms,
-                                                            int32_t* __restrict__ zero_buf, long long zero_n) {
+                                                            float* __restrict__ iscale, int32_t* __restrict__ zero_buf, long long zero_n) {
     __shared__ __attribute__((aligned(16))) float lmu[4][192];
     // the sweep's per-query survivor counters are cleared here (a separate memset launch cost 5 - 7 us per layer)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256) zero_buf[i] = 0;
@@ -541,6 +543,20 @@ __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restr
     const float* rp = f + ((size_t)b * N + (live ? r : 0)) * D + h * 8;
     const float* mp = lmu[threadIdx.x >> 6] + h * 8;
     unsigned short* op = out + (((size_t)b * tpi + tile) * KK * 64 + lane) * 8;
+    // pass 1: the centred row's largest magnitude -> its exact power-of-two scale (largest element -> [2^14, 2^15): the f16 window follows
+    // every row, as in gemm.hip; elements below 2^-24 of the row maximum go subnormal: absolute error 2^-39 of it, inside the bound's slack)
+    float amax = 0.f;
+#pragma unroll 3
+    for (int kk = 0; kk < KK; ++kk) {
+        const float4 x0 = *reinterpret_cast<const float4*>(rp + kk * 16), x1 = *reinterpret_cast<const float4*>(rp + kk * 16 + 4);
+        const float4 m0 = *reinterpret_cast<const float4*>(mp + kk * 16), m1 = *reinterpret_cast<const float4*>(mp + kk * 16 + 4);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x0.x - m0.x), fabsf(x0.y - m0.y))), fmaxf(fabsf(x0.z - m0.z), fabsf(x0.w - m0.w)));
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x1.x - m1.x), fabsf(x1.y - m1.y))), fmaxf(fabsf(x1.z - m1.z), fabsf(x1.w - m1.w)));
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    unsigned be = (__float_as_uint(amax) >> 23) & 0xffu;
+    be = be < 15u ? 15u : be;
+    const float sc = live ? __uint_as_float((268u - be) << 23) : 0.f;      // (Inf / NaN rows: the image row is non-finite, every pair with it survives)
     float s = 0.f;
 #pragma unroll 3
     for (int kk = 0; kk < KK; ++kk) {
@@ -553,13 +569,14 @@ __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restr
         for (int i = 0; i < 4; ++i) {
             const float c0 = live ? c[2 * i] : 0.f, c1 = live ? c[2 * i + 1] : 0.f;
             s += c0 * c0 + c1 * c1;
-            pk[i] = f32_to_bf16_rne(c0) | (f32_to_bf16_rne(c1) << 16);
+            const kh2_t hv = __builtin_convertvector(kf2_t{c0 * sc, c1 * sc}, kh2_t);     // round to nearest even
+            pk[i] = __builtin_bit_cast(unsigned, hv);
         }
         w.x = pk[0]; w.y = pk[1]; w.z = pk[2]; w.w = pk[3];
         *reinterpret_cast<uint4*>(op + (size_t)kk * 512) = w;
     }
     s += __shfl_xor(s, 32, 64);
-    if (h == 0 && live) norms[(size_t)b * N + r] = s;
+    if (h == 0 && live) { norms[(size_t)b * N + r] = s; iscale[(size_t)b * N + r] = __uint_as_float((be - 14u) << 23); }
 }
 
 // QG (round 3, A/B only -- LS_KNN_SWEEP_QG=2): a wave sweeps QG groups of 32 queries against every candidate fragment it loads, which
@@ -568,7 +585,8 @@ __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restr
 template <int D, int QG>
 __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
                                                              const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
-                                                             const float* __restrict__ nrm_src, int Nd, int dst_n, int dst_npad, int Ns,
+                                                             const float* __restrict__ nrm_src, const float* __restrict__ isc_dst,
+                                                             const float* __restrict__ isc_src, int Nd, int dst_n, int dst_npad, int Ns,
                                                              int ns_pad, int K, int qgroups, int nsplit, int total_waves, float epsB,
                                                              const u64* __restrict__ seedkeys, int32_t* __restrict__ surv_cnt,
                                                              unsigned short* __restrict__ surv) {
@@ -603,21 +621,23 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
-    // drop  <=>  d^ - eps nn > kth  <=>  S~ < ((1-eps)(nq + ns) - kth) / 2 = A[row] + Bc[candidate]
-    float A[QG][16];
+    // drop  <=>  d^ - eps nn > kth  <=>  S~ < ((1-eps)(nq + ns) - kth) / 2 = A[row] + Bc[candidate];  S~ = S / (s_q s_c) (the rows' scales)
+    float A[QG][16], IQ[QG][16];
 #pragma unroll
     for (int u = 0; u < QG; ++u)
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int q = q0 + 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-            float v = INFINITY;                                        // padding query: S < inf, always dropped
+            float v = INFINITY, iq = 0.f;                              // padding query: 0 < inf, always dropped
             if (q < Nd) {
                 const int row = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
                 const unsigned hi = (unsigned)(seedkeys[((size_t)b * Nd + q) * 16 + (K - 1)] >> 32);
                 const float kth = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);   // fewer than K distinct hints: nothing is dropped
                 v = 0.5f * (om * nrm_dst[(size_t)b * dst_n + row] - kth);
+                iq = isc_dst[(size_t)b * dst_n + row];
             }
             A[u][rr] = v;
+            IQ[u][rr] = iq;
         }
     // hint bitmap of the wave's queries.  The keys are loaded BEFORE the LDS clear (the wave barriers are scheduling fences: the
     // loads would otherwise be issued only after the clear, one more exposed memory round trip per wave)
@@ -652,16 +672,17 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
         for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = t * 32 + l31;
         const float Bc = 0.5f * om * nsb[min(cg, Ns - 1)];
+        const float ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)];
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
             f32x16 S;
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][kk], bf[kk], S, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][kk], bf[kk], S, 0, 0, 0);
             unsigned mask = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mask |= (S[r] < A[u][r] + Bc) ? 0u : (1u << r);
+            for (int r = 0; r < 16; ++r) mask |= (S[r] * (IQ[u][r] * ic) < A[u][r] + Bc) ? 0u : (1u << r);
             if (cg >= Ns) mask = 0;
             while (mask) {
                 const int r = __builtin_ctz(mask);
@@ -707,6 +728,7 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
 template <int D, int QG>
 __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
                                                                 const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_src,
+                                                                const float* __restrict__ isc_dst, const float* __restrict__ isc_src, int dst_n,
                                                                 int Nd, int dst_npad, int Ns, int ns_pad, int qgroups, int nsplit,
                                                                 int total_waves, float* __restrict__ win_val, int32_t* __restrict__ win_idx) {
     constexpr int KK = D / 16;
@@ -728,12 +750,16 @@ __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned s
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
-    float best[QG][16];
+    float best[QG][16], IQ[QG][16];
     int bt[QG][16];
 #pragma unroll
     for (int u = 0; u < QG; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { best[u][r] = -INFINITY; bt[u][r] = -1; }
+        for (int r = 0; r < 16; ++r) {
+            best[u][r] = -INFINITY; bt[u][r] = -1;
+            const int q = q0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            IQ[u][r] = q < Nd ? isc_dst[(size_t)b * dst_n + (dst_rows ? dst_rows[(size_t)b * Nd + q] : q)] : 0.f;
+        }
     const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
     const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
 #pragma unroll 2
@@ -744,17 +770,19 @@ __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned s
         for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = t * 32 + l31;
         const float hb = cg < Ns ? 0.5f * nsb[min(cg, Ns - 1)] : INFINITY;   // padding columns can never win
+        const float ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)];
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
             f32x16 S;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[r] = -hb;                          // S - |s|^2 / 2: largest = nearest (|q|^2 is per query)
+            for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][kk], bf[kk], S, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][kk], bf[kk], S, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool better = S[r] > best[u][r];
-                best[u][r] = better ? S[r] : best[u][r];
+                const float v = S[r] * (IQ[u][r] * ic) - hb;                  // S~ - |s|^2 / 2: largest = nearest (|q|^2 is per query)
+                const bool better = v > best[u][r];
+                best[u][r] = better ? v : best[u][r];
                 bt[u][r] = better ? t : bt[u][r];
             }
         }
@@ -790,6 +818,189 @@ __global__ __launch_bounds__(256) void knn_autohint_select_kernel(const float* _
     if (lane < 16) hints[(size_t)q * 16 + lane] = (k == ~0ull) ? -1 : (int)(unsigned)k;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE-SWEEP path for un-seeded calls with at most KO_MAXNS candidates (round 3; the encoder's layers 3 and 4).  The auto-hint path above
+// sweeps the pair matrix twice (class winners, then the filter against the exact K-th distance of the 16 hints) with an exact "seed"
+// phase in between: five launches, 16 + ~40 exact distances per query.  Here ONE sweep stores the approximate cosine of every pair
+// (16-bit fixed point: |q'||s'| cos~ = S~ to 2^-16 |q'||s'|, far inside the bf16 bound) and ONE wave per query then
+//   1. rebuilds d^ = |q'|^2 + |s'|^2 - 2 |q'||s'| cos~ with its two-sided bound  lo = d^ - eps nn <= d_canonical <= d^ + eps nn = hi
+//      (nn = |q'|^2 + |s'|^2, eps = eps_b of the bf16 sweep + 2^-13 for the fixed point and this kernel's own roundings),
+//   2. takes T = the K-th smallest of the 64 per-lane minima of hi -- 64 disjoint candidate groups contribute one candidate each, so at
+//      least K candidates have a canonical distance <= T: T bounds the K-th canonical distance from above,
+//   3. keeps every candidate with lo <= T (a candidate of the true top K has d_canonical <= K-th <= T, hence lo <= T),
+//   4. computes the canonical distance of the survivors (same quad chains, same key network as knn_finish_wave_kernel).
+// Three launches (image, sweep, finish), no hints, no thresholds from exact distances; the lists only ever hold canonical keys, so the
+// result is bit-identical by construction.  Non-finite rows: T is not finite -> everything survives -> brute force, still exact.
+constexpr int KO_MAXNS = 512;
+#ifndef LS_KO_US
+#define LS_KO_US 1
+#endif
+#ifndef LS_KO_WPS
+#define LS_KO_WPS 4
+#endif
+// quad steps (16 survivors each) per iteration of the finish / waves per SIMD it is compiled for.  Measured at layer 3 (32 768 queries,
+// ~20 survivors each, 12 steps in flight): 3 steps at 3 waves 82 us, 2 at 3: 82, 2 at 4 (8 spills): 83, 1 at 4 (110 VGPRs): 73.  The
+// front end (bounds, T, compaction) is 25 us of that; the rest is the canonical chains: VALU-issue-bound at ~70 % of the issue rate
+constexpr int KO_US = LS_KO_US;
+constexpr int KO_WPS = LS_KO_WPS;
+template <int D>
+__global__ __launch_bounds__(256) void knn_sweep_store_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
+                                                              const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
+                                                              const float* __restrict__ nrm_src, const float* __restrict__ isc_dst,
+                                                              const float* __restrict__ isc_src, int Nd, int dst_n, int dst_npad, int Ns, int ns_pad,
+                                                              int qgroups, int nsplit, int total_waves, short* __restrict__ cosq) {
+    constexpr int KK = D / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wg >= total_waves) return;
+    const int sp = wg % nsplit, g = (wg / nsplit) % qgroups, b = wg / (nsplit * qgroups);
+    const int q0 = g * 32, l31 = lane & 31, lh = lane >> 5;
+    const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
+    const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
+    const float* nsb = nrm_src + (size_t)b * Ns;
+    bf16x8 a[KK];
+    {
+        const int qi = q0 + l31;
+        const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
+        const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+    }
+    float rq[16];          // 32767 / |q'| of the lane's 16 query rows (0: padding query or a row at the centre)
+    short* orow[16];       // where the row's cosines go (null: padding query)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int q = q0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+        float v = 0.f;
+        orow[rr] = nullptr;
+        if (q < Nd) {
+            const int row = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
+            const float nq = nrm_dst[(size_t)b * dst_n + row];
+            v = nq > 0.f ? 32767.0f * __builtin_amdgcn_rsqf(nq) * isc_dst[(size_t)b * dst_n + row] : 0.f;   // (the row's image scale folded in)
+            orow[rr] = cosq + ((size_t)b * Nd + q) * ns_pad;
+        }
+        rq[rr] = v;
+    }
+    const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
+    const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
+#pragma unroll 2
+    for (int t = t0; t < t1; ++t) {
+        const unsigned short* bp = sqb + ((size_t)t * KK * 64 + lane) * 8;
+        bf16x8 bf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        const int cg = t * 32 + l31;
+        const float ns = nsb[min(cg, Ns - 1)];
+        const float rs = ns > 0.f ? __builtin_amdgcn_rsqf(ns) * isc_src[(size_t)b * Ns + min(cg, Ns - 1)] : 0.f;
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], bf[kk], S, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // |S| <= |q'||s'| for the exact product, so the clamp can only move S~ towards it
+            const float c = fminf(fmaxf(S[r] * rq[r] * rs, -32767.0f), 32767.0f);
+            if (orow[r]) orow[r][cg] = (short)__float2int_rn(c);
+        }
+    }
+}
+
+template <int CC, bool FMA>
+__global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
+                                                                   const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
+                                                                   const float* __restrict__ nrm_src, int Nd, int dst_n, int Ns, int ns_pad, int K,
+                                                                   float epsS, const short* __restrict__ cosq, int32_t* __restrict__ idx_out,
+                                                                   float* __restrict__ dist_out, int total_q) {
+    constexpr int RF = 3 * CC;
+    constexpr int NV = KO_MAXNS / 64;
+    __shared__ unsigned short llist[4][KO_MAXNS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qg = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // consecutive queries (one instance) share an XCD
+    if (qg >= total_q) return;
+    const int b = qg / Nd, q = qg % Nd;
+    const float* sbase = srcf + (size_t)b * Ns * RF;
+    const int r = dst_rows ? dst_rows[qg] : q;
+    const float* qrow = dstf + ((size_t)b * dst_n + r) * RF;
+    const int quad = lane >> 2;
+    const bool qlast = (lane & 3) == 3;
+    QuadRow<CC> qv;
+    qv.load(qrow, lane);
+
+    // 1. two-sided bounds of every candidate's canonical distance (candidate j = 64 i + lane)
+    const float nq = nrm_dst[(size_t)b * dst_n + r], snq = sqrtf(nq);
+    const short* cp = cosq + (size_t)qg * ns_pad;
+    const float* nsb = nrm_src + (size_t)b * Ns;
+    float lo[NV];
+    float himin = INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = i * 64 + lane;
+        const bool valid = j < Ns;
+        const float c = (float)cp[min(j, ns_pad - 1)] * (1.0f / 32767.0f);
+        const float ns = nsb[min(j, Ns - 1)];
+        const float nn = nq + ns;
+        const float dh = nn - 2.0f * c * (snq * sqrtf(ns)), e = epsS * nn;
+        lo[i] = valid ? dh - e : INFINITY;
+        const float hi = (valid && dh == dh) ? fmaxf(dh + e, 0.0f) : INFINITY;   // (a NaN bound never wins the minimum; its candidate survives below)
+        himin = fminf(himin, hi);
+    }
+    // 2. T = the K-th smallest of the 64 lane minima (non-negative floats order like their bit patterns)
+    unsigned hb = __float_as_uint(himin);
+    LS_SORT64(cx32, hb, lane)
+    const float T = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)hb, K - 1 < 63 ? K - 1 : 63));
+    // 3. survivors -> the wave's LDS list
+    unsigned short* sp = llist[wave];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j = i * 64 + lane;
+        const bool keep = j < Ns && !(lo[i] > T);              // (NaN bounds survive)
+        const unsigned long long m = __ballot(keep);
+        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (keep) sp[pos] = (unsigned short)j;
+        cnt += __popcll(m);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the list is wave-private, LDS ops of a wave complete in order
+    __builtin_amdgcn_wave_barrier();
+    // 4. canonical keys of the survivors, 16 KO_US per step, sorted with the list so far by the 64-lane network
+    // (Measured and not kept: two passes -- first the candidates with hi <= T, which give an exact K-th distance, then the rest against
+    // that one-sided bound: fewer exact distances but a second dependent round of gathers per query; 86 -> 97 us at layer 3 with the
+    // bf16 image.  With the f16 image the survivors fit one 48-wide step anyway.)
+    u64 best = ~0ull;
+#if defined(LS_VAR_KO_NOEXACT)   // dev timing variant: front end only
+    cnt = 0;
+#endif
+#if defined(LS_VAR_KO_ONEITER)   // dev timing variant: at most one step of exact distances
+    cnt = min(cnt, 16 * KO_US);
+#endif
+    for (int base = 0; base < cnt; base += 16 * KO_US) {
+        u64 ks[3] = {~0ull, ~0ull, ~0ull};
+#pragma unroll
+        for (int u = 0; u < KO_US; ++u) {
+            if (base + u * 16 < cnt) {   // wave-uniform
+                const int j = base + u * 16 + quad;
+                const bool v = j < cnt;
+                const int c = v ? (int)sp[j] : 0;
+                ks[u] = make_key(quad_pair_distance<CC, FMA>(qv, qrow, sbase + (size_t)c * RF, lane), c, v & qlast);
+            }
+        }
+        const int src = ((lane & 15) << 2) + 3;
+        const u64 n0 = bperm64(src, ks[0]), n1 = bperm64(src, ks[1]), n2 = KO_US > 2 ? bperm64(src, ks[2]) : ~0ull;
+        u64 k = lane < 16 ? best : (lane < 32 ? n0 : (lane < 48 ? n1 : n2));
+        LS_SORT64(cx64, k, lane)
+        best = k;
+    }
+    if (lane < K) {
+        const size_t o = (size_t)qg * K + lane;
+        const unsigned hi = (unsigned)(best >> 32), lw = (unsigned)best;
+        idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lw;
+        if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
+    }
+}
+
 static inline size_t pad32(size_t n) { return (n + 31) & ~(size_t)31; }
 static bool knn_sweep_bf16_enabled() {
     static const bool off = getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0;   // A/B: fp32 sweep kernel
@@ -802,7 +1013,9 @@ size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C) {
            + nq * 16 * sizeof(u64) + nq * sizeof(int32_t) + nq * KS_CAP * sizeof(unsigned short) + 256
            + (size_t)B * D * sizeof(float) + 256                            // instance means
            + ((size_t)B * pad32(Ns) + (size_t)B * pad32(dst_n)) * D * sizeof(unsigned short) + 512    // bf16 images (src, dst)
-           + nq * 64 * (sizeof(float) + sizeof(int32_t)) + nq * 16 * sizeof(int32_t) + 512;           // auto hints: class winners, hints
+           + nq * 64 * (sizeof(float) + sizeof(int32_t)) + nq * 16 * sizeof(int32_t) + 512            // auto hints: class winners, hints
+           + (pad32(Ns) <= (size_t)KO_MAXNS ? nq * pad32(Ns) * sizeof(short) + 256 : 0)                // one-sweep path: the pair cosines
+           + ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256;                               // inverse row scales of the f16 images
 }
 
 template <int CC>
@@ -818,6 +1031,12 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     float* ndst = nsrc;
     size_t off = (size_t)B * Ns * sizeof(float);
     if (dst != src) ndst = (float*)(sc + off);
+    off += (size_t)B * dst_n * sizeof(float);
+    off = (off + 255) & ~(size_t)255;
+    float* isrc = (float*)(sc + off);          // inverse row scales of the f16 images (knn_prep_bf16_kernel)
+    float* idst = isrc;
+    off += (size_t)B * Ns * sizeof(float);
+    if (dst != src) idst = (float*)(sc + off);
     off += (size_t)B * dst_n * sizeof(float);
     off = (off + 255) & ~(size_t)255;
     u64* seedkeys = (u64*)(sc + off);
@@ -847,12 +1066,35 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         static_assert(D <= 192, "knn_prep_bf16_kernel keeps the centre in a 192-float LDS slot per wave");
         (void)mu;
         hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, src, Ns, Ns, ns_pad, D,
-                           B * (ns_pad / 32), sq, nsrc, surv_cnt, (long long)nq);
+                           B * (ns_pad / 32), sq, nsrc, isrc, surv_cnt, (long long)nq);
         LS_LAUNCH_CHECK();
         if (dst != src) {   // same centre for both sets: the candidates' first rows
             hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, src, Ns, dst_n, dst_npad, D,
-                               B * (dst_npad / 32), dq, ndst, (int32_t*)nullptr, 0LL);
+                               B * (dst_npad / 32), dq, ndst, idst, (int32_t*)nullptr, 0LL);
             LS_LAUNCH_CHECK();
+        }
+        static const bool one_sweep_on = !(getenv("LS_KNN_ONE_SWEEP") && atoi(getenv("LS_KNN_ONE_SWEEP")) == 0);   // A/B: the two-sweep auto-hint path
+        if (!seed_idx && one_sweep_on && ns_pad <= KO_MAXNS && K <= 16) {   // un-seeded, few candidates: one sweep + one finish (see above)
+            unsigned short* img_end = dq + (size_t)B * dst_npad * D;
+            char* wend = (char*)((((uintptr_t)img_end + 255) & ~(uintptr_t)255) + nq * 64 * (sizeof(float) + sizeof(int32_t)) + nq * 16 * sizeof(int32_t) + 256);
+            short* cosq = (short*)(((uintptr_t)wend + 255) & ~(uintptr_t)255);
+            const int qgroups = cdiv(Nd, 32);
+            int nsplit = 1;
+            while ((long long)B * qgroups * nsplit < 4096 && nsplit * 2 <= ns_pad / 32 && nsplit < 16) nsplit *= 2;
+            const int total_waves = B * qgroups * nsplit;
+            hipLaunchKernelGGL((knn_sweep_store_kernel<D>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n, dst_npad,
+                               Ns, ns_pad, qgroups, nsplit, total_waves, cosq);
+            LS_LAUNCH_CHECK();
+            const float epsS = 1.02f * 0.0009765625f + 6.0f * (float)(D + 4) * 5.9604645e-8f + 6.103515625e-5f;   // f16 image + 2^-14 (fixed point, this kernel)
+            const int wblocks = cdiv((long long)nq, 4);
+            if (fma)
+                hipLaunchKernelGGL((knn_finish_select_kernel<CC, true>), dim3(wblocks), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, ns_pad,
+                                   K, epsS, cosq, idx_out, dist_out, (int)nq);
+            else
+                hipLaunchKernelGGL((knn_finish_select_kernel<CC, false>), dim3(wblocks), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, ns_pad,
+                                   K, epsS, cosq, idx_out, dist_out, (int)nq);
+            LS_LAUNCH_CHECK();
+            return LS_OK;
         }
         if (!seed_idx) {   // un-seeded call: hints from a first sweep (class winners; the 16 best are picked inside the seed kernel)
             unsigned short* img_end = dq + (size_t)B * dst_npad * D;
@@ -862,11 +1104,11 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
             win_w = 32 * nsplit;
             if (qg == 2) {
                 const int qgroups = cdiv(Nd, 64), total_waves = B * qgroups * nsplit;
-                hipLaunchKernelGGL((knn_sweep_winners_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, Nd, dst_npad,
+                hipLaunchKernelGGL((knn_sweep_winners_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, idst, isrc, dst_n, Nd, dst_npad,
                                    Ns, ns_pad, qgroups, nsplit, total_waves, win_val, win_idx);
             } else {
                 const int qgroups = cdiv(Nd, 32), total_waves = B * qgroups * nsplit;
-                hipLaunchKernelGGL((knn_sweep_winners_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, Nd, dst_npad,
+                hipLaunchKernelGGL((knn_sweep_winners_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, nsrc, idst, isrc, dst_n, Nd, dst_npad,
                                    Ns, ns_pad, qgroups, nsplit, total_waves, win_val, win_idx);
             }
             LS_LAUNCH_CHECK();
@@ -916,13 +1158,13 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         static const int wave_target = getenv("LS_KNN_SWEEP_WAVES") ? atoi(getenv("LS_KNN_SWEEP_WAVES")) : 4096;   // A/B
         while ((long long)B * qgroups * nsplit < wave_target && nsplit * 8 <= ns_pad / 32 && nsplit < 16) nsplit *= 2;   // >= 4 tiles per wave
         const int total_waves = B * qgroups * nsplit;
-        const float epsB = 1.02f * 0.0078125f + epsE;
+        const float epsB = 1.02f * 0.0009765625f + epsE + 9.5367431640625e-7f;   // f16 image: 2 u = 2^-10 (+ 2^-20: subnormal tails of a row)
         const size_t lds = (size_t)4 * (nqw * (ns_pad / 32) + nqw + nqw * (KB_CAPW / qg) / 2) * sizeof(unsigned);   // <= 52 KB (QG = 2: <= 50 KB)
         if (qg == 2)
-            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, Nd, dst_n,
+            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n,
                                dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
         else
-            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, Nd, dst_n,
+            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n,
                                dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
     } else {
         hipLaunchKernelGGL(knn_sweep_kernel<CC>, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles,

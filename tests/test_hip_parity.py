@@ -130,16 +130,17 @@ def test_knn_large_batch_unsplit_path():
     assert np.array_equal(ops.knn(ft, ft, 16, seeds=hints, flags=_lib.FLAG_KNN_VALU_ONLY).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("N", [640, 480])     # 480: un-seeded calls take the one-sweep path (<= 512 candidates), 640 the class-winner hints
 @pytest.mark.parametrize("C", [32, 64])
 @pytest.mark.parametrize("case", ["offset", "near_duplicates", "clustered", "scale_mix"])
-def test_knn_mfma_filter_is_exact_on_adversarial_features(case, C):
+def test_knn_mfma_filter_is_exact_on_adversarial_features(case, C, N):
     """The MFMA sweep kernel may only drop pairs that provably cannot enter a list.  Stress the cancellation in
     |q|^2+|s|^2-2q.s: a huge common offset, near-duplicate points, tight clusters, wildly different norms.  The result
     must be bit-identical to the oracle for the all-VALU kernel (un-seeded) AND the seeded MFMA sweep kernel."""
     from livingscenes_amd import _lib, ops
     from oracle import canon
     rng = np.random.default_rng({"offset": 1, "near_duplicates": 2, "clustered": 3, "scale_mix": 4}[case])
-    B, N = 3, 640
+    B = 3
     f = rng.standard_normal((B, N, 3, C)).astype(np.float32)
     if case == "offset":
         f = (f * 1e-3 + 50.0).astype(np.float32)            # norms ~ 7e5, spreads ~ 1e-3: d^ is pure cancellation noise
