@@ -251,7 +251,7 @@ static size_t knn_partial_bytes(int B, int Nd, int Ns) {
     return sp > 1 ? (size_t)B * Nd * sp * 16 * sizeof(u64) : 0;
 }
 // the MFMA sweep kernel (knn_mfma.hip) takes the seeded C == 32 launches unless the caller forces the all-VALU kernel
-// ... and, with hints of its own making (knn_mfma.hip, "auto hints"), the un-seeded ones whose candidates fit the bf16 sweep's bitmap
+// ... and, with hints of its own making (knn_mfma.hip, "auto hints"), the un-seeded ones whose candidates fit the f16 sweep's bitmap
 static bool knn_autohints_enabled() {
     static const bool off = (getenv("LS_KNN_AUTOHINTS") && atoi(getenv("LS_KNN_AUTOHINTS")) == 0) ||
                             (getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0);

@@ -6,8 +6,8 @@
 //
 // knn.hip spends ~250 M VALU instructions per layer-1 launch on the canonical (sub, mul, add) distance of EVERY pair, although
 // once a query's list holds its previous-layer neighbours only ~25 of 1024 candidates can still enter it.  Here:
-//   1. S = q . s on the matrix cores, giving d^ = |q|^2 + |s|^2 - 2S.  Default: bf16 operands on centred rows
-//      (v_mfma_f32_32x32x16_bf16, knn_sweep_bf16_kernel, error bound in the comment above it); fp32 operands
+//   1. S = q . s on the matrix cores, giving d^ = |q|^2 + |s|^2 - 2S.  Default: f16 operands on centred, row-scaled rows
+//      (v_mfma_f32_32x32x16_f16, knn_sweep_f16_kernel, error bound in the comment above it; bf16 until round 3); fp32 operands
 //      (v_mfma_f32_32x32x2_f32, knn_sweep_kernel) for Ns > 2048 or LS_KNN_SWEEP_FP32=1;
 //   2. a pair is DROPPED only if  d^ - eps > kth(q)  (kth = the query's current exact K-th distance), where for the fp32 sweep
 //      eps = 6 (D+4) 2^-24 (|q|^2+|s|^2) bounds |d^ - d_true| + |d_canonical - d_true| with 50 % slack
@@ -459,31 +459,29 @@ __global__ __launch_bounds__(256, 3) void knn_finish_wave_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 2'. bf16 sweep.  The filter only has to be SAFE, not accurate, so S = q . s does not need fp32 operands: with the rows
-// centred on the instance mean (distances are translation invariant) and rounded to bf16 (unit roundoff 2^-8),
-//     |S~ - S| <= (2^-8 + 2^-17) (|q'|^2 + |s'|^2)       (Cauchy-Schwarz; fp32 accumulation adds D 2^-23 of the same scale)
-// so  d^ = |q'|^2 + |s'|^2 - 2 S~  is within  eps_b (|q'|^2 + |s'|^2),  eps_b = 1.02 * 2^-7 + 6 (D+4) 2^-24,  of the canonical
-// distance (the second term: fp32 norms, the canonical chain's own rounding, the centring subtraction).  A pair is dropped
-// only if  d^ - eps_b (..) > kth;  on the encoder's features kth / (|q'|^2+|s'|^2) is 0.04 .. 0.3, so the wider margin
-// admits 5 .. 20 % more survivors than the fp32 sweep (tests/tools/knn_seed_quality.py) while the matrix cores run
-// v_mfma_f32_32x32x16_bf16 at 16x the fp32 rate.  Without centring a common offset would drown the distances in eps_b.
+// 2'. f16 sweep.  The filter only has to be SAFE, not accurate, so S = q . s does not need fp32 operands: with the rows
+// centred on the instance centre (distances are translation invariant), scaled by an exact power of two PER ROW (largest element
+// -> [2^14, 2^15): the f16 window follows the row as in gemm.hip; the inverse scales multiply S back) and rounded to f16 (unit
+// roundoff u = 2^-11),
+//     |S~ - S| <= (2u + u^2) |q'||s'| <= (2^-11 + 2^-23) (|q'|^2 + |s'|^2)      (fp32 accumulation adds D 2^-23 of the same scale)
+// so  d^ = |q'|^2 + |s'|^2 - 2 S~  is within  eps_b (|q'|^2 + |s'|^2),  eps_b = 1.02 * 2^-10 + 6 (D+4) 2^-24 + 2^-20,  of the canonical
+// distance (second term: fp32 norms, the canonical chain's own rounding, the centring subtraction; third: elements more than 24
+// binades below their row's maximum go subnormal).  A pair is dropped only if  d^ - eps_b (..) > kth.  Rounds 1-2 used bf16
+// (u = 2^-8, no row scale needed): the margin was 8x wider -- on the encoder's features kth / (|q'|^2+|s'|^2) is 0.04 .. 0.3, so bf16
+// admitted 5 .. 20 % more survivors than an fp32 sweep, f16 admits < 3 % more -- at the same matrix-core rate
+// (v_mfma_f32_32x32x16_f16).  Without centring a common offset would drown the distances in eps_b.
 //
-// Layout: knn_prep_bf16_kernel writes the centred rows "fragment-major": [instance][32-row tile][k-step of 16 dims][lane
-// (k-half h, row j)][8 bf16], i.e. exactly the 1 KB a wave's B operand load wants -> one fully coalesced 16-byte-per-lane load
+// Layout: knn_prep_f16_kernel writes the centred rows "fragment-major": [instance][32-row tile][k-step of 16 dims][lane
+// (k-half h, row j)][8 f16], i.e. exactly the 1 KB a wave's B operand load wants -> one fully coalesced 16-byte-per-lane load
 // per MFMA, no LDS staging, no workgroup barriers; the waves are independent (32 queries x a candidate range each) and any
 // (queries x splits) grid fills the chip.  Per-query hints live in a wave-private LDS bitmap (a pass that is a hint is not
 // recorded), survivors are appended through global counters.
-typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (the sweep image is f16 since round 3: see knn_prep_bf16_kernel)
+typedef _Float16 f16x8k __attribute__((ext_vector_type(8)));
 typedef _Float16 kh2_t __attribute__((ext_vector_type(2)));
 typedef float kf2_t __attribute__((ext_vector_type(2)));
 constexpr int KB_MAXNS = 2048;   // bitmap words per query = Ns / 32 <= 64
 constexpr int KB_CAPW = 64;      // survivor slots per (wave, query) in LDS
 
-__device__ __forceinline__ unsigned f32_to_bf16_rne(float x) {
-    const unsigned u = __float_as_uint(x);
-    if ((u & 0x7F800000u) == 0x7F800000u) return (u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u);   // inf / nan
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
 
 // centre of an instance: the mean of its first min(N, 64) rows (any centre is valid -- distances are translation invariant
 // and the error bound is relative to the centred norms; the encoder's rows are in FPS order, so a prefix is a spread-out
@@ -513,7 +511,7 @@ __global__ __launch_bounds__(1024) void knn_mean_rows_kernel(const float* __rest
 // into its own LDS slot -- lane l takes dims l, l + 64, l + 128, coalesced row reads out of L2.  Any centre is valid (header comment of
 // knn_mean_rows_kernel); 16 FPS-ordered rows instead of 64 widen the filter's margin by ~5 %.
 constexpr int KNN_CENTRE_ROWS = 16;
-__global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restrict__ f, const float* __restrict__ fc, int Nc, int N, int Npad, int D,
+__global__ __launch_bounds__(256) void knn_prep_f16_kernel(const float* __restrict__ f, const float* __restrict__ fc, int Nc, int N, int Npad, int D,
                                                             int tiles_total, unsigned short* __restrict__ out, float* __restrict__ norms,
                                                             float* __restrict__ iscale, int32_t* __restrict__ zero_buf, long long zero_n) {
     __shared__ __attribute__((aligned(16))) float lmu[4][192];
@@ -583,7 +581,7 @@ __global__ __launch_bounds__(256) void knn_prep_bf16_kernel(const float* __restr
 // halves the L2 -> CU stream of the candidate image (layer 1: 2 048 waves x 196 KB = 403 MB per launch with one group).  Measured slower
 // (see knn_sweep_launch_t): the kernel is latency-, not stream-bound.  One group is the default.
 template <int D, int QG>
-__global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
+__global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
                                                              const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
                                                              const float* __restrict__ nrm_src, const float* __restrict__ isc_dst,
                                                              const float* __restrict__ isc_src, int Nd, int dst_n, int dst_npad, int Ns,
@@ -612,14 +610,14 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
     unsigned short* llist = reinterpret_cast<unsigned short*>(lcnt + NQW);
 
     // A fragments: query row q0 + 32 u + l31 (padding queries: row 0; their threshold drops everything)
-    bf16x8 a[QG][KK];
+    f16x8k a[QG][KK];
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
         const int qi = q0 + 32 * u + l31;
         const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
         const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
     // drop  <=>  d^ - eps nn > kth  <=>  S~ < ((1-eps)(nq + ns) - kth) / 2 = A[row] + Bc[candidate];  S~ = S / (s_q s_c) (the rows' scales)
     float A[QG][16], IQ[QG][16];
@@ -667,9 +665,9 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
 #pragma unroll 2
     for (int t = t0; t < t1; ++t) {
         const unsigned short* bp = sqb + ((size_t)t * KK * 64 + lane) * 8;
-        bf16x8 bf[KK];
+        f16x8k bf[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = t * 32 + l31;
         const float Bc = 0.5f * om * nsb[min(cg, Ns - 1)];
         const float ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)];
@@ -720,7 +718,7 @@ __global__ __launch_bounds__(256) void knn_sweep_bf16_kernel(const unsigned shor
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 0'. hints for UN-SEEDED calls ("auto hints").  Without a previous layer's graph the thresholds come from the data itself: one
-// more bf16 sweep in which every lane keeps, for each of its 16 query rows, the best candidate it has seen -- lane l31 of a wave
+// more f16 sweep in which every lane keeps, for each of its 16 query rows, the best candidate it has seen -- lane l31 of a wave
 // sees the candidates of residue class l31 (mod 32) of its tile range, so a query gets 32 x nsplit class winners -- and
 // knn_autohint_select_kernel keeps the 16 best of them by approximate distance.  A true neighbour is missed only if a better
 // one shares its class (~2 of 16 with 64 classes), so the K-th exact distance among these hints is close to the final one and
@@ -741,14 +739,14 @@ __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned s
     const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
     const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
     const float* nsb = nrm_src + (size_t)b * Ns;
-    bf16x8 a[QG][KK];
+    f16x8k a[QG][KK];
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
         const int qi = q0 + 32 * u + l31;
         const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
         const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
     float best[QG][16], IQ[QG][16];
     int bt[QG][16];
@@ -765,9 +763,9 @@ __global__ __launch_bounds__(256) void knn_sweep_winners_kernel(const unsigned s
 #pragma unroll 2
     for (int t = t0; t < t1; ++t) {
         const unsigned short* bp = sqb + ((size_t)t * KK * 64 + lane) * 8;
-        bf16x8 bf[KK];
+        f16x8k bf[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = t * 32 + l31;
         const float hb = cg < Ns ? 0.5f * nsb[min(cg, Ns - 1)] : INFINITY;   // padding columns can never win
         const float ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)];
@@ -822,9 +820,9 @@ __global__ __launch_bounds__(256) void knn_autohint_select_kernel(const float* _
 // ONE-SWEEP path for un-seeded calls with at most KO_MAXNS candidates (round 3; the encoder's layers 3 and 4).  The auto-hint path above
 // sweeps the pair matrix twice (class winners, then the filter against the exact K-th distance of the 16 hints) with an exact "seed"
 // phase in between: five launches, 16 + ~40 exact distances per query.  Here ONE sweep stores the approximate cosine of every pair
-// (16-bit fixed point: |q'||s'| cos~ = S~ to 2^-16 |q'||s'|, far inside the bf16 bound) and ONE wave per query then
+// (16-bit fixed point: |q'||s'| cos~ = S~ to 2^-16 |q'||s'|, far inside the f16 bound) and ONE wave per query then
 //   1. rebuilds d^ = |q'|^2 + |s'|^2 - 2 |q'||s'| cos~ with its two-sided bound  lo = d^ - eps nn <= d_canonical <= d^ + eps nn = hi
-//      (nn = |q'|^2 + |s'|^2, eps = eps_b of the bf16 sweep + 2^-13 for the fixed point and this kernel's own roundings),
+//      (nn = |q'|^2 + |s'|^2, eps = eps_b of the f16 sweep + 2^-14 for the fixed point and this kernel's own roundings),
 //   2. takes T = the K-th smallest of the 64 per-lane minima of hi -- 64 disjoint candidate groups contribute one candidate each, so at
 //      least K candidates have a canonical distance <= T: T bounds the K-th canonical distance from above,
 //   3. keeps every candidate with lo <= T (a candidate of the true top K has d_canonical <= K-th <= T, hence lo <= T),
@@ -859,13 +857,13 @@ __global__ __launch_bounds__(256) void knn_sweep_store_kernel(const unsigned sho
     const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
     const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
     const float* nsb = nrm_src + (size_t)b * Ns;
-    bf16x8 a[KK];
+    f16x8k a[KK];
     {
         const int qi = q0 + l31;
         const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
         const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
     float rq[16];          // 32767 / |q'| of the lane's 16 query rows (0: padding query or a row at the centre)
     short* orow[16];       // where the row's cosines go (null: padding query)
@@ -887,9 +885,9 @@ __global__ __launch_bounds__(256) void knn_sweep_store_kernel(const unsigned sho
 #pragma unroll 2
     for (int t = t0; t < t1; ++t) {
         const unsigned short* bp = sqb + ((size_t)t * KK * 64 + lane) * 8;
-        bf16x8 bf[KK];
+        f16x8k bf[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = t * 32 + l31;
         const float ns = nsb[min(cg, Ns - 1)];
         const float rs = ns > 0.f ? __builtin_amdgcn_rsqf(ns) * isc_src[(size_t)b * Ns + min(cg, Ns - 1)] : 0.f;
@@ -1002,7 +1000,7 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
 }
 
 static inline size_t pad32(size_t n) { return (n + 31) & ~(size_t)31; }
-static bool knn_sweep_bf16_enabled() {
+static bool knn_sweep_f16_enabled() {
     static const bool off = getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0;   // A/B: fp32 sweep kernel
     return !off;
 }
@@ -1012,7 +1010,7 @@ size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C) {
     return ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256      // row norms
            + nq * 16 * sizeof(u64) + nq * sizeof(int32_t) + nq * KS_CAP * sizeof(unsigned short) + 256
            + (size_t)B * D * sizeof(float) + 256                            // instance means
-           + ((size_t)B * pad32(Ns) + (size_t)B * pad32(dst_n)) * D * sizeof(unsigned short) + 512    // bf16 images (src, dst)
+           + ((size_t)B * pad32(Ns) + (size_t)B * pad32(dst_n)) * D * sizeof(unsigned short) + 512    // f16 images (src, dst)
            + nq * 64 * (sizeof(float) + sizeof(int32_t)) + nq * 16 * sizeof(int32_t) + 512            // auto hints: class winners, hints
            + (pad32(Ns) <= (size_t)KO_MAXNS ? nq * pad32(Ns) * sizeof(short) + 256 : 0)                // one-sweep path: the pair cosines
            + ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256;                               // inverse row scales of the f16 images
@@ -1025,7 +1023,7 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     const int C = CC;
     constexpr int D = 3 * CC;
     const size_t nq = (size_t)B * Nd;
-    const bool bf16 = knn_sweep_bf16_enabled() && Ns <= KB_MAXNS;
+    const bool f16img = knn_sweep_f16_enabled() && Ns <= KB_MAXNS;
     char* sc = (char*)scratch;
     float* nsrc = (float*)sc;
     float* ndst = nsrc;
@@ -1033,7 +1031,7 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     if (dst != src) ndst = (float*)(sc + off);
     off += (size_t)B * dst_n * sizeof(float);
     off = (off + 255) & ~(size_t)255;
-    float* isrc = (float*)(sc + off);          // inverse row scales of the f16 images (knn_prep_bf16_kernel)
+    float* isrc = (float*)(sc + off);          // inverse row scales of the f16 images (knn_prep_f16_kernel)
     float* idst = isrc;
     off += (size_t)B * Ns * sizeof(float);
     if (dst != src) idst = (float*)(sc + off);
@@ -1054,7 +1052,7 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     unsigned short* dq = sq;
     if (dst != src) dq = sq + (size_t)B * ns_pad * D;
     int rc;
-    // query groups per sweep wave (knn_sweep_bf16_kernel): LS_KNN_SWEEP_QG=2 halves the candidate stream per query (A/B; measured SLOWER in
+    // query groups per sweep wave (knn_sweep_f16_kernel): LS_KNN_SWEEP_QG=2 halves the candidate stream per query (A/B; measured SLOWER in
     // round 3 -- k-NN build 138 / 102 / 148 / 92 us at layers 1 - 4 with one group, 161 / 133 / 152 / 97 us with two: the sweep is bound by
     // the latency of its fragment loads at 2 - 3 waves per SIMD, not by the L2 stream -- so one group stays the default)
     static const int qg_env = getenv("LS_KNN_SWEEP_QG") ? atoi(getenv("LS_KNN_SWEEP_QG")) : 0;
@@ -1062,14 +1060,14 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     float* win_val = nullptr;      // auto hints: class winners of the first sweep (selected inside the seed kernel)
     int32_t* win_idx = nullptr;
     int win_w = 0;
-    if (bf16) {
-        static_assert(D <= 192, "knn_prep_bf16_kernel keeps the centre in a 192-float LDS slot per wave");
+    if (f16img) {
+        static_assert(D <= 192, "knn_prep_f16_kernel keeps the centre in a 192-float LDS slot per wave");
         (void)mu;
-        hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, src, Ns, Ns, ns_pad, D,
+        hipLaunchKernelGGL(knn_prep_f16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, src, Ns, Ns, ns_pad, D,
                            B * (ns_pad / 32), sq, nsrc, isrc, surv_cnt, (long long)nq);
         LS_LAUNCH_CHECK();
         if (dst != src) {   // same centre for both sets: the candidates' first rows
-            hipLaunchKernelGGL(knn_prep_bf16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, src, Ns, dst_n, dst_npad, D,
+            hipLaunchKernelGGL(knn_prep_f16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, src, Ns, dst_n, dst_npad, D,
                                B * (dst_npad / 32), dq, ndst, idst, (int32_t*)nullptr, 0LL);
             LS_LAUNCH_CHECK();
         }
@@ -1151,7 +1149,7 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         hipLaunchKernelGGL((knn_seed_kernel<CC, false>), dim3(gblocks), dim3(256), 0, st, dst, src, dst_rows, Nd, dst_n, Ns, K, seed_idx, seed_n,
                            seed_by_row, seedkeys, groups, B * groups, (const float*)nullptr, (const int32_t*)nullptr, 0);
     LS_LAUNCH_CHECK();
-    if (bf16) {
+    if (f16img) {
         const int nqw = 32 * qg;                    // queries per wave
         const int qgroups = cdiv(Nd, nqw);
         int nsplit = 1;   // >= ~4 waves per SIMD over the chip (4096 waves) when the query grid alone is smaller
@@ -1161,10 +1159,10 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         const float epsB = 1.02f * 0.0009765625f + epsE + 9.5367431640625e-7f;   // f16 image: 2 u = 2^-10 (+ 2^-20: subnormal tails of a row)
         const size_t lds = (size_t)4 * (nqw * (ns_pad / 32) + nqw + nqw * (KB_CAPW / qg) / 2) * sizeof(unsigned);   // <= 52 KB (QG = 2: <= 50 KB)
         if (qg == 2)
-            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n,
+            hipLaunchKernelGGL((knn_sweep_f16_kernel<D, 2>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n,
                                dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
         else
-            hipLaunchKernelGGL((knn_sweep_bf16_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n,
+            hipLaunchKernelGGL((knn_sweep_f16_kernel<D, 1>), dim3(cdiv(total_waves, 4)), dim3(256), lds, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n,
                                dst_npad, Ns, ns_pad, K, qgroups, nsplit, total_waves, epsB, seedkeys, surv_cnt, surv);
     } else {
         hipLaunchKernelGGL(knn_sweep_kernel<CC>, dim3(B * qtiles), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, K, qtiles,
