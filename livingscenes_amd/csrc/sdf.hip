@@ -37,36 +37,70 @@ __global__ __launch_bounds__(256) void sdf_prep_kernel(const float* __restrict__
 }
 
 // h[row][o] = relu( (accumulate ? h[row][o] : 0) + A[b][o][0:3] . q + A[b][o][3] |q| + beff[b][o] ),
-// q = (query - t[b]) / s[b]   (model_utils.py:236, :238-239).  Workgroup = (column block of 256, instance, row slab).
+// q = (query - t[b]) / s[b]   (model_utils.py:236, :238-239).  Workgroup = (column block of 256, instance, slab of 64 rows); a lane owns
+// FOUR consecutive columns (one 16-byte store per row), wave w the rows w, w + 4, ... of the slab.
+// The normalised query (three IEEE divisions and a square root) is the same for every column: lane l computes it for row l of the slab and
+// the row loop reads it back with v_readlane.  (Round 2 recomputed it in all 256 threads for every row and stored one float per thread:
+// ~55 instructions per stored float, 581 us per 262 144-row chunk at width 768; once per row: 367 us; four columns per lane: see DESIGN
+// 11.10.)  Same formulas per element: results unchanged.
+struct AffCols {   // one lane's four columns of the folded layer
+    float4 a[4];
+    float4 bb;
+};
+__device__ __forceinline__ AffCols aff_load(const float* __restrict__ A, const float* __restrict__ beff, int b, int out_dim, int ow) {
+    AffCols c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.a[i] = *reinterpret_cast<const float4*>(A + ((size_t)b * out_dim + ow + i) * 4);
+    c.bb = *reinterpret_cast<const float4*>(beff + (size_t)b * out_dim + ow);
+    return c;
+}
+// one row: the lane's four outputs (stored), max|.| over the lane's 16-lane group = 64 columns (returned in every lane of the group)
+__device__ __forceinline__ float aff_row(const AffCols& c, float qx, float qy, float qz, float len, bool on, int accumulate, float* __restrict__ hp) {
+    float4 v;
+    v.x = c.a[0].x * qx + c.a[0].y * qy + c.a[0].z * qz + c.a[0].w * len + c.bb.x;
+    v.y = c.a[1].x * qx + c.a[1].y * qy + c.a[1].z * qz + c.a[1].w * len + c.bb.y;
+    v.z = c.a[2].x * qx + c.a[2].y * qy + c.a[2].z * qz + c.a[2].w * len + c.bb.z;
+    v.w = c.a[3].x * qx + c.a[3].y * qy + c.a[3].z * qz + c.a[3].w * len + c.bb.w;
+    if (on) {
+        if (accumulate) { const float4 p = *reinterpret_cast<const float4*>(hp); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<float4*>(hp) = v;
+    } else v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    m = dpp_fmax_rm<0xB1, 0xF>(m);    // quad_perm [1,0,3,2]
+    m = dpp_fmax_rm<0x4E, 0xF>(m);    // quad_perm [2,3,0,1]
+    m = dpp_fmax_rm<0x141, 0xF>(m);   // row_half_mirror
+    m = dpp_fmax_rm<0x140, 0xF>(m);   // row_mirror
+    return m;
+}
 __global__ __launch_bounds__(256) void sdf_affine_kernel(const float* __restrict__ query, const float* __restrict__ s,
                                                          const float* __restrict__ t, const float* __restrict__ A,
                                                          const float* __restrict__ beff, int M, int out_dim, int ldh,
                                                          int accumulate, int rows_per_block, float* __restrict__ h,
                                                          float* __restrict__ rowmax) {
-    // rowmax (nullable) [rows][4 * gridDim.x]: max|h[row, this wave's 64 columns]| -- the operand range of the GEMM that reads h (gemm.hip, GemmAux)
-    const int rm_parts = 4 * gridDim.x, rm_part = 4 * blockIdx.x + (threadIdx.x >> 6);
-    const int b = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
+    // rowmax (nullable) [rows][4 * gridDim.x]: max|h[row, 64-column group]| -- the operand range of the GEMM that reads h (gemm.hip, GemmAux)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rm_parts = 4 * gridDim.x, rm_part = 4 * blockIdx.x + (lane >> 4);
+    const int b = blockIdx.y, o = blockIdx.x * 256 + lane * 4;
     const int r0 = blockIdx.z * rows_per_block;
-    const bool on = o < out_dim;
-    const int ow = on ? o : 0;
-    const float4 a = *reinterpret_cast<const float4*>(A + ((size_t)b * out_dim + ow) * 4);
-    const float bb = beff[(size_t)b * out_dim + ow];
+    const bool on = o < out_dim;      // (out_dim % 4 == 0: a lane's four columns are all inside or all outside)
+    const AffCols c = aff_load(A, beff, b, out_dim, on ? o : 0);
     const float sc = s[b], tx = t[b * 3], ty = t[b * 3 + 1], tz = t[b * 3 + 2];
     const int r1 = min(M, r0 + rows_per_block);
-    for (int r = r0; r < r1; ++r) {
-        const float* qp = query + ((size_t)b * M + r) * 3;
-        const float qx = (qp[0] - tx) / sc, qy = (qp[1] - ty) / sc, qz = (qp[2] - tz) / sc;
-        const float len = sqrtf(qx * qx + qy * qy + qz * qz);
-        float v = a.x * qx + a.y * qy + a.z * qz + a.w * len + bb;
-        if (on) {
-            float* hp = h + ((size_t)b * M + r) * ldh + o;
-            if (accumulate) v += *hp;
-            v = fmaxf(v, 0.f);
-            *hp = v;
-        } else v = 0.f;
-        if (rowmax) {
-            const float wm = wave_max_lane63(v);
-            if ((threadIdx.x & 63) == 63) rowmax[((size_t)b * M + r) * rm_parts + rm_part] = wm;
+    for (int rb = r0; rb < r1; rb += 64) {
+        const int rl = min(rb + lane, r1 - 1);
+        const float* qp = query + ((size_t)b * M + rl) * 3;
+        const float qxl = (qp[0] - tx) / sc, qyl = (qp[1] - ty) / sc, qzl = (qp[2] - tz) / sc;
+        const float lenl = sqrtf(qxl * qxl + qyl * qyl + qzl * qzl);
+        const int nr = min(64, r1 - rb);
+        for (int j = wave; j < nr; j += 4) {
+            const int r = rb + j;
+            const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qxl), j));
+            const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qyl), j));
+            const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qzl), j));
+            const float len = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lenl), j));
+            const float m = aff_row(c, qx, qy, qz, len, on, accumulate, h + ((size_t)b * M + r) * ldh + o);
+            if (rowmax && (lane & 15) == 15) rowmax[((size_t)b * M + r) * rm_parts + rm_part] = m;
         }
     }
 }
@@ -78,36 +112,36 @@ __global__ __launch_bounds__(256) void sdf_affine_rows_kernel(const float* __res
                                                               const float* __restrict__ A, const float* __restrict__ beff, long long R,
                                                               int out_dim, int ldh, int accumulate, int rows_per_block,
                                                               float* __restrict__ h, float* __restrict__ rowmax) {
-    const int rm_parts = 4 * gridDim.x, rm_part = 4 * blockIdx.x + (threadIdx.x >> 6);
-    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rm_parts = 4 * gridDim.x, rm_part = 4 * blockIdx.x + (lane >> 4);
+    const int o = blockIdx.x * 256 + lane * 4;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     const bool on = o < out_dim;
     const int ow = on ? o : 0;
     const long long r1 = min(R, r0 + rows_per_block);
     int bprev = -1;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    float bb = 0.f, sc = 1.f, tx = 0.f, ty = 0.f, tz = 0.f;
-    for (long long r = r0; r < r1; ++r) {
-        const int b = row_inst[r];
-        if (b != bprev) {   // rows of an instance are contiguous: reloaded a handful of times per block
-            a = *reinterpret_cast<const float4*>(A + ((size_t)b * out_dim + ow) * 4);
-            bb = beff[(size_t)b * out_dim + ow];
-            sc = s[b]; tx = t[b * 3]; ty = t[b * 3 + 1]; tz = t[b * 3 + 2];
-            bprev = b;
-        }
-        const float* qp = query + (size_t)r * 3;
-        const float qx = (qp[0] - tx) / sc, qy = (qp[1] - ty) / sc, qz = (qp[2] - tz) / sc;
-        const float len = sqrtf(qx * qx + qy * qy + qz * qz);
-        float v = a.x * qx + a.y * qy + a.z * qz + a.w * len + bb;
-        if (on) {
-            float* hp = h + (size_t)r * ldh + o;
-            if (accumulate) v += *hp;
-            v = fmaxf(v, 0.f);
-            *hp = v;
-        } else v = 0.f;
-        if (rowmax) {
-            const float wm = wave_max_lane63(v);
-            if ((threadIdx.x & 63) == 63) rowmax[(size_t)r * rm_parts + rm_part] = wm;
+    AffCols c;
+    for (long long rb = r0; rb < r1; rb += 64) {   // lane l normalises row rb + l, the row loop reads it back (see sdf_affine_kernel)
+        const long long rl = min(rb + lane, r1 - 1);
+        const int bl = row_inst[rl];
+        const float sc = s[bl], tx = t[bl * 3], ty = t[bl * 3 + 1], tz = t[bl * 3 + 2];
+        const float* qp = query + (size_t)rl * 3;
+        const float qxl = (qp[0] - tx) / sc, qyl = (qp[1] - ty) / sc, qzl = (qp[2] - tz) / sc;
+        const float lenl = sqrtf(qxl * qxl + qyl * qyl + qzl * qzl);
+        const int nr = (int)min((long long)64, r1 - rb);
+        for (int j = wave; j < nr; j += 4) {
+            const long long r = rb + j;
+            const int b = __builtin_amdgcn_readlane(bl, j);
+            if (b != bprev) {   // rows of an instance are contiguous: reloaded a handful of times per block
+                c = aff_load(A, beff, b, out_dim, ow);
+                bprev = b;
+            }
+            const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qxl), j));
+            const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qyl), j));
+            const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qzl), j));
+            const float len = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lenl), j));
+            const float m = aff_row(c, qx, qy, qz, len, on, accumulate, h + (size_t)r * ldh + o);
+            if (rowmax && (lane & 15) == 15) rowmax[(size_t)r * rm_parts + rm_part] = m;
         }
     }
 }
@@ -346,6 +380,7 @@ int sdf_prep_launch(const float* inv_t, const float* so3_t, const float* wlen, c
 int sdf_affine_launch(const float* query, const float* s, const float* t, const float* A, const float* beff, int B, int M,
                       int out_dim, int ldh, int accumulate, float* h, hipStream_t st, float* rowmax) {
     const int rpb = 64;
+    LS_REQUIRE(out_dim % 4 == 0 && ldh % 4 == 0, "sdf_affine: width %d / row stride %d must be multiples of 4", out_dim, ldh);
     // gridDim.y / .z are limited to 65535: say so instead of a generic launch failure (direct C-ABI callers; ops.sdf_decode chunks)
     LS_REQUIRE(B <= 65535 && cdiv(M, rpb) <= 65535, "sdf_decode: B=%d or M=%d too large for one call (B <= 65535, M <= %d): split the queries", B, M,
                65535 * rpb);
@@ -358,6 +393,7 @@ int sdf_affine_rowmax_parts(int out_dim) { return 4 * cdiv(out_dim, 256); }
 int sdf_affine_rows_launch(const float* query, const int32_t* row_inst, const float* s, const float* t, const float* A, const float* beff,
                            long long R, int out_dim, int ldh, int accumulate, float* h, hipStream_t st, float* rowmax) {
     const int rpb = 64;
+    LS_REQUIRE(out_dim % 4 == 0 && ldh % 4 == 0, "sdf_affine: width %d / row stride %d must be multiples of 4", out_dim, ldh);
     LS_REQUIRE(cdiv(R, rpb) <= 65535, "sdf_decode_rows: R=%lld rows too many for one call (<= %d): split the rows", R, 65535 * rpb);
     hipLaunchKernelGGL(sdf_affine_rows_kernel, dim3(cdiv(out_dim, 256), (unsigned)cdiv(R, rpb)), dim3(256), 0, st, query, row_inst, s, t, A,
                        beff, R, out_dim, ldh, accumulate, rpb, h, rowmax);
