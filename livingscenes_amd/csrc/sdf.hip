@@ -41,8 +41,7 @@ __global__ __launch_bounds__(256) void sdf_prep_kernel(const float* __restrict__
 // FOUR consecutive columns (one 16-byte store per row), wave w the rows w, w + 4, ... of the slab.
 // The normalised query (three IEEE divisions and a square root) is the same for every column: lane l computes it for row l of the slab and
 // the row loop reads it back with v_readlane.  (Round 2 recomputed it in all 256 threads for every row and stored one float per thread:
-// ~55 instructions per stored float, 581 us per 262 144-row chunk at width 768; once per row: 367 us; four columns per lane: see DESIGN
-// 11.10.)  Same formulas per element: results unchanged.
+// ~55 instructions per stored float, 581 us per 262 144-row chunk at width 768; once per row: 367 us; four columns per lane: 245 us.)  Same formulas per element: results unchanged.
 struct AffCols {   // one lane's four columns of the folded layer
     float4 a[4];
     float4 bb;
