@@ -26,6 +26,7 @@
 // product is unchanged.  Next-tile global loads are issued before the MFMA block (register double buffer).
 #include "ls_common.h"
 #include <string.h>
+#include <algorithm>
 
 namespace ls {
 
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 template <bool MASKED, bool WPL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_w2_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc,
-    int M, int N, int K, int relu, int ntiles_n, const float* __restrict__ mask, GemmAux aux) {
+    int M, int N, int K, int relu, int ntiles_n, int ntiles, const float* __restrict__ mask, GemmAux aux) {
     constexpr int TM = 256, TN = 256;
     constexpr int STG = 32 * 68;
     constexpr int PLANE = TM * 64;         // one f16 plane: 256 rows x 32 k
@@ -752,10 +753,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * BUF + (TM + TN) * 4 bytes
     float* rsc = reinterpret_cast<float*>(smem + 2 * BUF);        // inverse power-of-two scales: the tile's A rows, then its W rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = logical / ntiles_n, tn = logical % ntiles_n;
-    const int m0 = tm * TM, n0 = tn * TN;
     const int wm = wave >> 2, wn = wave & 3;
+    // a workgroup takes the tiles blockIdx.x, + gridDim.x, ... (default launch: one tile each; LS_GEMM_W2_PERSIST=1: one workgroup per CU);
+    // the workgroups resident on an XCD cover a contiguous range of tiles, tiles of one M block next to each other
+    for (int tile = xcd_remap(blockIdx.x, gridDim.x); tile < ntiles; tile += gridDim.x) {
+    const int tm = tile / ntiles_n, tn = tile % ntiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -944,6 +947,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         store_half_tile(stg, out, ldc, M, N, m0 + wm * 128 + i * 32, gn0, lane, full_tile, vec_ok, MASKED ? mask : nullptr,
                         4 * tn + wn < rm_parts ? aux.out_rowmax : nullptr, rm_parts, 4 * tn + wn);   // (a part without valid columns receives 0)
         __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();   // the staging area and rsc are rewritten by the next tile
     }
 }
 
@@ -1836,7 +1841,11 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
             LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-#define LS_W2(MK, PL) hipLaunchKernelGGL((gemm_w2_kernel<MK, PL>), dim3(wtm * wtn), dim3(512), lds, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, wtn, mask, aux)
+        // LS_GEMM_W2_PERSIST=1: one workgroup per CU walking the tiles (measured: 942 - 944 vs 950 - 956 us at the decoder shape, but 73 -> 79 us at
+        // 480 tiles, where the static assignment balances worse than the dispatcher) -- off by default
+        static const bool w2_persist = getenv("LS_GEMM_W2_PERSIST") && atoi(getenv("LS_GEMM_W2_PERSIST")) != 0;
+        const int w2_grid = w2_persist ? std::min(wtm * wtn, 256) : wtm * wtn;
+#define LS_W2(MK, PL) hipLaunchKernelGGL((gemm_w2_kernel<MK, PL>), dim3(w2_grid), dim3(512), lds, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, wtn, wtm * wtn, mask, aux)
         if (mask) { if (wpl) LS_W2(true, true); else LS_W2(true, false); }
         else { if (wpl) LS_W2(false, true); else LS_W2(false, false); }
 #undef LS_W2
