@@ -885,30 +885,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
             f16x8_t a[4][2], b[2][2];
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
+#if defined(LS_VAR_W2_NOLO_READ)   // dev timing variant: half of the LDS operand reads
+                if (pc == 1) { for (int j = 0; j < 2; ++j) b[j][1] = b[j][0]; for (int i = 0; i < 4; ++i) a[i][1] = a[i][0]; continue; }
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + offb[j] + ((q ^ xb[j]) << 4)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
             }
             // per accumulator and 16-k step: lo(a) hi(w), hi(a) hi(w), hi(a) lo(w) -- the order every unified-accumulator kernel uses
+#if !defined(LS_VAR_W2_NOX_MFMA)    // dev timing variant: a third of the MFMAs (the reads stay alive through the staging below)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i][1]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(b[j][1]));
+#endif
+#if !defined(LS_VAR_W2_NOSTAGE)    // dev timing variant: no split, no LDS stores
             if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); }
             else { stage_w(Bn, 0); stage_w(Bn, 1); }
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#if defined(LS_VAR_W2_NOSTAGE)
+            if (s2 == 0) gload_a(k0 + 64); else gload_b(k0 + 64);
+#elif defined(LS_VAR_W2_NOGLOAD)   // dev timing variant: no global loads in the loop
+            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); }
+            else { stage_w(Bn, 2); stage_w(Bn, 3); }
+#else
             if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
             else { stage_w(Bn, 2); stage_w(Bn, 3); gload_b(k0 + 64); }
+#endif
+#if !defined(LS_VAR_W2_NOX_MFMA)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+#endif
         }
+#if !defined(LS_VAR_W2_NOBARRIER)   // dev timing variant (racy)
         __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
+#endif
     }
 
     // (Not kept: s_setprio(1) around the MFMA groups: 930 -> 1 055 us.  The operand fragments as an explicit four-sub-phase software pipeline -- every LDS read batch one sub-phase ahead of its
