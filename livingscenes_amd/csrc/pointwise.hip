@@ -289,6 +289,41 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// R[x][o] = sum_c Wt[c][o] X[x][c]  (x < 3, o < n_out; Wt row stride ldw, X [3][Cd] in LDS) for the whole workgroup: the c range is split
+// over the four waves (a wave's lane l owns outputs l, l + 64, ...: coalesced weight rows, up to 16 independent fma chains of length
+// Cd / 4 instead of one of length Cd per thread -- the one-chain form was a load latency per term: 70 us for the whole tail), partial sums
+// through LDS (part [4][3][n_out]), combined in wave order.  Ends with a barrier: R is readable by every thread.
+__device__ __forceinline__ void tail_gemv3(const float* __restrict__ Wt, int ldw, int Cd, int n_out, const float* X, float* part, float* R) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cq = (Cd + 3) / 4, c0 = wave * cq, c1 = min(Cd, c0 + cq);
+    for (int ob = 0; ob < n_out; ob += 64 * 4) {      // four outputs per lane per pass
+        float a[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j][0] = a[j][1] = a[j][2] = 0.f;
+#pragma unroll 4   // sixteen weight loads in flight
+        for (int c = c0; c < c1; ++c) {
+            const float x0 = X[c], x1 = X[Cd + c], x2 = X[2 * Cd + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = ob + j * 64 + lane;
+                const float wv = o < n_out ? Wt[(size_t)c * ldw + o] : 0.f;
+                a[j][0] += wv * x0; a[j][1] += wv * x1; a[j][2] += wv * x2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = ob + j * 64 + lane;
+            if (o < n_out) { part[(wave * 3 + 0) * n_out + o] = a[j][0]; part[(wave * 3 + 1) * n_out + o] = a[j][1]; part[(wave * 3 + 2) * n_out + o] = a[j][2]; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * n_out; i += 256) {
+        const int x = i / n_out, o = i - x * n_out;
+        R[i] = (part[(0 * 3 + x) * n_out + o] + part[(1 * 3 + x) * n_out + o]) + (part[(2 * 3 + x) * n_out + o] + part[(3 * 3 + x) * n_out + o]);
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc, int ldc, int NP, int Cd, TailW w, float oms,
                                                    float scale_factor, int center_pred, int center_scale,
                                                    const float* __restrict__ centroid, const float* __restrict__ scale0,
@@ -298,6 +333,8 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     float* X = sm;                 // [3][Cd]
     float* kdir = X + 3 * Cd;      // [NP][3] normalised shared directions
     float* H = kdir + 3 * NP;      // [3][h]
+    float* part = H + 3 * (Cd / 2);  // [4][3][Cd] partial sums of tail_gemv3
+    float* R = part + 12 * Cd;       // [3][Cd] its result
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int h = Cd / 2;
@@ -311,6 +348,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     float ss = 0.f, sn = 0.f;
     for (int c = tid; c < Cd; c += 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 8   // 24 loads in flight (un-unrolled: one L2 round trip per point, ~30 us of the kernel's 70)
         for (int n = 0; n < NP; ++n) {
             const float* r = Tb + (size_t)n * 3 * ldc + c;
             float y0 = r[0], y1 = r[ldc], y2 = r[2 * ldc];
@@ -329,15 +367,12 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     const float invf = 1.0f / fmaxf(fro, 1e-12f);
     __syncthreads();
     // fc_inv
+    tail_gemv3(w.inv_t, Cd, Cd, Cd, X, part, R);
     float yi[4][3];
     float ssi = 0.f;
     int cnt = 0;
     for (int o = tid; o < Cd; o += 256, ++cnt) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int c = 0; c < Cd; ++c) {
-            const float wv = w.inv_t[(size_t)c * Cd + o];
-            a0 += wv * X[c]; a1 += wv * X[Cd + c]; a2 += wv * X[2 * Cd + c];
-        }
+        const float a0 = R[o], a1 = R[Cd + o], a2 = R[2 * Cd + o];
         if (cnt < 4) { yi[cnt][0] = a0; yi[cnt][1] = a1; yi[cnt][2] = a2; }
         ssi += a0 * a0 + a1 * a1 + a2 * a2;
     }
@@ -354,14 +389,10 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     // fc_center
     float ctr[3] = {0.f, 0.f, 0.f};
     if (center_pred) {
+        tail_gemv3(w.fc0_t, 2 * h, Cd, 2 * h, X, part, R);    // columns [0, h): fc0.lin, [h, 2h): fc0.dir * fc0.lin
         for (int o = tid; o < h; o += 256) {
-            float y0 = 0.f, y1 = 0.f, y2 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
-            for (int c = 0; c < Cd; ++c) {
-                const float wl = w.fc0_t[(size_t)c * 2 * h + o], wd = w.fc0_t[(size_t)c * 2 * h + h + o];
-                const float x0 = X[c], x1 = X[Cd + c], x2 = X[2 * Cd + c];
-                y0 += wl * x0; y1 += wl * x1; y2 += wl * x2;
-                k0 += wd * x0; k1 += wd * x1; k2 += wd * x2;
-            }
+            float y0 = R[o], y1 = R[2 * h + o], y2 = R[4 * h + o];
+            const float k0 = R[h + o], k1 = R[2 * h + h + o], k2 = R[4 * h + h + o];
             vn_act(y0, y1, y2, k0, k1, k2, oms);
             H[o] = y0; H[h + o] = y1; H[2 * h + o] = y2;
         }
@@ -448,7 +479,8 @@ int tail_launch(const float* Tc, int ldc, int B, int NP, int Cd, const float* in
                 const float* scale0, float* z_so3, float* z_inv, float* s_out, float* t_out, hipStream_t st) {
     LS_REQUIRE(Cd <= 1024 && Cd % 2 == 0, "tail: c_dim=%d unsupported (even, <= 1024)", Cd);
     TailW w{inv_t, fc0_t, misc};
-    const size_t smem = (size_t)(3 * Cd + 3 * NP + 3 * (Cd / 2)) * sizeof(float);
+    const size_t smem = (size_t)(3 * Cd + 3 * NP + 3 * (Cd / 2) + 15 * Cd) * sizeof(float);   // X | kdir | H | gemv partials + result
+    if (smem > 64 * 1024) LS_HIP_CHECK(hipFuncSetAttribute((const void*)tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));   // c_dim > ~800
     hipLaunchKernelGGL(tail_kernel, dim3(B), dim3(256), smem, st, Tc, ldc, NP, Cd, w, 1.0f - neg_slope, scale_factor,
                        center_pred, center_scale, centroid, scale0, z_so3, z_inv, s_out, t_out);
     LS_LAUNCH_CHECK();
