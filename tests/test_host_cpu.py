@@ -65,6 +65,12 @@ def test_argument_validation_without_device(lib):
     assert lib.ls_cosine_scores_f32(P(16), P(16), 32, 32, 256, P(16), None, 0, None) == -3
     assert lib.ls_fps_f32(P(16), None, 1, 100000, 8, 0, P(16), None, None, 0, None) == -1
     assert b"too large" in lib.ls_last_error()
+    # pre-split weight planes: only where a kernel reads them (K >= 512, K % 32 == 0), the caller's buffer is checked, planes need their maxima
+    assert lib.ls_gemm_w_planes_bytes(768, 768) == 4 * 768 * 768 and lib.ls_gemm_w_planes_bytes(768, 256) == 0 and lib.ls_gemm_w_planes_bytes(64, 520) == 0
+    assert lib.ls_gemm_presplit_w_f32(P(16), 768, 768, 768, P(16), P(16), 4 * 768 * 768 - 1, None) == -3
+    assert lib.ls_gemm_presplit_w_f32(P(16), 256, 64, 256, P(16), P(16), 1 << 20, None) == -1
+    assert lib.ls_gemm_f32_planes(P(16), 768, P(16), 768, P(16), None, P(16), 768, 4, 768, 768, 0, None, 0, None, None, None) == -1
+    assert b"w_rowmax" in lib.ls_last_error()
 
 
 def test_module_mirrors_keep_reference_state_dict_keys():
