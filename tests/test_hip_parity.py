@@ -504,21 +504,33 @@ def test_sdf_decode_vs_oracle_small_and_chunked():
 
 
 def test_equivariance_properties():
-    """The reference's own self-check (vec_dgcnn_atten.py:276-320) as assertions: z_so3 rotates with the input,
-    z_inv is invariant, scale is linear in s."""
+    """The reference's own self-check (vec_dgcnn_atten.py:276-320) as assertions: z_so3 rotates with the input, z_inv is invariant, scale
+    is linear in s.  The bar is 1e-4 whenever the rotated cloud produces the same graphs (k-NN of every layer, FPS of every level) -- the
+    measured error is then 5e-6 .. 1.5e-5 (scripts/diag/equivariance_probe.py).  A rotation changes the rounding of the coordinates, so a
+    near-tie may resolve differently and, with random weights, cascade through the layers (seed 23 of the probe: 5 % of the layer-6
+    neighbours, codes 7e-2 apart -- a property of the network, the reference behaves the same): those cases keep the loose 1e-3 and only
+    when at most 1 % of any layer's neighbour entries moved.  At least one of the clouds here must take the tight branch."""
     cfg = synth.default_encoder_cfg()
     w = synth.make_encoder_weights(cfg, 0)
     m = _hip_model(cfg, w)
-    x = synth.make_instances(2, 1024, seed=21, rigid=False)
-    x = x - x.mean(-1, keepdim=True)
-    rng = np.random.default_rng(0)
-    R = torch.from_numpy(np.stack([synth._rand_rot(rng) for _ in range(2)]).astype(np.float32))
-    sc = torch.tensor([0.7, 1.4])
-    xa = torch.einsum("bij,bjn->bin", R, x * sc[:, None, None])
-    z0, i0, s0, _ = m.encode(x.to(_dev()), pre_normalised=True)
-    z1, i1, s1, _ = m.encode(xa.to(_dev()), pre_normalised=True)
-    zr = torch.einsum("bij,bcj->bci", R.to(_dev()), z0)
-    assert relerr(z1, zr) < 1e-3 and relerr(i1, i0) < 1e-3 and relerr(s1, s0 * sc.to(_dev())) < 1e-3
+    tight = 0
+    for seed in (21, 22, 25):
+        x = synth.make_instances(2, 1024, seed=seed, rigid=False)
+        x = x - x.mean(-1, keepdim=True)
+        rng = np.random.default_rng(seed)
+        R = torch.from_numpy(np.stack([synth._rand_rot(rng) for _ in range(2)]).astype(np.float32))
+        sc = torch.tensor([0.7, 1.4])
+        xa = torch.einsum("bij,bjn->bin", R, x * sc[:, None, None])
+        z0, i0, s0, _, k0, f0 = m.encode(x.to(_dev()), pre_normalised=True, trace=True)
+        z1, i1, s1, _, k1, f1 = m.encode(xa.to(_dev()), pre_normalised=True, trace=True)
+        zr = torch.einsum("bij,bcj->bci", R.to(_dev()), z0)
+        same = all(torch.equal(a, b) for a, b in zip(k0, k1)) and all(torch.equal(a, b) for a, b in zip(f0, f1))
+        if not same:
+            assert min(float((a == b).float().mean()) for a, b in zip(k0, k1)) > 0.99, seed
+        tol = 1e-4 if same else 1e-3
+        tight += same
+        assert relerr(z1, zr) < tol and relerr(i1, i0) < tol and relerr(s1, s0 * sc.to(_dev())) < tol, (seed, same)
+    assert tight >= 1
 
 
 # ------------------------------------------------------------------------------------------------ matcher / Kabsch / ICP
