@@ -91,8 +91,8 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     if kind == "knn":
         D = 3 * Cin
         return (B * ((Nd + Ns) * D * f4 + Nd * 16 * 4), 3.0 * B * Nd * Ns * D, FP32_PEAK_TFLOPS,
-                "direct-difference-EQUIVALENT fp32 flops (3 per pair and dimension): the kernels execute fewer -- a bf16-MFMA safe filter "
-                "over all pairs plus exact canonical distances on the ~40 survivors per query")
+                "direct-difference-EQUIVALENT fp32 flops (3 per pair and dimension): the kernels execute fewer -- an f16-MFMA safe filter "
+                "over all pairs plus exact canonical distances on the hints and the few survivors (~25 pairs per query)")
     if kind == "gemm_edge":
         return (B * Ns * 3 * Cin * f4 + table_floats * f4 + (pc if fused else nc) * Cin * f4, mm_mult * 2.0 * table_floats * Cin, mm_peak, mm_what)
     if kind in ("edge_attn", "edge_pool"):
@@ -357,7 +357,7 @@ def main():
         dom = max((q for q in prof if q["kind"] == dom_kind), key=lambda q: q["total_ms"])
         roof = roofline_entry(dom["kind"], dom["layer"], dom["total_ms"] / dom["launches"] * 1e-3, ecfg, B, N, bf16x3)
         if dom["kind"] == "knn":
-            roof["note"] = ("one k-NN graph build = the launch sequence of that layer (bf16 image incl. centre / [class-winner sweep] / seed incl. hint selection / sweep / finish: 4 - 5 launches); "
+            roof["note"] = ("one k-NN graph build = the launch sequence of that layer (seeded layers 1 / 2: f16 image incl. centre, seed, sweep, finish = 4 - 5 launches; un-seeded layers 3 / 4: image, sweep, finish = 3); "
                             "bound by fp32 VALU issue on the direct-difference-equivalent count -- see `basis`")
         roof["timing"] = f"hipEvent pair per launch on the launching stream, separate profiled pass of {prof_steps} steps (one step in flight)"
         roof["share_of_device_time"] = dom["total_ms"] / max(tot, 1e-9)
@@ -372,6 +372,9 @@ def main():
                 continue
             e = max(cands, key=lambda p: p["total_ms"])
             extra.append(roofline_entry(kind, e["layer"], e["total_ms"] / e["launches"] * 1e-3, ecfg, B, N, bf16x3))
+        for e in sorted((p for p in prof if p["kind"] == "edge_attn" and 2 <= p["layer"] <= 4), key=lambda p: p["layer"]):   # every fused-gather layer
+            if all(x["kernel"] != f"edge_attn[layer {e['layer']}]" for x in extra):
+                extra.append(roofline_entry("edge_attn", e["layer"], e["total_ms"] / e["launches"] * 1e-3, ecfg, B, N, bf16x3))
         if cands := [p for p in prof if p["kind"] == "gemm_edge"]:   # and the most matrix-core-heavy table GEMM (largest K)
             e = max(cands, key=lambda p: p["layer"])
             if all(x["kernel"] != f"gemm_edge[layer {e['layer']}]" for x in extra):
