@@ -30,11 +30,11 @@ import time
 # HIP runtime initialises, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-import torch  # noqa: E402
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+
+from livingscenes_amd import launch  # noqa: E402  (no torch import: `--gpus N` re-executes under the launcher before HIP initialises)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 FP32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32 MFMA peak
@@ -181,12 +181,15 @@ def main():
         # 20 -> 42.8 - 43.0k)
         args.inflight = 12 if args.steps >= 48 else 8
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --gpus N is the number of RANKS (one process per GPU).  Started plainly with N > 1 this re-executes itself under
+    # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (does not return); started by a launcher it
+    # insists on WORLD_SIZE == N -- a `--gpus 8` command can never silently measure one GPU.
+    world, rank, local_rank = launch.ensure_ranks(args.gpus, __file__, sys.argv[1:])
+    global torch
+    import torch
     # LS_BENCH_FORCE_DIST=1: run the collective code path (RCCL init, weight broadcast, barriers, all-reduce / all-gather) even with
     # ONE rank -- the only way to exercise the "nccl" backend on the single-GPU test box
     multi = world > 1 or bool(os.environ.get("LS_BENCH_FORCE_DIST"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the hot path)")
     # LS_BENCH_BACKEND=gloo: dry run of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices; the
@@ -194,6 +197,9 @@ def main():
     backend = os.environ.get("LS_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"--gpus {args.gpus}: rank {rank} needs device {local_rank} but this node exposes {torch.cuda.device_count()} "
+                         f"(RCCL wants one GPU per rank; LS_BENCH_BACKEND=gloo is the shared-device dry run)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -288,7 +294,7 @@ def main():
     step_stats = {"inter_completion_ms_min": round(gaps[0], 4), "inter_completion_ms_median": round(gaps[len(gaps) // 2], 4),
                   "inter_completion_ms_p90": round(gaps[int(0.9 * (len(gaps) - 1))], 4), "inter_completion_ms_max": round(gaps[-1], 4),
                   "last_step_done_ms": round(done_ms[-1], 3)}
-    my = torch.tensor([dt, dt_host], device=dev, dtype=torch.float64)
+    my = torch.tensor([dt, dt_host, float(torch.cuda.current_device()), float(B * args.steps)], device=dev, dtype=torch.float64)
     dt_t = my[:1].clone()
     per_rank = None
     if multi:
@@ -296,7 +302,7 @@ def main():
         mine = my if backend == "nccl" else my.cpu()     # gloo gathers through host memory only
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "ms_per_step": round(float(v[0]) / args.steps * 1e3, 4),
+        per_rank = [{"rank": r, "device": int(v[2]), "objects": int(v[3]), "ms_per_step": round(float(v[0]) / args.steps * 1e3, 4),
                      "host_enqueue_ms_per_step": round(float(v[1]) / args.steps * 1e3, 4)} for r, v in enumerate(allr)]
     dt = float(dt_t.item())
 
@@ -430,6 +436,11 @@ def main():
             "value": total_objects / dt,
             "unit": "object-instances/s",
             "n_gpus": world,
+            "ranks": world,
+            "collective_backend": (("rccl" if backend == "nccl" else backend + " (shared-device dry run: NOT a measurement)") if multi else None),
+            "rccl_ranks": world if (multi and backend == "nccl") else (1 if not multi else 0),
+            "devices": [p_["device"] for p_ in per_rank] if per_rank else [torch.cuda.current_device()],
+            "device_name": torch.cuda.get_device_name(dev),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

@@ -1,7 +1,7 @@
 """BASELINE.json configs[3] and configs[4] with the instances SHARDED over the GPUs of one node (livingscenes_amd/sharding.py,
 lib_more.more_solver.solve_end2end_batch(sharded=True)), synthetic data, released widths:
 
-    python scripts/configs_sharded.py [--scenes 16] [--optim] [--dense-instances 256]                      # 1 GPU
+    python scripts/configs_sharded.py [--gpus N] [--scenes 16] [--optim] [--dense-instances 256]           # N ranks, one per GPU (self-launching: livingscenes_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P scripts/configs_sharded.py ...
 
   configs[3]  3RScan-style end to end (eval_3rscan.py:337-463): 16 scenes x (reference + 2 rescans) x 8-24 instances of 1 024 .. 60 000 raw
@@ -15,13 +15,10 @@ Timing: barrier + device sync on both sides, MAX over ranks; rank 0 prints one J
 import argparse, json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np, torch
-import torch.distributed as dist
-from livingscenes_amd import sharding, synth
-from livingscenes_amd.lib_more.more_solver import More_Solver, solve_end2end_batch
-from livingscenes_amd.model_utils import Shape_Prior
+from livingscenes_amd import launch
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int, default=0, help="ranks (one per GPU); 0 = whatever the launcher started (1 when started plainly)")
 ap.add_argument("--scenes", type=int, default=16)
 ap.add_argument("--optim", action="store_true", help="registration.optim: true (the 400-step refinement of every matched pair)")
 ap.add_argument("--optim-steps", type=int, default=400)
@@ -30,9 +27,13 @@ ap.add_argument("--dense-instances", type=int, default=256)
 ap.add_argument("--skip-dense", action="store_true")
 ap.add_argument("--skip-scenes", action="store_true")
 args = ap.parse_args()
-world = int(os.environ.get("WORLD_SIZE", "1"))
-rank = int(os.environ.get("RANK", "0"))
-local = int(os.environ.get("LOCAL_RANK", "0"))
+# --gpus N started plainly re-executes under torch.distributed.run with N ranks; under a launcher WORLD_SIZE must equal N
+world, rank, local = launch.ensure_ranks(args.gpus or int(os.environ.get("WORLD_SIZE", "1")), __file__, sys.argv[1:])
+import numpy as np, torch
+import torch.distributed as dist
+from livingscenes_amd import sharding, synth
+from livingscenes_amd.lib_more.more_solver import More_Solver, solve_end2end_batch
+from livingscenes_amd.model_utils import Shape_Prior
 multi = world > 1
 torch.cuda.set_device(local if torch.cuda.device_count() > local else 0)
 dev = torch.device("cuda", torch.cuda.current_device())

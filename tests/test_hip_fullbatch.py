@@ -170,3 +170,57 @@ def test_fused_global_conv_matches_the_two_launch_path():
         a, b = np.load(f"/tmp/_ls_glob_1_{layer}_{B}_{N}.npy"), np.load(f"/tmp/_ls_glob_0_{layer}_{B}_{N}.npy")
         assert np.isfinite(a).all()
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), (layer, B, N, np.abs(a - b).max())
+
+
+def _run_json(cmd, env, timeout=900):
+    import json
+    import subprocess
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, p.stdout[-2000:]
+    assert p.stdout.rstrip().endswith(lines[-1]), "the JSON line must be the last thing on stdout"
+    return [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_2_runs_two_ranks():
+    """`python bench.py --gpus 2` (the driver's command form) must START two ranks -- round 3's bench parsed --gpus and never used it.
+    On the one-GPU test box the two ranks share cuda:0 and rendezvous over gloo (LS_BENCH_BACKEND=gloo: a logic check of the N > 1 path,
+    not a measurement): n_gpus == 2, one per_rank row per rank, value == 2 ranks x 64 instances x steps / the max-over-ranks time, the
+    handles of every rank bit-identical, and the line says it was a dry run."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    (line,) = _run_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-profile",
+                         "--cpu-instances", "0", "--no-fma-variant", "--inflight", "2"], env)
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["steps"] == 4
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["objects"] == 64 * 4 for r in line["per_rank"])
+    assert line["devices"] == [0, 0] and "dry run" in line["collective_backend"] and line["rccl_ranks"] == 0
+    assert abs(line["value"] - 2 * 64 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+    assert line["ms_per_step"] >= max(r["ms_per_step"] for r in line["per_rank"]) - 1e-3      # MAX over ranks, never the mean
+    assert line["check"]["handles_bit_identical"].startswith("True") and line["check"]["rotations_proper"]
+    # one rank, RCCL initialised (the "nccl" backend with a single rank: the only RCCL leg a one-GPU box can run)
+    env1 = dict(env, LS_BENCH_FORCE_DIST="1")
+    env1.pop("LS_BENCH_BACKEND")
+    (one,) = _run_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-profile",
+                        "--cpu-instances", "0", "--no-fma-variant", "--inflight", "2"], env1)
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1 and one["collective_backend"] == "rccl" and len(one["per_rank"]) == 1
+
+
+def test_configs_sharded_gpus_2_runs_two_ranks():
+    """scripts/configs_sharded.py --gpus 2: the same self-launch for configs[3] / [4]; two gloo ranks on the one GPU reproduce the
+    single-process counts (registrations, meshes, dense instances)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--scenes", "1", "--dense-instances", "2", "--no-mesh"]
+    two = _run_json([sys.executable, os.path.join(root, "scripts", "configs_sharded.py"), "--gpus", "2"] + args, env)
+    one = _run_json([sys.executable, os.path.join(root, "scripts", "configs_sharded.py")] + args, env)
+    assert [d["n_gpus"] for d in two] == [2, 2] and [d["n_gpus"] for d in one] == [1, 1]
+    for a, b in zip(two, one):
+        for k in ("scene_pairs", "instance_encodes", "registrations", "meshes", "instances"):
+            assert a.get(k) == b.get(k), (k, a, b)

@@ -564,3 +564,39 @@ def test_packed_fp32_build_guard_fires_without_the_flag(tmp_path):
     shutil.copy(os.path.join(B.LIBDIR, "obj", "pointwise.o"), tmp_path / "pointwise.o")
     with pytest.raises(RuntimeError, match="packed fp32"):
         B.check_packed_fp32(str(tmp_path))
+
+
+def test_launcher_refuses_a_world_size_other_than_gpus(monkeypatch):
+    """`--gpus N` is the number of ranks (livingscenes_amd/launch.py): under a launcher the world size must BE N, started
+    plainly with N = 1 nothing is launched, and a nonsensical N is refused."""
+    from livingscenes_amd import launch
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert launch.ensure_ranks(1, "x.py", []) == (1, 0, 0)
+    with pytest.raises(SystemExit):
+        launch.ensure_ranks(0, "x.py", [])
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert launch.ensure_ranks(4, "x.py", []) == (4, 3, 3)
+    with pytest.raises(SystemExit) as e:
+        launch.ensure_ranks(8, "x.py", [])
+    assert "WORLD_SIZE=4" in str(e.value)
+    with pytest.raises(SystemExit):
+        launch.ensure_ranks(1, "x.py", [])
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` started plainly re-executes under torch.distributed.run with two ranks (there is no HIP device here:
+    BOTH ranks must reach the device check and say so -- a one-rank run would print it once), and a launcher world of another size is
+    refused before anything is timed."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("device present: tests/test_hip_fullbatch.py::test_bench_gpus_2_runs_two_ranks covers the real run")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0
+    assert (p.stdout + p.stderr).count("bench.py needs a HIP device") == 2, (p.stdout + p.stderr)[-2000:]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
