@@ -185,6 +185,8 @@ def main():
     # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (does not return); started by a launcher it
     # insists on WORLD_SIZE == N -- a `--gpus 8` command can never silently measure one GPU.
     world, rank, local_rank = launch.ensure_ranks(args.gpus, __file__, sys.argv[1:])
+    if world > 1:   # one line per rank on stderr, before anything can fail: the launcher's log shows how many ranks really started
+        print(f"bench.py: rank {rank} of {world} started (local_rank {local_rank}, pid {os.getpid()})", file=sys.stderr, flush=True)
     global torch
     import torch
     # LS_BENCH_FORCE_DIST=1: run the collective code path (RCCL init, weight broadcast, barriers, all-reduce / all-gather) even with

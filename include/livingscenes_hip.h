@@ -239,6 +239,9 @@ void ls_model_destroy(ls_model_t* m);
                                      (workspace, B, N, flags, stream); needs a non-NULL stream; profiled / traced calls always enqueue directly).
                                      Off by default: on ROCm 7.2 the replay measured slower than direct enqueue (22.2k vs 29.6k obj/s, one step in flight) */
 int ls_model_set_option(ls_model_t* m, int option, int value);
+/* the handle's CURRENT value of an option (what ls_model_create read from the environment, or the last ls_model_set_option): the only
+ * way a caller can change an option temporarily and put back exactly what was there */
+int ls_model_get_option(const ls_model_t* m, int option, int* value);
 
 /* ------------------------------------------------------------------------------------------------
  * Composite hot path
@@ -367,12 +370,14 @@ typedef struct ls_adam_group {
     float* m;
     float* v;
     long long n;
-    float lr;
+    double lr;
 } ls_adam_group;
 int ls_mse_f32(const float* sdf, int P, int N, float* loss, float* grad_sdf, float* min_loss, int32_t* improved, void* stream);
-int ls_adam_step_f32(const ls_adam_group* groups, int count, float beta1, float beta2, float adam_eps, int step, void* stream);
-int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float* loss, int P, int N, float lr, float beta1, float beta2,
-                         float adam_eps, int step, float stop_angle, float* g, float* m1, float* m2, float* min_loss, float* best_g,
+/* betas, eps and learning rates are DOUBLES (torch.optim.Adam's Python floats): 1 - beta, 1 - beta^t, lr / (1 - beta1^t), sqrt(1 - beta2^t) are formed
+ * in double on the host and rounded to fp32 once, as torch hands them to its kernels */
+int ls_adam_step_f32(const ls_adam_group* groups, int count, double beta1, double beta2, double adam_eps, int step, void* stream);
+int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float* loss, int P, int N, double lr, double beta1, double beta2,
+                         double adam_eps, int step, float stop_angle, float* g, float* m1, float* m2, float* min_loss, float* best_g,
                          const float* init_R, int32_t* active, float* query, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

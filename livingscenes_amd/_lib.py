@@ -68,6 +68,7 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _U = ctypes.c_uint
 _F = ctypes.c_float
+_D = ctypes.c_double
 _SZ = ctypes.c_size_t
 
 # name -> (restype, argtypes); every symbol include/livingscenes_hip.h declares
@@ -80,7 +81,7 @@ class SoftminProblem(ctypes.Structure):
 class AdamGroup(ctypes.Structure):
     """ls_adam_group (include/livingscenes_hip.h)."""
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("n", ctypes.c_longlong),
-                ("lr", ctypes.c_float)]
+                ("lr", ctypes.c_double)]
 
 
 SIGNATURES = {
@@ -111,13 +112,14 @@ SIGNATURES = {
     "ls_model_create": (_I, [ctypes.POINTER(ModelDesc), _P, ctypes.POINTER(_P)]),
     "ls_model_destroy": (None, [_P]),
     "ls_model_set_option": (_I, [_P, _I, _I]),
+    "ls_model_get_option": (_I, [_P, _I, ctypes.POINTER(ctypes.c_int)]),
     "ls_se3_transform_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "ls_smooth_l1_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "ls_sinkhorn_softmin_batched_f32": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "ls_sinkhorn_softmin_multi_f32": (_I, [_P, _I, _P, _I, _I, _P]),
     "ls_mse_f32": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
-    "ls_adam_step_f32": (_I, [ctypes.POINTER(AdamGroup), _I, _F, _F, _F, _I, _P]),
-    "ls_se3_adam_step_f32": (_I, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ls_adam_step_f32": (_I, [ctypes.POINTER(AdamGroup), _I, _D, _D, _D, _I, _P]),
+    "ls_se3_adam_step_f32": (_I, [_P, _P, _P, _I, _I, _D, _D, _D, _D, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ls_encoder_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ls_encode": (_I, [_P, _P, _I, _I, _I, _U, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "ls_vn_edgeconv_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I, _I]),

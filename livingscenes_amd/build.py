@@ -30,7 +30,20 @@ EXTRA_FLAGS = {"pointwise.hip": ["-fno-vectorize"]}   # per-file additions: {"fi
 # kernels that spell packed math on purpose (explicit 2-vectors in the f16 split of the fused attention kernel's staging phase and of
 # the weight pre-split), covered by the bit-identity tests with 12 handles in flight (tests/test_hip_fullbatch.py).
 PACKED_FP32_GUARD = {"edge.hip": ["edge_attn_fq_kernel", "edge_presplit_wq_kernel"], "pointwise.hip": []}
-LLVM_BIN = os.environ.get("LS_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def llvm_bin():
+    """Directory of llvm-objdump: LS_LLVM_BIN, else the toolchain the resolved hipcc belongs to (<rocm>/bin/hipcc -> <rocm>/lib/llvm/bin), else
+    /opt/rocm.  A relocated or versioned ROCm (HIPCC=/opt/rocm-x.y/bin/hipcc) is disassembled with ITS objdump."""
+    if os.environ.get("LS_LLVM_BIN"):
+        return os.environ["LS_LLVM_BIN"]
+    import shutil
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hipcc = shutil.which(hipcc) or hipcc
+    cand = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin")
+    return cand if os.path.exists(os.path.join(cand, "llvm-objdump")) else "/opt/rocm/lib/llvm/bin"
+
+
 # host-only translation units (no device code): g++, strict fp (no contraction: simplify.cpp reproduces the reference's doubles bit for bit)
 HOST_SOURCES = ["simplify.cpp"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off"]
@@ -53,12 +66,16 @@ def packed_fp32_report(obj):
     try:
         local = os.path.join(tmp, os.path.basename(obj))
         shutil.copy(obj, local)
-        subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", local], cwd=tmp, check=True, stdout=subprocess.DEVNULL,
+        objdump = os.path.join(llvm_bin(), "llvm-objdump")
+        if not os.path.exists(objdump):
+            raise RuntimeError(f"packed-fp32 guard: {objdump} not found (set LS_LLVM_BIN to the directory of the llvm-objdump that belongs to "
+                               f"your hipcc; the guard is part of the build -- DESIGN.md, determinism)")
+        subprocess.run([objdump, "--offloading", local], cwd=tmp, check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
         dev = [f for f in os.listdir(tmp) if "amdgcn" in f]
         if not dev:
             raise RuntimeError(f"packed-fp32 guard: no gfx950 bundle found in {obj}")
-        dis = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", os.path.join(tmp, dev[0])], check=True, capture_output=True,
+        dis = subprocess.run([objdump, "-d", os.path.join(tmp, dev[0])], check=True, capture_output=True,
                              text=True).stdout
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

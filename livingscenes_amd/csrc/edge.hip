@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     __shared__ float l_score[EK][256];
     __shared__ __attribute__((aligned(16))) float slab[ROWS * SLD];
     __shared__ __attribute__((aligned(16))) char a_pl[2][MT * 32 * ASTR];   // the workgroup's feature rows as (hi, lo) f16 planes
-    __shared__ float a_inv[MT * 32];                                        // inverse power-of-two scale of each staged row
+    __shared__ int a_inv[MT * 32];                                          // inverse power-of-two scale of each staged row
     const float* __restrict__ winv = reinterpret_cast<const float*>(Wp + (size_t)(6 * Co / 32) * KS * 128);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / LPP, ll = lane % LPP;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
             if constexpr (CIN == 64) am = edpp_fmax<0x140>(am);
             float sc, inv;
             epow2_scale(am, sc, inv);
-            if (kq == 0) a_inv[r] = inv;
+            if (kq == 0) a_inv[r] = (__float_as_int(inv) >> 23) - 127;    // exponent of the exact power of two (gemm.hip: pow2_e / scale_pow2)
             esplit_pair(ef2_t{v.x * sc, v.y * sc}, h.x, l.x);
             esplit_pair(ef2_t{v.z * sc, v.w * sc}, h.y, l.y);
         }
@@ -575,11 +575,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
             // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); rows past the workgroup's points: dropped
             const int row0 = 32 * mt + 4 * (lane >> 5);
             float* sp = slab + row0 * SLD + 32 * nt + (lane & 31);
-            const float cs = winv[cb + 32 * nt + (lane & 31)];
+            const int ce = (__float_as_int(winv[cb + 32 * nt + (lane & 31)]) >> 23) - 127;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
-                if (row0 + dr < ROWS) sp[dr * SLD] = acc[r] * (a_inv[row0 + dr] * cs);
+                if (row0 + dr < ROWS) sp[dr * SLD] = __builtin_ldexpf(acc[r], a_inv[row0 + dr] + ce);   // acc * s_a^-1 * s_w^-1, exponents added as integers (as gemm.hip)
             }
         }
     };

@@ -24,6 +24,7 @@
 // permuted inside a BK block (lanes 0-31 take k = 8h+s, lanes 32-63 take k = 8h+4+s at MFMA step (h,s)) so
 // that every lane fetches its four k-values with ONE ds_read_b128; A and B use the same permutation, so the
 // product is unchanged.  Next-tile global loads are issued before the MFMA block (register double buffer).
+#include <atomic>
 #include "ls_common.h"
 #include <string.h>
 #include <algorithm>
@@ -101,6 +102,12 @@ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
     s = __uint_as_float((268u - be) << 23);
     inv = __uint_as_float((be - 14u) << 23);
 }
+// The epilogue's acc * s_a^-1 * s_w^-1: both inverse scales are exact NORMAL powers of two (pow2_scale), so their exponents are kept as
+// integers (pow2_e), added, and applied by ONE v_ldexp_f32 -- exact wherever fp32 holds the result, rounded once into the subnormals, never
+// an intermediate overflow.  (Until round 4 the two floats were multiplied first: that product flushes to 0 below 2^-149 -- two operand rows
+// at ~1e-19 each -- although acc times it can be a normal number.)  In range the result is bit-identical to the multiply.
+__device__ __forceinline__ int pow2_e(float p) { return (__float_as_int(p) >> 23) - 127; }
+__device__ __forceinline__ float scale_pow2(float acc, int e) { return __builtin_ldexpf(acc, e); }
 template <int CTRL>
 __device__ __forceinline__ float dpp_fmax(float v) {
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
@@ -111,12 +118,6 @@ __device__ __forceinline__ float max16(float v) { return dpp_fmax<0x140>(max8(v)
 // split of s * v (s: the row's power of two); the multiply is spelled as packed fp32 (v_pk_mul_f32: the file is built without SLP vectorisation)
 template <int WHICH>   // 0 = A operand, 1 = W operand (dev timing variants below)
 __device__ __forceinline__ void split2_f16s(const float4& v, float s, uint2& h, uint2& l) {
-#if defined(LS_VAR_NO_AMUL)
-    if constexpr (WHICH == 0) { split2_f16(v, h, l); return; }
-#endif
-#if defined(LS_VAR_NO_WMUL)
-    if constexpr (WHICH == 1) { split2_f16(v, h, l); return; }
-#endif
     const f32x2_t sv = {s, s};
     split2_f16_pair(f32x2_t{v.x, v.y} * sv, h.x, l.x);
     split2_f16_pair(f32x2_t{v.z, v.w} * sv, h.y, l.y);
@@ -134,9 +135,6 @@ constexpr int GM = 128, GN = 128, GK = 16, GLD = 20;
 __device__ __forceinline__ void store_half_tile(const float* stg, float* __restrict__ out, int ldc, int M, int N, int gm0, int gn0,
                                                 int lane, bool full_tile, bool vec_ok, const float* __restrict__ mask,
                                                 float* __restrict__ rowmax = nullptr, int rm_parts = 0, int rm_part = 0) {
-#if defined(LS_VAR_NO_EMIT)
-    rowmax = nullptr;
-#endif
     if (full_tile) {
         float4 v[8];
 #pragma unroll
@@ -197,9 +195,6 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
 
 // Optional row gather (down-sampled encoder layers): output row m = (b*gNd + n)*3 + x reads A row
 // (b*gNs + a_rows[b*gNd + n])*3 + x, i.e. the GEMM runs only on the FPS-selected points of each instance.
-#ifdef LS_GEMM_PROF
-__device__ unsigned long long ls_gemm_prof[8];
-#endif
 // PIECES = 2 (opt-in, LS_SDF_BF16X2): a = a1 + a2 only, three MFMAs per 16 k (a1b1 + a1b2 + a2b1); products carry a 2^-16
 // relative error instead of 2^-24 -- a decode mode for throughput, never the default.
 template <bool SPLIT, int PIECES = 3>
@@ -243,8 +238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     float sa[NST], sw[NST];   // f16 split: power-of-two scale of this thread's staged A / W rows (GemmAux)
 #pragma unroll
     for (int h = 0; h < NST; ++h) { sa[h] = 1.f; sw[h] = 1.f; }
-    __shared__ float rsc[H2 ? GM + GN : 1];   // inverse scales of the tile's 128 A rows, then of its 128 W rows
-    if constexpr (H2) { if (aux.noscale) rsc[tid] = 1.f; }   // (256 threads = GM + GN entries; otherwise the range block below writes every entry)
+    __shared__ int rsc[H2 ? GM + GN : 1];   // inverse scales of the tile's 128 A rows, then of its 128 W rows
+    if constexpr (H2) { if (aux.noscale) rsc[tid] = 0; }   // (256 threads = GM + GN entries; otherwise the range block below writes every entry)
     long long arow[NST];  // source row of A for this thread's staged rows (-1 = out of range)
 #pragma unroll
     for (int h = 0; h < NST; ++h) {
@@ -301,12 +296,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
     };
 
-#ifdef LS_GEMM_PROF   // dev instrumentation (scripts/ubench/gemm_phases.hip): s_memtime per phase, every wave, summed
-#define LS_PH(i) if ((blockIdx.x & 127) == 5) { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&ls_gemm_prof[i], (unsigned long long)(t_ - tph)); tph = t_; }   /* one workgroup in 128 */
-    long long tph = __builtin_readcyclecounter();
-#else
-#define LS_PH(i)
-#endif
     if constexpr (H2) {
         // operand range (see GemmAux): per-row powers of two from a pre-pass over this tile's rows, or from the caller's row maxima
         if (!aux.noscale) {
@@ -333,18 +322,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 float ia, iw;
                 pow2_scale(ma[h], sa[h], ia);
                 pow2_scale(mw[h], sw[h], iw);
-                if ((tid & 7) == 0) { rsc[r] = ia; rsc[GM + r] = iw; }
+                if ((tid & 7) == 0) { rsc[r] = pow2_e(ia); rsc[GM + r] = pow2_e(iw); }
             }
         }
     }
     gload(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
-        LS_PH(0)
         lstore();
-        LS_PH(1)
         __syncthreads();
-        LS_PH(2)
         if (k0 + BK < kend) gload(k0 + BK);  // in flight under the MFMA block
         const int lr = lane & 31, lk = (lane >> 5) * 4;
         if constexpr (SPLIT) {
@@ -396,7 +382,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 LS_TERM(1, 0) LS_TERM(0, 1) LS_TERM(0, 0)
 #undef LS_TERM
             }
-            LS_PH(3)
         } else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -433,12 +418,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wn * 64 + j * 32 + col_l;
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
-            float cs = 1.f;
-            if constexpr (H2) cs = rsc[GM + wn * 64 + j * 32 + col_l];
+            int ce = 0;
+            if constexpr (H2) ce = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r];
-                if constexpr (H2) v = v * (rsc[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rowh] * cs);
+                if constexpr (H2) v = scale_pow2(v, rsc[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rowh] + ce);
                 v += bv;
                 if (relu) v = fmaxf(v, 0.0f);
                 stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
@@ -474,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     constexpr int BUF = 4 * PLANE;         // A hi, A lo, B hi, B lo
     static_assert(2 * BUF >= 4 * STG * 4, "epilogue staging aliases the operand buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];   // inverse power-of-two scales of the tile's A rows, then of its W rows (GemmAux)
+    __shared__ __attribute__((aligned(16))) int rsc[GM + GN];   // inverse power-of-two scales of the tile's A rows, then of its W rows (GemmAux)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = logical / ntiles_n, tn = logical % ntiles_n;
@@ -509,12 +494,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
         arow[h] = A + r * lda;
         brow[h] = W + (size_t)gn * ldw;
-#if defined(LS_VAR_H2_SAMEA)       // dev timing variant: every workgroup reads the first A tile (all L2 hits)
-        arow[h] = A + (size_t)(sr0 + h * 32) * lda;
-#endif
-#if defined(LS_VAR_H2_SAMEA8)      // dev timing variant: the A tiles of 8 M-tiles only
-        arow[h] = A + (size_t)((tm & 7) * GM + sr0 + h * 32) * lda;
-#endif
     }
     auto kof = [&](int k0) { return KAL ? min(k0, kend - 32) + sk : min(k0 + sk, kend - 4); };
     auto gload_a = [&](int k0) {
@@ -585,7 +564,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
     };
     // operand range: one exact power of two per staged row (GemmAux), from the caller's row maxima or a pre-pass over the rows
-    if (aux.noscale) rsc[tid] = 1.f;
+    if (aux.noscale) rsc[tid] = 0;
     else {
         float ma[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f};
         if (aux.a_rowmax) {
@@ -620,7 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             float ia, iw;
             pow2_scale(ma[h], sa[h], ia);
             pow2_scale(mw[h], sw[h], iw);
-            if ((tid & 7) == 0) { rsc[sr0 + h * 32] = ia; rsc[GM + sr0 + h * 32] = iw; }
+            if ((tid & 7) == 0) { rsc[sr0 + h * 32] = pow2_e(ia); rsc[GM + sr0 + h * 32] = pow2_e(iw); }
         }
     }
     const int lr = lane & 31;
@@ -650,9 +629,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc) {
-#if defined(LS_VAR_H2_NOLO_READ)   // dev timing variant: half of the LDS operand reads
-                    if (pc == 1) { a[i][1] = a[i][0]; b[i][1] = b[i][0]; continue; }
-#endif
                     a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
                     b[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + offb[i] + ((q ^ xb[i]) << 4)));
                 }
@@ -662,42 +638,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-#if defined(LS_VAR_H2_NOX_MFMA)   // dev timing variant: a third of the MFMAs, every LDS read kept alive
-                    asm volatile("" :: "v"(a[i][1]), "v"(b[j][1]));
-                    continue;
-#endif
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
                 }
-#if !defined(LS_VAR_H2_NOSTAGE)
             if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); } else stage_w(Bn, 0);
-#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-#if defined(LS_VAR_H2_NOSTAGE)     // dev timing variant: no split, no LDS stores (the loads stay)
-            if (s2 == 0) { for (int h = 0; h < 4; ++h) asm volatile("" :: "v"(ra[h].x), "v"(ra[h].y), "v"(ra[h].z), "v"(ra[h].w)); gload_a(k0 + 64); }
-            else { for (int h = 0; h < 4; ++h) asm volatile("" :: "v"(rb[h].x), "v"(rb[h].y), "v"(rb[h].z), "v"(rb[h].w)); gload_b(k0 + 64); }
-#elif defined(LS_VAR_H2_NOGLOAD)   // dev timing variant: no global loads in the loop
-            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); }
-            else stage_w(Bn, 1);
-#else
             if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
             else { stage_w(Bn, 1); gload_b(k0 + 64); }
-#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-#if defined(LS_VAR_H2_NOX_MFMA)
-                    continue;
-#endif
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
                 }
         }
-#if !defined(LS_VAR_H2_NOBARRIER)  // dev timing variant (racy)
         __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
-#endif
     }
 
     // epilogue: as gemm_f32_kernel (each wave transposes its 64x64 sub-tile through LDS in two 32-row halves)
@@ -711,15 +668,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wn * 64 + j * 32 + col_l;
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
-            const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
+            const int ce = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
-                const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                const int4 rs = *reinterpret_cast<const int4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                const int rev[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
                 for (int rl = 0; rl < 4; ++rl) {
                     const int r = r4 * 4 + rl;
-                    float v = acc[i][j][r] * (rsv[rl] * cs) + bv;
+                    float v = scale_pow2(acc[i][j][r], rev[rl] + ce) + bv;
                     if (relu) v = fmaxf(v, 0.0f);
                     stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
                 }
@@ -751,7 +708,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     constexpr int BUF = 4 * PLANE;         // A hi, A lo, W hi, W lo
     static_assert(2 * BUF >= 8 * STG * 4, "epilogue staging aliases the operand buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * BUF + (TM + TN) * 4 bytes
-    float* rsc = reinterpret_cast<float*>(smem + 2 * BUF);        // inverse power-of-two scales: the tile's A rows, then its W rows
+    int* rsc = reinterpret_cast<int*>(smem + 2 * BUF);          // inverse power-of-two scales: the tile's A rows, then its W rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     // a workgroup takes the tiles blockIdx.x, + gridDim.x, ... (default launch: one tile each; LS_GEMM_W2_PERSIST=1: one workgroup per CU);
@@ -822,7 +779,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         *reinterpret_cast<uint2*>(plane_hi + off) = ph;
         *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
     };
-    if (aux.noscale) rsc[tid] = 1.f;
+    if (aux.noscale) rsc[tid] = 0;
     else {
         float ma[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f};
         if (aux.a_rowmax) {
@@ -857,7 +814,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
             float ia, iw;
             pow2_scale(ma[h], sa[h], ia);
             pow2_scale(mw[h], sw[h], iw);
-            if ((tid & 7) == 0) { rsc[sr0 + h * 64] = ia; rsc[TM + sr0 + h * 64] = iw; }
+            if ((tid & 7) == 0) { rsc[sr0 + h * 64] = pow2_e(ia); rsc[TM + sr0 + h * 64] = pow2_e(iw); }
         }
     }
     const int lr = lane & 31;
@@ -885,53 +842,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
             f16x8_t a[4][2], b[2][2];
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
-#if defined(LS_VAR_W2_NOLO_READ)   // dev timing variant: half of the LDS operand reads
-                if (pc == 1) { for (int j = 0; j < 2; ++j) b[j][1] = b[j][0]; for (int i = 0; i < 4; ++i) a[i][1] = a[i][0]; continue; }
-#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + offb[j] + ((q ^ xb[j]) << 4)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
             }
             // per accumulator and 16-k step: lo(a) hi(w), hi(a) hi(w), hi(a) lo(w) -- the order every unified-accumulator kernel uses
-#if !defined(LS_VAR_W2_NOX_MFMA)    // dev timing variant: a third of the MFMAs (the reads stay alive through the staging below)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-#else
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i][1]));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(b[j][1]));
-#endif
-#if !defined(LS_VAR_W2_NOSTAGE)    // dev timing variant: no split, no LDS stores
             if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); }
             else { stage_w(Bn, 0); stage_w(Bn, 1); }
-#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-#if defined(LS_VAR_W2_NOSTAGE)
-            if (s2 == 0) gload_a(k0 + 64); else gload_b(k0 + 64);
-#elif defined(LS_VAR_W2_NOGLOAD)   // dev timing variant: no global loads in the loop
-            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); }
-            else { stage_w(Bn, 2); stage_w(Bn, 3); }
-#else
             if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
             else { stage_w(Bn, 2); stage_w(Bn, 3); gload_b(k0 + 64); }
-#endif
-#if !defined(LS_VAR_W2_NOX_MFMA)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-#endif
         }
-#if !defined(LS_VAR_W2_NOBARRIER)   // dev timing variant (racy)
         __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
-#endif
     }
 
     // (Not kept: s_setprio(1) around the MFMA groups: 930 -> 1 055 us.  The operand fragments as an explicit four-sub-phase software pipeline -- every LDS read batch one sub-phase ahead of its
@@ -950,15 +884,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + wn * 64 + j * 32 + col_l;
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
-            const float cs = rsc[TM + wn * 64 + j * 32 + col_l];
+            const int ce = rsc[TM + wn * 64 + j * 32 + col_l];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 128 + i * 32 + 8 * r4 + rowh]);
-                const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                const int4 rs = *reinterpret_cast<const int4*>(&rsc[wm * 128 + i * 32 + 8 * r4 + rowh]);
+                const int rev[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
                 for (int rl = 0; rl < 4; ++rl) {
                     const int r = r4 * 4 + rl;
-                    float v = acc[i][j][r] * (rsv[rl] * cs) + bv;
+                    float v = scale_pow2(acc[i][j][r], rev[rl] + ce) + bv;
                     if (relu) v = fmaxf(v, 0.0f);
                     stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
                 }
@@ -994,7 +928,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     constexpr int BUF = 4 * PLANE;         // A hi, A lo, B hi, B lo
     static_assert(2 * BUF >= 4 * STG * 4, "epilogue staging aliases the operand buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];   // inverse power-of-two scales of the staged A rows, then of the staged W rows (GemmAux)
+    __shared__ __attribute__((aligned(16))) int rsc[GM + GN];   // inverse power-of-two scales of the staged A rows, then of the staged W rows (GemmAux)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = logical / ntiles_n, tn = logical % ntiles_n;
@@ -1062,7 +996,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     };
     // operand range: one exact power of two per staged row (GemmAux), from the caller's row maxima or a pre-pass over the rows
     float sa[4] = {1.f, 1.f, 1.f, 1.f}, sw[4] = {1.f, 1.f, 1.f, 1.f};
-    if (aux.noscale) rsc[tid] = 1.f;
+    if (aux.noscale) rsc[tid] = 0;
     else {
         float ma[4] = {0.f, 0.f, 0.f, 0.f}, mw[4] = {0.f, 0.f, 0.f, 0.f};
         if (aux.a_rowmax) {
@@ -1097,7 +1031,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             float ia, iw;
             pow2_scale(ma[h], sa[h], ia);
             pow2_scale(mw[h], sw[h], iw);
-            if ((tid & 7) == 0) { rsc[sr0 + h * 32] = ia; rsc[GM + sr0 + h * 32] = iw; }
+            if ((tid & 7) == 0) { rsc[sr0 + h * 32] = pow2_e(ia); rsc[GM + sr0 + h * 32] = pow2_e(iw); }
         }
     }
     const int lr = lane & 31;
@@ -1157,15 +1091,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
+            const int ce = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
-                const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                const int4 rs = *reinterpret_cast<const int4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                const int rev[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
                 for (int rl = 0; rl < 4; ++rl) {
                     const int r = r4 * 4 + rl;
-                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = acc[i][j][r] * (rsv[rl] * cs);
+                    stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = scale_pow2(acc[i][j][r], rev[rl] + ce);
                 }
             }
         }
@@ -1341,7 +1275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     constexpr int OPER = 2 * NSL * PLANE;           // hi + lo planes of all slabs of one operand
     constexpr int ABYTES = (OPER > 4 * STG * 4) ? OPER : 4 * STG * 4;   // the A planes double as the epilogue staging area
     __shared__ __attribute__((aligned(16))) char smem[ABYTES + OPER];
-    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];   // inverse power-of-two scales of the current tile's A rows, then of the W rows (GemmAux)
+    __shared__ __attribute__((aligned(16))) int rsc[GM + GN];   // inverse power-of-two scales of the current tile's A rows, then of the W rows (GemmAux)
     char* Ap = smem;
     char* Bp = smem + ABYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1363,7 +1297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         *reinterpret_cast<uint2*>(base + (2 * slab + 1) * PLANE + off) = pl;
     };
     const bool scaled = !aux.noscale;
-    if (!scaled) rsc[tid] = 1.f;
+    if (!scaled) rsc[tid] = 0;
     // W tile, once (columns past N: clamped row, computed and never stored); each row scaled by its own power of two (GemmAux: the
     // whole K of a row is in this thread group's registers, so the row maximum costs three DPP steps)
     {
@@ -1383,7 +1317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) mw = amax4(mw, rw[sl][h]);
                 pow2_scale(max8(mw), sw, iw);
-                if ((tid & 7) == 0) rsc[GM + sr0 + h * 32] = iw;
+                if ((tid & 7) == 0) rsc[GM + sr0 + h * 32] = pow2_e(iw);
             }
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) lstore2(Bp, sl, rw[sl][h], sw, swz[h]);
@@ -1430,7 +1364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) ma = amax4(ma, ra[sl][h]);
                 pow2_scale(max8(ma), sa, ia);
-                if ((tid & 7) == 0) rsc[sr0 + h * 32] = ia;
+                if ((tid & 7) == 0) rsc[sr0 + h * 32] = pow2_e(ia);
             }
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) lstore2(Ap, sl, ra[sl][h], sa, swz[h]);
@@ -1481,15 +1415,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             //  are only written after the loop-top barrier)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
+                const int ce = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
-                    const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                    const int4 rs = *reinterpret_cast<const int4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                    const int rev[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
                     for (int rl = 0; rl < 4; ++rl) {
                         const int r = r4 * 4 + rl;
-                        float v = acc[i][j][r] * (rsv[rl] * cs) + bv[j];
+                        float v = scale_pow2(acc[i][j][r], rev[rl] + ce) + bv[j];
                         if (relu) v = fmaxf(v, 0.0f);
                         stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = v;
                     }
@@ -1521,7 +1455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     constexpr int OPER = 2 * NSL * PLANE;
     constexpr int ABYTES = (OPER > 4 * STG * 4) ? OPER : 4 * STG * 4;   // the A planes double as the epilogue staging area
     __shared__ __attribute__((aligned(16))) char smem[ABYTES + OPER];
-    __shared__ __attribute__((aligned(16))) float rsc[GM + GN];
+    __shared__ __attribute__((aligned(16))) int rsc[GM + GN];
     char* Ap = smem;
     char* Bp = smem + ABYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1542,7 +1476,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         *reinterpret_cast<uint2*>(base + (2 * slab + 1) * PLANE + off) = pl;
     };
     const bool scaled = !aux.noscale;
-    if (!scaled) rsc[tid] = 1.f;
+    if (!scaled) rsc[tid] = 0;
     // W tile, once: staged row sr0 + 32 h = tile column (wn = h >> 1, lin | dir = h & 1, channel sr0)
     {
         float4 rw[NSL][4];
@@ -1565,7 +1499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                     mw = max8(mw);
                 }
                 pow2_scale(mw, sw, iw);
-                if ((tid & 7) == 0) rsc[GM + sr0 + h * 32] = iw;
+                if ((tid & 7) == 0) rsc[GM + sr0 + h * 32] = pow2_e(iw);
             }
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) lstore2(Bp, sl, rw[sl][h], sw, swz[h]);
@@ -1606,7 +1540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                     ma = max8(ma);
                 }
                 pow2_scale(ma, sa, ia);
-                if ((tid & 7) == 0) rsc[sr0 + h * 32] = ia;
+                if ((tid & 7) == 0) rsc[sr0 + h * 32] = pow2_e(ia);
             }
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) lstore2(Ap, sl, ra[sl][h], sa, swz[h]);
@@ -1654,15 +1588,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float cs = rsc[GM + wn * 64 + j * 32 + col_l];
+                const int ce = rsc[GM + wn * 64 + j * 32 + col_l];
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 rs = *reinterpret_cast<const float4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
-                    const float rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+                    const int4 rs = *reinterpret_cast<const int4*>(&rsc[wm * 64 + i * 32 + 8 * r4 + rowh]);
+                    const int rev[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
                     for (int rl = 0; rl < 4; ++rl) {
                         const int r = r4 * 4 + rl;
-                        stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = acc[i][j][r] * (rsv[rl] * cs);
+                        stg[((r & 3) + 8 * (r >> 2) + rowh) * 68 + j * 32 + col_l] = scale_pow2(acc[i][j][r], rev[rl] + ce);
                     }
                 }
             }
@@ -1856,13 +1790,17 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     } else if (split && pieces == 22 && wide_on && !a_rows && K % 32 == 0 && K >= 128) {
         const int wtm = cdiv(M, 256), wtn = cdiv(N, 256);
         const size_t lds = 2 * 4 * 256 * 64 + 512 * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        // the dynamic-LDS opt-in is a per-DEVICE function attribute: one flag per device ordinal (a process may drive several GPUs)
+        static std::atomic<unsigned long long> attr_devices{0};
+        int dev_ord = 0;
+        LS_HIP_CHECK(hipGetDevice(&dev_ord));
+        const unsigned long long dev_bit = 1ull << (dev_ord & 63);
+        if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
             LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            attr_devices.fetch_or(dev_bit, std::memory_order_release);
         }
         // LS_GEMM_W2_PERSIST=1: one workgroup per CU walking the tiles (measured: 942 - 944 vs 950 - 956 us at the decoder shape, but 73 -> 79 us at
         // 480 tiles, where the static assignment balances worse than the dispatcher) -- off by default

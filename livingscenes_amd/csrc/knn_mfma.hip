@@ -968,12 +968,6 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
     // that one-sided bound: fewer exact distances but a second dependent round of gathers per query; 86 -> 97 us at layer 3 with the
     // bf16 image.  With the f16 image the survivors fit one 48-wide step anyway.)
     u64 best = ~0ull;
-#if defined(LS_VAR_KO_NOEXACT)   // dev timing variant: front end only
-    cnt = 0;
-#endif
-#if defined(LS_VAR_KO_ONEITER)   // dev timing variant: at most one step of exact distances
-    cnt = min(cnt, 16 * KO_US);
-#endif
     for (int base = 0; base < cnt; base += 16 * KO_US) {
         u64 ks[3] = {~0ull, ~0ull, ~0ull};
 #pragma unroll

@@ -126,7 +126,7 @@ struct ls_model {
                                    // race hunting by comparing workspaces (scripts/diag/)
     bool fps_side = true;          // LS_FPS_SIDE=0 runs the FPS chain on the caller's stream (A/B timing, race hunting)
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
-    unsigned skip_mask = 0;        // LS_SKIP=knn,attn,...: dev timing knob -- after LS_SKIP_AFTER (default 3) ls_encode calls on this handle the named
+    unsigned skip_mask = 0;        // (always 0 unless built with -DLS_DEV_KNOBS) LS_SKIP=knn,attn,...: dev timing knob -- after LS_SKIP_AFTER (default 3) ls_encode calls on this handle the named
     int skip_after = 3, calls = 0; // launches are skipped (their outputs keep the previous call's values): marginal cost of a kernel family
                                    // with many steps in flight.  Results are then STALE: never set outside scripts/dev.
     bool profiling = false;
@@ -584,11 +584,13 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     if (const char* ev = getenv("LS_KNN_HINTS")) m->hint_policy = !strcmp(ev, "prev") ? 1 : (!strcmp(ev, "auto") ? 2 : 0);
     if (const char* ev = getenv("LS_SDF_BF16X2")) m->sdf_bf16x2 = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_FILTER")) m->knn_filter = atoi(ev) != 0;
+#ifdef LS_DEV_KNOBS   // only in the variant library scripts/dev/marginal_cost.sh builds (-DLS_DEV_KNOBS): the release library cannot be made to skip work
     if (const char* ev = getenv("LS_SKIP")) {
         const char* names[] = {"knn", "attn", "pool", "l0", "tables", "glob", "fps", "tail", "prologue"};
         for (int i = 0; i < 9; ++i) if (strstr(ev, names[i])) m->skip_mask |= 1u << i;
         if (const char* ea = getenv("LS_SKIP_AFTER")) m->skip_after = atoi(ea);
     }
+#endif
     hipError_t e = hipMalloc((void**)&m->blob, (size_t)desc->blob_floats * sizeof(float));
     if (e != hipSuccess) { delete m; set_error("hipMalloc(model blob): %s", hipGetErrorString(e)); return LS_ERR_HIP; }
     e = hipMemcpy(m->blob, blob_host, (size_t)desc->blob_floats * sizeof(float), hipMemcpyHostToDevice);
@@ -665,6 +667,16 @@ int ls_model_set_option(ls_model_t* m, int option, int value) {
         case LS_OPT_SDF_BF16X2: m->sdf_bf16x2 = value != 0; return LS_OK;
         case LS_OPT_ENCODE_GRAPH: m->use_graph = value != 0; return LS_OK;
         default: set_error("model_set_option: unknown option %d", option); return LS_ERR_INVALID;
+    }
+}
+
+int ls_model_get_option(const ls_model_t* m, int option, int* value) {
+    LS_REQUIRE(m && value, "model_get_option: null argument");
+    switch (option) {
+        case LS_OPT_SDF_TRAIN_SPLITK: *value = m->train_splitk ? 1 : 0; return LS_OK;
+        case LS_OPT_SDF_BF16X2: *value = m->sdf_bf16x2 ? 1 : 0; return LS_OK;
+        case LS_OPT_ENCODE_GRAPH: *value = m->use_graph ? 1 : 0; return LS_OK;
+        default: set_error("model_get_option: unknown option %d", option); return LS_ERR_INVALID;
     }
 }
 

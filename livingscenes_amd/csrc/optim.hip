@@ -81,17 +81,20 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ sdf,
 // torch.optim.Adam (no weight decay, no amsgrad) on up to four parameter tensors in one launch, each with its own learning rate
 // (more_solver.py:199-203: z_inv 1e-5, t 1e-4, z_so3 5e-4), in torch's operation order:
 //   m <- m + (g - m)(1 - b1);  v <- b2 v + (1 - b2) g g;  p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-struct AdamSet { ls_adam_group g[4]; };
-__global__ __launch_bounds__(256) void adam_multi_kernel(AdamSet s, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+// Every scalar arrives ROUNDED ONCE from the double the host computed it in -- torch.optim.Adam forms 1 - beta, 1 - beta^t, lr / (1 - beta1^t)
+// and sqrt(1 - beta2^t) from Python floats (doubles) and hands each to its fp32 kernel as one cast: with beta2 = 0.999, 1.0f - 0.999f is
+// 1.3e-5 away from float(1 - 0.999), and 1 - powf(beta2, t) carries the cancellation of an fp32 power.
+struct AdamSet { ls_adam_group g[4]; float step_size[4]; };   // step_size = float(lr / (1 - beta1^t))
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamSet s, float omb1, float b2, float omb2, float eps, float bc2_sqrt) {
     const ls_adam_group& q = s.g[blockIdx.y];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= q.n) return;
     const float g = q.grad[i];
-    const float m = __builtin_fmaf(g - q.m[i], 1.0f - b1, q.m[i]);
-    const float v = __builtin_fmaf((1.0f - b2) * g, g, b2 * q.v[i]);
+    const float m = __builtin_fmaf(g - q.m[i], omb1, q.m[i]);
+    const float v = __builtin_fmaf(omb2 * g, g, b2 * q.v[i]);
     q.m[i] = m; q.v[i] = v;
     const float denom = sqrtf(v) / bc2_sqrt + eps;
-    q.param[i] = __builtin_fmaf(-(q.lr / bc1), m / denom, q.param[i]);
+    q.param[i] = __builtin_fmaf(-s.step_size[blockIdx.y], m / denom, q.param[i]);
 }
 
 // Batched log-domain softmin of entropic OT with cost |x - y|^2 / 2 (sinkhorn.hip's primitive with a pair index):
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void softmin_multi_kernel(SoftminSet s, const 
     softmin_rows<false, 8, 4>(q.x, q.y, q.pot_y, q.logw, eps_p, q.prev, average, q.N, q.M, q.out, nullptr);
 }
 
-struct AdamCfg { float lr, b1, b2, eps, bc1, bc2, stop_angle; };   // bc = 1 - beta^(step + 1)
+struct AdamCfg { float lr, b1, b2, omb1, omb2, eps, bc1, bc2, stop_angle; };   // omb = float(1 - beta), bc = float(1 - beta^(step + 1)): each formed in double on the host
 
 // One workgroup per pair: d loss / d (v, omega) in the LEFT tangent space from the point gradients G = d loss / d query
 //   grad = (sum_i G_i, sum_i query_i x G_i),
@@ -244,8 +247,8 @@ __global__ __launch_bounds__(256) void se3_adam_step_kernel(const float* __restr
         float st[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const float a = c.b1 * m1[p * 6 + k] + (1.f - c.b1) * acc[k];
-            const float b = c.b2 * m2[p * 6 + k] + (1.f - c.b2) * acc[k] * acc[k];
+            const float a = c.b1 * m1[p * 6 + k] + c.omb1 * acc[k];
+            const float b = c.b2 * m2[p * 6 + k] + c.omb2 * acc[k] * acc[k];
             m1[p * 6 + k] = a; m2[p * 6 + k] = b;
             st[k] = -(c.lr * (a / c.bc1) / (sqrtf(b / c.bc2) + c.eps));
         }
@@ -333,7 +336,7 @@ int ls_mse_f32(const float* sdf, int P, int N, float* loss, float* grad_sdf, flo
     return LS_OK;
 }
 
-int ls_adam_step_f32(const ls_adam_group* groups, int count, float beta1, float beta2, float adam_eps, int step, void* stream) {
+int ls_adam_step_f32(const ls_adam_group* groups, int count, double beta1, double beta2, double adam_eps, int step, void* stream) {
     LS_REQUIRE(groups && count >= 1 && count <= 4 && step >= 0, "adam_step: bad arguments (count=%d step=%d)", count, step);
     AdamSet s;
     long long nmax = 0;
@@ -343,8 +346,10 @@ int ls_adam_step_f32(const ls_adam_group* groups, int count, float beta1, float 
         nmax = std::max(nmax, groups[i].n);
     }
     for (int i = count; i < 4; ++i) s.g[i] = s.g[0];
-    const float bc1 = 1.0f - powf(beta1, (float)(step + 1)), bc2 = 1.0f - powf(beta2, (float)(step + 1));
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(cdiv(nmax, 256), count), dim3(256), 0, (hipStream_t)stream, s, beta1, beta2, adam_eps, bc1, sqrtf(bc2));
+    const double bc1 = 1.0 - pow(beta1, (double)(step + 1)), bc2 = 1.0 - pow(beta2, (double)(step + 1));   // as torch: Python floats
+    for (int i = 0; i < 4; ++i) s.step_size[i] = (float)(s.g[i].lr / bc1);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(cdiv(nmax, 256), count), dim3(256), 0, (hipStream_t)stream, s, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)adam_eps, (float)sqrt(bc2));
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -383,12 +388,13 @@ int ls_sinkhorn_softmin_multi_f32(const ls_softmin_problem* problems, int count,
     return LS_OK;
 }
 
-int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float* loss, int P, int N, float lr, float beta1, float beta2,
-                         float adam_eps, int step, float stop_angle, float* g, float* m1, float* m2, float* min_loss, float* best_g,
+int ls_se3_adam_step_f32(const float* src, const float* grad_query, const float* loss, int P, int N, double lr, double beta1, double beta2,
+                         double adam_eps, int step, float stop_angle, float* g, float* m1, float* m2, float* min_loss, float* best_g,
                          const float* init_R, int32_t* active, float* query, void* stream) {
     LS_REQUIRE(src && grad_query && loss && g && m1 && m2 && min_loss && best_g && init_R && active && query, "se3_adam_step: null argument");
     LS_REQUIRE(P > 0 && N > 0 && step >= 0, "se3_adam_step: bad sizes");
-    AdamCfg c{lr, beta1, beta2, adam_eps, 1.0f - powf(beta1, (float)(step + 1)), 1.0f - powf(beta2, (float)(step + 1)), stop_angle};
+    AdamCfg c{(float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)adam_eps,
+              (float)(1.0 - pow(beta1, (double)(step + 1))), (float)(1.0 - pow(beta2, (double)(step + 1))), stop_angle};
     hipLaunchKernelGGL(se3_adam_step_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, src, grad_query, loss, c, N, g, m1, m2, min_loss, best_g,
                        init_R, active, query);
     LS_LAUNCH_CHECK();

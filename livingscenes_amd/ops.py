@@ -317,17 +317,17 @@ class HipModel:
             ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return ws
 
+    def get_option(self, option):
+        """ls_model_get_option (_lib.OPT_*): the handle's current value, read from the library (never mirrored in Python)."""
+        v = ctypes.c_int(0)
+        check(load().ls_model_get_option(self._h, int(option), ctypes.byref(v)), "ls_model_get_option")
+        return int(v.value)
+
     def set_option(self, option, value):
-        """ls_model_set_option (_lib.OPT_*) -> the value the option had before (the library's default the first time), so that a
-        temporary change can be undone without clobbering a caller's setting."""
-        opts = self.__dict__.setdefault("_opts", {})
-        if int(option) not in opts:
-            defaults = {_lib.OPT_SDF_TRAIN_SPLITK: 1, _lib.OPT_SDF_BF16X2: int(os.environ.get("LS_SDF_BF16X2", "0") != "0"),
-                        _lib.OPT_ENCODE_GRAPH: int(os.environ.get("LS_ENCODE_GRAPH", "0") != "0")}
-            opts[int(option)] = defaults.get(int(option), 0)
-        prev = opts[int(option)]
+        """ls_model_set_option (_lib.OPT_*) -> the value the option had before (asked of the library), so that a temporary change can be
+        undone without clobbering a caller's setting or the environment's default."""
+        prev = self.get_option(option)
         check(load().ls_model_set_option(self._h, int(option), int(value)), "ls_model_set_option")
-        opts[int(option)] = int(value)
         return prev
 
     def profile_begin(self):

@@ -115,11 +115,14 @@ def test_gemm_row_scaling_by_powers_of_two_changes_only_the_exponent(M, N, K):
     assert torch.equal(out.double(), want)
 
 
-@pytest.mark.parametrize("scale_a,scale_w", [(1e-6, 1e-6), (3e6, 1e-7), (1e-9, 1.0), (7e4, 7e4), (1e-20, 1e12)])
+@pytest.mark.parametrize("scale_a,scale_w", [(1e-6, 1e-6), (3e6, 1e-7), (1e-9, 1.0), (7e4, 7e4), (1e-20, 1e12), (1e-19, 1e-18), (1e25, 1e-22)])
 @pytest.mark.parametrize("M,N,K", [(3000, 260, 64), (3000, 260, 256), (256, 260, 768)])
 def test_gemm_tiny_and_huge_operands_keep_the_fp32_chain_bound(M, N, K, scale_a, scale_w):
     """All operands far below the f16 normal range (1e-6: the round-2 split lost 1e-5 .. 1e-4 there) or above f16's maximum
-    (65504: the round-2 split returned NaN): componentwise error against fp64 within the fp32 FMA chain's own bound."""
+    (65504: the round-2 split returned NaN): componentwise error against fp64 within the fp32 FMA chain's own bound.  (1e-19, 1e-18):
+    the two inverse row scales multiply to ~2^-153, below fp32's smallest subnormal, while the results (~1e-36) are normal numbers --
+    the epilogue adds the two exponents as integers (gemm.hip: scale_pow2) instead of multiplying the scales (round 3 returned 0);
+    (1e25, 1e-22): one scale is huge, the other tiny -- no intermediate may overflow either."""
     from livingscenes_amd import ops
     g = torch.Generator().manual_seed(K)
     A = torch.randn(M, K, generator=g) * torch.exp(2 * torch.randn(M, K, generator=g)) * scale_a

@@ -67,6 +67,36 @@ def test_sdf_decode_two_piece_mode_stays_inside_the_tolerance():
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_SDF_BF16X2="1"), cwd=root)
 
 
+def test_model_options_are_read_back_from_the_library():
+    """ls_model_get_option returns what the HANDLE holds: the environment's value as the C side parsed it (atoi: "false" and "" are 0 --
+    a Python-side mirror with `!= "0"` called both 1), then whatever ls_model_set_option stored; set_option's "previous value" is that
+    read-back, so a temporary change restores exactly the state it found.  Unknown options are errors, not zeros."""
+    import os, subprocess, sys
+    code = (
+        "import torch\n"
+        "from livingscenes_amd import _lib, synth\n"
+        "from livingscenes_amd.model_utils import Shape_Prior\n"
+        "ecfg, dcfg = synth.small_encoder_cfg(), synth.small_decoder_cfg()\n"
+        "sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=torch.device('cuda:0'))\n"
+        "hip = sp.hip_model()\n"
+        "import os\n"
+        "want = [int(v) for v in os.environ['LS_EXPECT'].split(',')]\n"
+        "got = [hip.get_option(o) for o in (_lib.OPT_SDF_TRAIN_SPLITK, _lib.OPT_SDF_BF16X2, _lib.OPT_ENCODE_GRAPH)]\n"
+        "assert got == want, (got, want)\n"
+        "prev = hip.set_option(_lib.OPT_SDF_BF16X2, 1 - want[1])\n"
+        "assert prev == want[1] and hip.get_option(_lib.OPT_SDF_BF16X2) == 1 - want[1]\n"
+        "assert hip.set_option(_lib.OPT_SDF_BF16X2, prev) == 1 - want[1] and hip.get_option(_lib.OPT_SDF_BF16X2) == want[1]\n"
+        "try:\n"
+        "    hip.get_option(99)\n"
+        "    raise SystemExit('unknown option accepted')\n"
+        "except _lib.LsError:\n"
+        "    pass\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("LS_SDF_BF16X2", "LS_ENCODE_GRAPH")}
+    for env, want in (({}, "1,0,0"), ({"LS_SDF_BF16X2": "1", "LS_ENCODE_GRAPH": "1"}, "1,1,1"), ({"LS_SDF_BF16X2": "false", "LS_ENCODE_GRAPH": ""}, "1,0,0")):
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(base, LS_EXPECT=want, **env), cwd=root)
+
+
 def test_encoder_refuses_a_cloud_too_small_for_its_schedule():
     """The released schedule down-samples by 32: with N = 256 the last layer would have 8 source points for 16 neighbours
     (-1 padded lists into the gather kernels).  The library refuses instead of reading out of bounds."""
