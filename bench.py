@@ -154,6 +154,58 @@ def roofline_entry(kind, layer, avg_s, cfg, B, N, bf16x3):
     return e
 
 
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 78.6 T fp32 lane-ops/s (256 CUs x 4 SIMD-32 at 2.4 GHz): the rate behind the 157.3 TFLOP/s FMA peak
+
+
+def knn_hw_utilisation(e, layer, avg_s, cfg, B, N, survivors_per_call, seeded):
+    """The k-NN graph build against what the HARDWARE does: `frac` above prices the direct-difference-EQUIVALENT flops of
+    SURVEY 8(d), which the kernels do not execute -- a better filter would push it past 1.  frac_hw = the longest of three hardware floors
+    over the measured build time:
+      hbm   compulsory bytes / 8 TB/s
+      mfma  EXECUTED f16 MFMA flops of the safe filter (every (query, candidate) pair once, padded to the 32-wide tiles) / 2.5 PF
+      valu  EXECUTED fp32 lane-operations of the exact phases / 78.6 T lane-ops/s: every candidate that gets a canonical distance (the 16 hints
+            of a seeded layer + the filter's survivors, counted on the device: ls_profile_knn_stats) costs D subtractions + D multiplications +
+            4 D additions -- the canonical chain is serial, and the quad form that keeps the row gathers coalesced executes each add in four
+            lanes (csrc/knn_mfma.hip: quad_pair_distance)."""
+    pl = layer_plan(cfg, N)
+    L = pl[min(layer, len(pl) - 1)]
+    D = 3 * L["Cin"]
+    pad = lambda n: (n + 31) // 32 * 32
+    mfma_flops = 2.0 * B * pad(L["Nd"]) * pad(L["Ns"]) * D
+    pairs = B * L["Nd"] * (16 if seeded else 0) + survivors_per_call
+    lane_ops = pairs * 6.0 * D
+    floors = {"hbm": e["algorithmic_bytes_per_launch"] / (HBM_PEAK_GBS * 1e9), "mfma": mfma_flops / (BF16_PEAK_TFLOPS * 1e12),
+              "valu": lane_ops / VALU_LANE_OPS_PER_S}
+    which = max(floors, key=floors.get)
+    e["frac_hw"] = floors[which] / avg_s
+    e["frac_hw_detail"] = {
+        "bound": which, "floor_us": {k: round(v * 1e6, 2) for k, v in floors.items()}, "measured_us": round(avg_s * 1e6, 2),
+        "executed_f16_mfma_flops": mfma_flops, "executed_exact_pairs": pairs, "exact_pairs_per_query": pairs / (B * L["Nd"]),
+        "survivors_per_query": survivors_per_call / (B * L["Nd"]), "executed_valu_lane_ops": lane_ops,
+        "useful_valu_lane_ops": pairs * 3.0 * D,
+        "note": "frac_hw = max(compulsory bytes / 8 TB/s, executed f16 MFMA flops / 2.5 PFLOP/s, executed exact-phase fp32 lane-ops / 78.6 T lane-ops/s) "
+                "/ measured duration of the whole build (image + seed + sweep + finish launches); `frac` keeps SURVEY 8(d)'s direct-difference-equivalent basis"}
+    return e
+
+
+FPS_STEP_FLOOR_US = 0.25   # one dependent arg-max step: an LDS round trip for the winner + a barrier + the DPP wave reduction (DESIGN.md 5)
+
+
+def fps_entry(level, avg_s, cfg, B, N):
+    """FPS is neither HBM- nor pipe-bound: one workgroup per instance runs n_samples DEPENDENT arg-max steps."""
+    n = [N]
+    for p in layer_plan(cfg, N):
+        if p["Nd"] != p["Ns"]:
+            n.append(p["Nd"])
+    steps = n[min(level + 1, len(n) - 1)]
+    return {"kernel": f"fps[level {level}]", "bound": "latency", "dependent_steps": steps, "avg_launch_us": avg_s * 1e6,
+            "ns_per_step": avg_s * 1e9 / steps, "floor_us_per_step": FPS_STEP_FLOOR_US, "achieved": steps / (avg_s * 1e6), "peak": 1.0 / FPS_STEP_FLOOR_US,
+            "unit": "dependent steps/us", "frac": FPS_STEP_FLOOR_US * steps / (avg_s * 1e6), "workgroups": B,
+            "points_in": n[min(level, len(n) - 1)],
+            "basis": f"{steps} dependent arg-max steps x {FPS_STEP_FLOOR_US} us (LDS round trip + workgroup barrier + DPP reduction) / measured launch duration; "
+                     f"{B} workgroups = {B / 256:.0%} of the CUs, on a side stream beside layers 0 - 1"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,6 +406,7 @@ def main():
         with torch.no_grad():
             for _ in range(prof_steps):
                 step()
+        knn_stats = hip.profile_knn_stats()     # {layer: (candidates given a canonical distance beyond the hints, queries)} over the profiled steps
         prof = hip.profile_end()
         tot = sum(p["total_ms"] for p in prof)
         by = sorted(prof, key=lambda p: -p["total_ms"])
@@ -367,6 +420,14 @@ def main():
         if dom["kind"] == "knn":
             roof["note"] = ("one k-NN graph build = the launch sequence of that layer (seeded layers 1 / 2: f16 image incl. centre, seed, sweep, finish = 4 - 5 launches; un-seeded layers 3 / 4: image, sweep, finish = 3); "
                             "bound by fp32 VALU issue on the direct-difference-equivalent count -- see `basis`")
+        seeded_layers = {i for i, L in enumerate(layer_plan(ecfg, N)) if i >= 1 and L["Cin"] == 32}   # model.hip: the previous layer's lists seed the C = 32 layers
+
+        def with_hw(e, q):
+            if q["kind"] == "knn" and q["layer"] in knn_stats and knn_stats[q["layer"]][1]:
+                knn_hw_utilisation(e, q["layer"], q["total_ms"] / q["launches"] * 1e-3, ecfg, B, N, knn_stats[q["layer"]][0] / max(q["launches"], 1),
+                                   q["layer"] in seeded_layers)
+            return e
+        with_hw(roof, dom)
         roof["timing"] = f"hipEvent pair per launch on the launching stream, separate profiled pass of {prof_steps} steps (one step in flight)"
         roof["share_of_device_time"] = dom["total_ms"] / max(tot, 1e-9)
         roof["breakdown_ms_per_step"] = {k: round(v / prof_steps, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
@@ -387,7 +448,43 @@ def main():
             e = max(cands, key=lambda p: p["layer"])
             if all(x["kernel"] != f"gemm_edge[layer {e['layer']}]" for x in extra):
                 extra.append(roofline_entry("gemm_edge", e["layer"], e["total_ms"] / e["launches"] * 1e-3, ecfg, B, N, bf16x3))
+        for q in sorted((p for p in prof if p["kind"] == "knn" and p["layer"] in knn_stats and p is not dom), key=lambda p: p["layer"]):   # every filter-path k-NN layer
+            extra.append(with_hw(roofline_entry("knn", q["layer"], q["total_ms"] / q["launches"] * 1e-3, ecfg, B, N, bf16x3), q))
+        for q in sorted((p for p in prof if p["kind"] == "fps"), key=lambda p: p["layer"])[:1]:     # the single heaviest kernel of the step: FPS level 0
+            extra.append(fps_entry(q["layer"], q["total_ms"] / q["launches"] * 1e-3, ecfg, B, N))
         roof["other_kernels"] = extra
+        # the whole step against its own floors: every profiled operator's compulsory bytes and max(bytes / HBM peak, flops / pipe peak)
+        ws_bytes = ws_floor = ws_floor_hw = ws_pmc = 0.0
+        pmc_missing = []
+        for q in prof:
+            per = q["launches"] / prof_steps
+            ab, af, fpk, _ = algorithmic_cost(q["kind"], q["layer"], ecfg, B, N, bf16x3)
+            fl = max(ab / (HBM_PEAK_GBS * 1e9), af / (fpk * 1e12))
+            ws_bytes += ab * per
+            ws_floor += fl * per
+            hw = fl
+            if q["kind"] == "knn" and q["layer"] in knn_stats and knn_stats[q["layer"]][1]:
+                tmp = knn_hw_utilisation({"algorithmic_bytes_per_launch": ab}, q["layer"], 1.0, ecfg, B, N, knn_stats[q["layer"]][0] / max(q["launches"], 1),
+                                         q["layer"] in seeded_layers)
+                hw = tmp["frac_hw"]            # (avg_s = 1: frac_hw is the floor in seconds)
+            elif q["kind"] == "fps":
+                hw = fps_entry(q["layer"], 1.0, ecfg, B, N)["frac"]      # (avg_s = 1: the floor in seconds)
+            ws_floor_hw += hw * per
+            pm = committed_pmc(f"{q['kind']}[layer {q['layer']}]")
+            if "hbm_read_bytes" in pm and "hbm_write_bytes" in pm:
+                ws_pmc += (pm["hbm_read_bytes"] + pm["hbm_write_bytes"]) * per
+            else:
+                pmc_missing.append(f"{q['kind']}[{q['layer']}]")
+        roof["whole_step"] = {
+            "algorithmic_bytes": ws_bytes, "pmc_bytes": ws_pmc or None, "pmc_over_algorithmic": (ws_pmc / ws_bytes) if ws_pmc else None,
+            "pmc_operators_without_a_committed_counter_pass": pmc_missing,
+            "sum_floor_ms": ws_floor * 1e3, "sum_floor_hw_ms": ws_floor_hw * 1e3, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_one_in_flight_profiled": tot / prof_steps,
+            "frac_of_sum_floor": ws_floor / (dt / args.steps), "frac_of_sum_floor_hw": ws_floor_hw / (dt / args.steps),
+            "algorithmic_GBps": ws_bytes / (dt / args.steps) / 1e9, "algorithmic_frac_of_hbm_peak": ws_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "note": "sum over every launch of one step of max(compulsory bytes / 8 TB/s, flops / pipe peak) (sum_floor_ms: k-NN on the direct-difference-equivalent "
+                    "basis; sum_floor_hw_ms: k-NN on executed work, FPS at 0.25 us per dependent step) against the timed ms_per_step; floors of kernels "
+                    "that run concurrently on different streams are still summed, so this is a lower bound on a serial schedule, not on the chip"}
 
     cpu = None
     oracle_check = None

@@ -446,6 +446,11 @@ typedef struct {
 
 int ls_profile_begin(ls_model_t* m);
 int ls_profile_end(ls_model_t* m, ls_profile_entry* out_host, int max_entries, int* n_out_host);
+/* Exact-phase statistics of the k-NN graph builds of the profiled ls_encode calls since ls_profile_begin (call BEFORE ls_profile_end, or
+ * after it: the counters persist until the next ls_profile_begin): for encoder layer i, out_host[2 i] = candidates that were given a
+ * canonical distance beyond the hints, summed over queries and calls, out_host[2 i + 1] = queries (0 for layers that do not run the
+ * filter / exact-phase path).  bench.py derives the EXECUTED fp32 VALU work of the dominant k-NN launch from it (roofline.frac_hw). */
+int ls_profile_knn_stats(ls_model_t* m, unsigned long long* out_host, int max_layers);
 
 #ifdef __cplusplus
 }

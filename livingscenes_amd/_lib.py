@@ -112,6 +112,7 @@ SIGNATURES = {
     "ls_model_create": (_I, [ctypes.POINTER(ModelDesc), _P, ctypes.POINTER(_P)]),
     "ls_model_destroy": (None, [_P]),
     "ls_model_set_option": (_I, [_P, _I, _I]),
+    "ls_profile_knn_stats": (_I, [_P, ctypes.POINTER(ctypes.c_ulonglong), _I]),
     "ls_model_get_option": (_I, [_P, _I, ctypes.POINTER(ctypes.c_int)]),
     "ls_se3_transform_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "ls_smooth_l1_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),

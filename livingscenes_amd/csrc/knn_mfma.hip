@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
                                                                    const int32_t* __restrict__ dst_rows, const float* __restrict__ nrm_dst,
                                                                    const float* __restrict__ nrm_src, int Nd, int dst_n, int Ns, int ns_pad, int K,
                                                                    float epsS, const short* __restrict__ cosq, int32_t* __restrict__ idx_out,
-                                                                   float* __restrict__ dist_out, int total_q) {
+                                                                   float* __restrict__ dist_out, int total_q, int32_t* __restrict__ surv_cnt) {
     constexpr int RF = 3 * CC;
     constexpr int NV = KO_MAXNS / 64;
     __shared__ unsigned short llist[4][KO_MAXNS];
@@ -961,6 +961,7 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
         if (keep) sp[pos] = (unsigned short)j;
         cnt += __popcll(m);
     }
+    if (lane == 0) surv_cnt[qg] = cnt;    // how many candidates get a canonical distance: the exact-phase statistic (knn_sweep_stats_launch)
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the list is wave-private, LDS ops of a wave complete in order
     __builtin_amdgcn_wave_barrier();
     // 4. canonical keys of the survivors, 16 KO_US per step, sorted with the list so far by the 64-lane network
@@ -1081,10 +1082,10 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
             const int wblocks = cdiv((long long)nq, 4);
             if (fma)
                 hipLaunchKernelGGL((knn_finish_select_kernel<CC, true>), dim3(wblocks), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, ns_pad,
-                                   K, epsS, cosq, idx_out, dist_out, (int)nq);
+                                   K, epsS, cosq, idx_out, dist_out, (int)nq, surv_cnt);
             else
                 hipLaunchKernelGGL((knn_finish_select_kernel<CC, false>), dim3(wblocks), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, ns_pad,
-                                   K, epsS, cosq, idx_out, dist_out, (int)nq);
+                                   K, epsS, cosq, idx_out, dist_out, (int)nq, surv_cnt);
             LS_LAUNCH_CHECK();
             return LS_OK;
         }
@@ -1192,6 +1193,32 @@ int knn_sweep_launch(const float* dst, const float* src, const int32_t* dst_rows
     if (C == 32)
         return knn_sweep_launch_t<32>(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
     return knn_sweep_launch_t<64>(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
+}
+
+// Exact-phase statistics of the LAST sweep-path call that used `scratch` (bench.py's hardware-utilisation roofline; profiled passes only):
+// out[0] += sum over the queries of the candidates that were given a canonical distance BEYOND the hints (survivor lists; a query that
+// overflowed its list scanned all Ns), out[1] += the number of queries.  The counters sit where knn_sweep_launch_t put them.
+__global__ __launch_bounds__(256) void knn_stats_kernel(const int32_t* __restrict__ surv_cnt, long long nq, int Ns, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long long)gridDim.x * 256) {
+        const int c = surv_cnt[i];
+        s += (unsigned long long)(c > KS_CAP ? Ns : c);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[0], s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&out[1], (unsigned long long)nq);
+}
+int knn_sweep_stats_launch(const void* scratch, int B, int Nd, int dst_n, int Ns, unsigned long long* out, hipStream_t st) {
+    const size_t nq = (size_t)B * Nd;
+    size_t off = (size_t)B * Ns * sizeof(float) + (size_t)B * dst_n * sizeof(float);     // row norms            (layout of knn_sweep_launch_t)
+    off = (off + 255) & ~(size_t)255;
+    off += (size_t)B * Ns * sizeof(float) + (size_t)B * dst_n * sizeof(float);            // inverse row scales
+    off = (off + 255) & ~(size_t)255;
+    off += nq * 16 * sizeof(u64);                                                         // seed keys
+    hipLaunchKernelGGL(knn_stats_kernel, dim3((unsigned)std::min<size_t>(cdiv((long long)nq, 256), 256)), dim3(256), 0, st,
+                       (const int32_t*)((const char*)scratch + off), (long long)nq, Ns, out);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
 }
 
 int row_norms_launch(const float* f, int row_f, long long npts, float* norms, hipStream_t st) {

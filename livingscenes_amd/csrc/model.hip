@@ -24,6 +24,7 @@ int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int,
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags);
 int knn_compose_hints_launch(const int32_t* prev_knn, const int32_t* prev_rows, int B, int Nd, int Ns, int32_t* inv, int32_t* hints, hipStream_t st);
 bool knn_would_sweep(int C, int Ns, unsigned flags);
+int knn_sweep_stats_launch(const void* scratch, int B, int Nd, int dst_n, int Ns, unsigned long long* out, hipStream_t st);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, void*, size_t, hipStream_t);
 size_t fps_scratch_bytes_per_cloud(int N);
 int gemm_dispatch(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t, GemmAux aux = GemmAux());
@@ -132,6 +133,7 @@ struct ls_model {
     bool profiling = false;
     std::vector<ProfRec> prof;          // pending (un-collected) event pairs
     std::vector<hipEvent_t> ev_pool;    // recycled events
+    unsigned long long* knn_stats = nullptr;   // device [LS_MAX_LAYERS][2]: exact-phase statistics of the sweep-path k-NN layers, filled by profiled ls_encode calls only
     float prof_ms[LS_K_COUNT][16];
     int prof_n[LS_K_COUNT][16];
     std::vector<hipStream_t> prof_streams;
@@ -603,6 +605,8 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->knn_stats, sizeof(unsigned long long) * 2 * LS_MAX_LAYERS);
+    if (e == hipSuccess) e = hipMemset(m->knn_stats, 0, sizeof(unsigned long long) * 2 * LS_MAX_LAYERS);
     if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
     for (int i = desc->atten_start_layer; i < desc->num_layers && i >= 1; ++i) {
         const int Co = desc->feat_dim[i], Cin = layer_cin(*desc, i);
@@ -654,6 +658,7 @@ void ls_model_destroy(ls_model_t* m) {
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->knn_stats) (void)hipFree(m->knn_stats);
     for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : m->ev_pool) (void)hipEventDestroy(e);
@@ -805,6 +810,11 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 }
                 rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
             if (rc != LS_OK) return rc;
+            if (m->profiling && m->knn_stats && !(skip & SK_KNN) && knn_would_sweep(Cin, Ns, flags | (m->knn_filter ? 0u : LS_FLAG_KNN_VALU_ONLY))) {
+                // (outside the launch's event bracket) how many candidates got a canonical distance: ls_profile_knn_stats
+                rc = knn_sweep_stats_launch(ws + p.o_knns, B, Nd, Ns, Ns, m->knn_stats + 2 * i, st);
+                if (rc != LS_OK) return rc;
+            }
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if (skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) rc = LS_OK;
             else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm);
@@ -1310,7 +1320,18 @@ int ls_profile_begin(ls_model_t* m) {
     prof_collect(m);
     memset(m->prof_ms, 0, sizeof(m->prof_ms));
     memset(m->prof_n, 0, sizeof(m->prof_n));
+    if (m->knn_stats) LS_HIP_CHECK(hipMemset(m->knn_stats, 0, sizeof(unsigned long long) * 2 * LS_MAX_LAYERS));
     m->profiling = true;
+    return LS_OK;
+}
+
+int ls_profile_knn_stats(ls_model_t* m, unsigned long long* out_host, int max_layers) {
+    LS_REQUIRE(m && out_host && max_layers >= 1, "profile_knn_stats: null argument");
+    LS_REQUIRE(m->knn_stats, "profile_knn_stats: the handle has no statistics buffer");
+    for (auto s : m->prof_streams) (void)hipStreamSynchronize(s);
+    unsigned long long h[2 * LS_MAX_LAYERS];
+    LS_HIP_CHECK(hipMemcpy(h, m->knn_stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < std::min(max_layers, (int)LS_MAX_LAYERS); ++i) { out_host[2 * i] = h[2 * i]; out_host[2 * i + 1] = h[2 * i + 1]; }
     return LS_OK;
 }
 

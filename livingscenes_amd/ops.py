@@ -341,6 +341,12 @@ class HipModel:
         return [dict(kind=_lib.KERNEL_KINDS[buf[i].kind], layer=buf[i].layer, launches=buf[i].launches, total_ms=buf[i].total_ms)
                 for i in range(n.value)]
 
+    def profile_knn_stats(self):
+        """ls_profile_knn_stats -> {layer: (candidates given a canonical distance beyond the hints, queries)} of the profiled encode calls."""
+        buf = (ctypes.c_ulonglong * 16)()
+        check(load().ls_profile_knn_stats(self._h, buf, 8), "ls_profile_knn_stats")
+        return {i: (int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(8) if buf[2 * i + 1]}
+
     def n_levels(self):
         return [int(self.desc.down_factor[i]) for i in range(self.desc.num_layers)]
 
