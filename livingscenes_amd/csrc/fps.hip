@@ -137,14 +137,46 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ 
 }
 
 // Four waves per instance (N = 256 .. 2048): cloud and running min-distance in VGPRs (<= 8 points per thread), per-wave DPP
-// arg-max, the four wave maxima exchanged through a double-buffered LDS slot with ONE workgroup barrier per step.  A step is
-// ~PPT*8 VALU ops + the DPP network + ~2 LDS round trips: 4x shorter than the one-wave kernel's 16 points per lane at N = 1024
-// (the encoder's first down-sampling: 0.52 -> 0.18 ms), same arithmetic and tie rule.
+// arg-max, the four wave results exchanged through a double-buffered LDS slot with ONE workgroup barrier per step.  Same arithmetic
+// and tie rule as the one-wave kernel (the encoder's first down-sampling: 0.52 -> 0.18 ms when it replaced that kernel).
+// Round 4: a step's critical path was FIVE dependent LDS round trips (the winner's coordinates lp[last], the slot write, then the
+// four wave records read one after the other behind short-circuit branches) around ~120 VALU instructions: 0.61 - 0.65 us per step,
+// 1 460 cycles, of which ~500 were LDS latency.  Now the winning lane of every wave writes its record WITH the point's coordinates
+// {value, index, x, y | z}, every thread reads the four records in one batch of independent 16-byte broadcast reads after the barrier
+// and merges them branch-free: two round trips per step (write -> barrier, read), and lp[] is only the first sample's source.
+// One instruction per stage: the DPP permutation as the source modifier of v_max_f32 / v_min_u32 (hipcc emits v_mov_b32, s_nop, v_mov_b32_dpp,
+// a canonicalising v_max and the v_max per stage of the update_dpp form: 5 dependent issue slots; here 2 -- the s_nop 1 are the two wait states a
+// DPP read of a just-written VGPR needs, which nothing inserts inside an asm statement).  Lanes a row_bcast does not reach keep their value
+// (row_mask / bound_ctrl 0), so lane 63 ends up with the wave's maximum / minimum.
+__device__ __forceinline__ float wave_max_to_lane63(float v) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_to_lane63(unsigned v) {
+    asm("s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return v;
+}
+struct FpsRec { float v; unsigned i; float x, y; };
 template <int PPT, bool FMA>
 __global__ __launch_bounds__(256) void fps_quad_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
                                                        int N, int K, int32_t* __restrict__ idx_out, float* __restrict__ pts_out) {
     extern __shared__ __attribute__((aligned(16))) float lp[];  // [N][3]
-    __shared__ unsigned lmax[2][4][2];                          // [buffer][wave][hi, lo]
+    __shared__ __attribute__((aligned(16))) FpsRec lrec[2][4];  // [buffer][wave] {value, index, x, y}
+    __shared__ __attribute__((aligned(16))) float lz[2][4];     // [buffer][wave] z
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = pts + (size_t)b * N * 3;
     const int n = lengths ? min(lengths[b], N) : N;
@@ -162,51 +194,50 @@ __global__ __launch_bounds__(256) void fps_quad_kernel(const float* __restrict__
     }
     int32_t* out = idx_out + (size_t)b * K;
     float* po = pts_out ? pts_out + (size_t)b * K * 3 : nullptr;
-    int last = 0;
     const int kk = min(K, n);
+    float lx = lp[0], ly = lp[1], lz0 = lp[2];     // the first sample is point 0
     if (tid == 0 && n > 0) {
         out[0] = 0;
-        if (po) { po[0] = lp[0]; po[1] = lp[1]; po[2] = lp[2]; }
+        if (po) { po[0] = lx; po[1] = ly; po[2] = lz0; }
     }
     for (int k = 1; k < kk; ++k) {
-        const float lx = lp[last * 3 + 0], ly = lp[last * 3 + 1], lz = lp[last * 3 + 2];
-        float bv = -INFINITY;
+        float bv = -INFINITY, bx = 0.f, by = 0.f, bz = 0.f;
         int bi = INT_MAX;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const float d = dist3<FMA>(lx, ly, lz, px[i], py[i], pz[i]);
+            const float d = dist3<FMA>(lx, ly, lz0, px[i], py[i], pz[i]);
             const float m = fminf(md[i], d);
             md[i] = (md[i] == -INFINITY) ? md[i] : m;
-            if (md[i] > bv) { bv = md[i]; bi = i * 256 + tid; }  // ascending index inside the thread: strict '>'
+            const bool up = md[i] > bv;                          // ascending index inside the thread: strict '>'
+            bv = up ? md[i] : bv; bi = up ? i * 256 + tid : bi;
+            bx = up ? px[i] : bx; by = up ? py[i] : by; bz = up ? pz[i] : bz;
         }
-        // wave arg-max in two single-instruction-per-stage DPP reductions (the compiler folds the DPP move into v_max_f32 /
-        // v_min_u32): the maximum value, then the smallest index among the lanes that hold it.  (The 64-bit key network of the
-        // one-wave kernel costs ~8 dependent instructions per stage.)
-        float wm = bv;
-        wm = fmaxf(wm, dpp_f<0xB1, 0xF>(wm)); wm = fmaxf(wm, dpp_f<0x4E, 0xF>(wm));
-        wm = fmaxf(wm, dpp_f<0x141, 0xF>(wm)); wm = fmaxf(wm, dpp_f<0x140, 0xF>(wm));
-        wm = fmaxf(wm, dpp_f<0x142, 0xA>(wm)); wm = fmaxf(wm, dpp_f<0x143, 0xC>(wm));
-        const float wmax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(wm), 63));
-        unsigned ci = (bv == wmax) ? (unsigned)bi : 0xFFFFFFFFu;
-        ci = min(ci, dpp_u<0xB1, 0xF>(ci)); ci = min(ci, dpp_u<0x4E, 0xF>(ci));
-        ci = min(ci, dpp_u<0x141, 0xF>(ci)); ci = min(ci, dpp_u<0x140, 0xF>(ci));
-        ci = min(ci, dpp_u<0x142, 0xA>(ci)); ci = min(ci, dpp_u<0x143, 0xC>(ci));
-        if (lane == 63) { lmax[k & 1][wave][0] = __float_as_uint(wmax); lmax[k & 1][wave][1] = ci; }
-        __syncthreads();
-        float bh = __uint_as_float(lmax[k & 1][0][0]);
-        unsigned bl = lmax[k & 1][0][1];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float oh = __uint_as_float(lmax[k & 1][w][0]);
-            const unsigned ol = lmax[k & 1][w][1];
-            const bool take = oh > bh || (oh == bh && ol < bl);
-            bh = take ? oh : bh;
-            bl = take ? ol : bl;
+        // wave arg-max in two single-instruction-per-stage DPP reductions: the maximum value, then the smallest index among the lanes that
+        // hold it.  (The 64-bit key network of the one-wave kernel costs ~8 dependent instructions per stage.)
+        const float wmax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(wave_max_to_lane63(bv)), 63));
+        const unsigned wci = (unsigned)__builtin_amdgcn_readlane((int)wave_min_to_lane63((bv == wmax) ? (unsigned)bi : 0xFFFFFFFFu), 63);
+        // the lane that holds the wave's winner publishes it (a wave without a live point: every lane holds (-inf, INT_MAX) and writes the
+        // same record, which loses against any live point)
+        if ((unsigned)bi == wci && bv == wmax) {
+            lrec[k & 1][wave] = FpsRec{wmax, wci, bx, by};
+            lz[k & 1][wave] = bz;
         }
-        last = (int)bl;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the global stores below stay in flight across steps
+        const FpsRec r0 = lrec[k & 1][0], r1 = lrec[k & 1][1], r2 = lrec[k & 1][2], r3 = lrec[k & 1][3];
+        const float4 zz = *reinterpret_cast<const float4*>(lz[k & 1]);
+        // branch-free merge, larger value first, then smaller index: (0, 1) and (2, 3) side by side, then the two winners
+        const bool t01 = (r1.v > r0.v) | ((r1.v == r0.v) & (r1.i < r0.i));
+        const bool t23 = (r3.v > r2.v) | ((r3.v == r2.v) & (r3.i < r2.i));
+        const float av = t01 ? r1.v : r0.v, cv = t23 ? r3.v : r2.v;
+        const unsigned ai = t01 ? r1.i : r0.i, cix = t23 ? r3.i : r2.i;
+        const float ax = t01 ? r1.x : r0.x, ay = t01 ? r1.y : r0.y, az = t01 ? zz.y : zz.x;
+        const float cx = t23 ? r3.x : r2.x, cy = t23 ? r3.y : r2.y, cz = t23 ? zz.w : zz.z;
+        const bool tf = (cv > av) | ((cv == av) & (cix < ai));
+        const int last = (int)(tf ? cix : ai);
+        lx = tf ? cx : ax; ly = tf ? cy : ay; lz0 = tf ? cz : az;
         if (tid == 0) {
             out[k] = last;
-            if (po) { po[k * 3 + 0] = lp[last * 3 + 0]; po[k * 3 + 1] = lp[last * 3 + 1]; po[k * 3 + 2] = lp[last * 3 + 2]; }
+            if (po) { po[k * 3 + 0] = lx; po[k * 3 + 1] = ly; po[k * 3 + 2] = lz0; }
         }
     }
     for (int k = max(kk, 0) + tid; k < K; k += 256) {

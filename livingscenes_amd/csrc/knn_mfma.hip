@@ -577,6 +577,103 @@ __global__ __launch_bounds__(256) void knn_prep_f16_kernel(const float* __restri
     if (h == 0 && live) { norms[(size_t)b * N + r] = s; iscale[(size_t)b * N + r] = __uint_as_float((be - 14u) << 23); }
 }
 
+// Round 4: the same image, one WORKGROUP per 32-row tile.  The one-wave form walks a row twice (maximum, then scale + convert) in KK dependent
+// steps of two loads each and leaves 2 waves per SIMD on the chip at the encoder's shapes (2 048 tiles): 17.5 us per layer for 25 MB in and
+// 12.5 MB out, i.e. latency, not bandwidth.  Here the WPT waves of a workgroup take KK / WPT k-steps each, every load of a wave is issued
+// up front and the row stays in registers; the row maximum and the squared norm are combined through LDS (two barriers).  Same centre (the
+// mean of the first min(Nc, 16) rows in the same summation order), same scale, same f16 values; the norm is summed in a different order
+// (per wave, then over the waves ascending), which the filter's margin covers like any other fp32 rounding of the norms.
+template <int KK, int WPT>
+__global__ __launch_bounds__(64 * WPT) void knn_prep_f16_tile_kernel(const float* __restrict__ f, const float* __restrict__ fc, int Nc, int N, int Npad,
+                                                                    unsigned short* __restrict__ out, float* __restrict__ norms, float* __restrict__ iscale,
+                                                                    int32_t* __restrict__ zero_buf, long long zero_n) {
+    constexpr int D = KK * 16, KPW = KK / WPT, DW = KPW * 16;     // dims of one wave
+    static_assert(KK % WPT == 0 && DW <= 64, "a wave's dims fit one lane each for the centre");
+    __shared__ __attribute__((aligned(16))) float lmu[WPT][64];
+    __shared__ float lamax[WPT][32], lsum[WPT][32];
+    for (long long i = (long long)blockIdx.x * (64 * WPT) + threadIdx.x; i < zero_n; i += (long long)gridDim.x * (64 * WPT)) zero_buf[i] = 0;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, h = lane >> 5;
+    const int tpi = Npad >> 5, b = blockIdx.x / tpi, tile = blockIdx.x % tpi, r = tile * 32 + j;
+    const bool live = r < N;
+    // the row's share of this wave: dims w * DW + kk * 16 + h * 8 .. + 7, all loads in flight before the centre arrives
+    const float* rp = f + ((size_t)b * N + (live ? r : 0)) * D + w * DW + h * 8;
+    float4 x[KPW][2];
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) { x[kk][0] = *reinterpret_cast<const float4*>(rp + kk * 16); x[kk][1] = *reinterpret_cast<const float4*>(rp + kk * 16 + 4); }
+    {   // centre of this wave's dims (lane l: dim w * DW + l), summation order of knn_prep_f16_kernel
+        const int nc = min(Nc, KNN_CENTRE_ROWS);
+        const float* cp = fc + (size_t)b * Nc * D + w * DW + lane;
+        if (lane < DW) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int rr = 0; rr + 3 < nc; rr += 4) {
+                s0 += cp[(size_t)rr * D]; s1 += cp[(size_t)(rr + 1) * D]; s2 += cp[(size_t)(rr + 2) * D]; s3 += cp[(size_t)(rr + 3) * D];
+            }
+            for (int rr = nc & ~3; rr < nc; ++rr) s0 += cp[(size_t)rr * D];
+            lmu[w][lane] = ((s0 + s1) + (s2 + s3)) / (float)nc;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the slot is wave-private
+        __builtin_amdgcn_wave_barrier();
+    }
+    float c[KPW][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+        const float4 m0 = *reinterpret_cast<const float4*>(&lmu[w][kk * 16 + h * 8]), m1 = *reinterpret_cast<const float4*>(&lmu[w][kk * 16 + h * 8 + 4]);
+        const float4 x0 = x[kk][0], x1 = x[kk][1];
+        const float t[8] = {x0.x - m0.x, x0.y - m0.y, x0.z - m0.z, x0.w - m0.w, x1.x - m1.x, x1.y - m1.y, x1.z - m1.z, x1.w - m1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c[kk][i] = live ? t[i] : 0.f; amax = fmaxf(amax, fabsf(t[i])); }
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    if (h == 0) lamax[w][j] = amax;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) amax = fmaxf(amax, lamax[u][j]);
+    unsigned be = (__float_as_uint(amax) >> 23) & 0xffu;
+    be = be < 15u ? 15u : be;
+    const float sc = live ? __uint_as_float((268u - be) << 23) : 0.f;
+    unsigned short* op = out + ((((size_t)b * tpi + tile) * KK + w * KPW) * 64 + lane) * 8;
+    float s = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+        unsigned pk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float c0 = c[kk][2 * i], c1 = c[kk][2 * i + 1];
+            s += c0 * c0 + c1 * c1;
+            const kh2_t hv = __builtin_convertvector(kf2_t{c0 * sc, c1 * sc}, kh2_t);     // round to nearest even
+            pk[i] = __builtin_bit_cast(unsigned, hv);
+        }
+        uint4 wv;
+        wv.x = pk[0]; wv.y = pk[1]; wv.z = pk[2]; wv.w = pk[3];
+        *reinterpret_cast<uint4*>(op + (size_t)kk * 512) = wv;
+    }
+    s += __shfl_xor(s, 32, 64);
+    if (h == 0) lsum[w][j] = s;
+    __syncthreads();
+    if (w == 0 && h == 0 && live) {
+        float t = lsum[0][j];
+#pragma unroll
+        for (int u = 1; u < WPT; ++u) t += lsum[u][j];
+        norms[(size_t)b * N + r] = t;
+        iscale[(size_t)b * N + r] = __uint_as_float((be - 14u) << 23);
+    }
+}
+// the image of `f` ([B, N, D] rows, centre from fc): tile kernel for the encoder's row widths, the one-wave kernel otherwise / for A/B (LS_KNN_PREP_WAVE=1)
+static int knn_prep_launch(const float* f, const float* fc, int Nc, int B, int N, int Npad, int D, unsigned short* out, float* norms, float* iscale,
+                           int32_t* zero_buf, long long zero_n, hipStream_t st) {
+    static const bool wave_form = getenv("LS_KNN_PREP_WAVE") && atoi(getenv("LS_KNN_PREP_WAVE")) != 0;
+    const int tiles = B * (Npad / 32);
+    if (D == 96 && !wave_form)
+        hipLaunchKernelGGL((knn_prep_f16_tile_kernel<6, 3>), dim3(tiles), dim3(192), 0, st, f, fc, Nc, N, Npad, out, norms, iscale, zero_buf, zero_n);
+    else if (D == 192 && !wave_form)
+        hipLaunchKernelGGL((knn_prep_f16_tile_kernel<12, 4>), dim3(tiles), dim3(256), 0, st, f, fc, Nc, N, Npad, out, norms, iscale, zero_buf, zero_n);
+    else
+        hipLaunchKernelGGL(knn_prep_f16_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, f, fc, Nc, N, Npad, D, tiles, out, norms, iscale, zero_buf, zero_n);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
 // QG (round 3, A/B only -- LS_KNN_SWEEP_QG=2): a wave sweeps QG groups of 32 queries against every candidate fragment it loads, which
 // halves the L2 -> CU stream of the candidate image (layer 1: 2 048 waves x 196 KB = 403 MB per launch with one group).  Measured slower
 // (see knn_sweep_launch_t): the kernel is latency-, not stream-bound.  One group is the default.
@@ -1058,13 +1155,11 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     if (f16img) {
         static_assert(D <= 192, "knn_prep_f16_kernel keeps the centre in a 192-float LDS slot per wave");
         (void)mu;
-        hipLaunchKernelGGL(knn_prep_f16_kernel, dim3(cdiv(B * (ns_pad / 32), 4)), dim3(256), 0, st, src, src, Ns, Ns, ns_pad, D,
-                           B * (ns_pad / 32), sq, nsrc, isrc, surv_cnt, (long long)nq);
-        LS_LAUNCH_CHECK();
+        rc = knn_prep_launch(src, src, Ns, B, Ns, ns_pad, D, sq, nsrc, isrc, surv_cnt, (long long)nq, st);
+        if (rc != LS_OK) return rc;
         if (dst != src) {   // same centre for both sets: the candidates' first rows
-            hipLaunchKernelGGL(knn_prep_f16_kernel, dim3(cdiv(B * (dst_npad / 32), 4)), dim3(256), 0, st, dst, src, Ns, dst_n, dst_npad, D,
-                               B * (dst_npad / 32), dq, ndst, idst, (int32_t*)nullptr, 0LL);
-            LS_LAUNCH_CHECK();
+            rc = knn_prep_launch(dst, src, Ns, B, dst_n, dst_npad, D, dq, ndst, idst, (int32_t*)nullptr, 0LL, st);
+            if (rc != LS_OK) return rc;
         }
         static const bool one_sweep_on = !(getenv("LS_KNN_ONE_SWEEP") && atoi(getenv("LS_KNN_ONE_SWEEP")) == 0);   // A/B: the two-sweep auto-hint path
         if (!seed_idx && one_sweep_on && ns_pad <= KO_MAXNS && K <= 16) {   // un-seeded, few candidates: one sweep + one finish (see above)
