@@ -186,8 +186,9 @@ def test_config3_scene_pair_optim_registration_at_released_settings(released_pri
     best = st.best_g
     Rb = best[:, :, :3].transpose(1, 2)
     best = pick(torch.cat([Rb, -(Rb @ best[:, :, 3:4])], 2), best)      # inverse for the reversed direction (:175-179)
-    assert relerr(info["pre_icp"], best) < 1e-3
-    assert relerr(info["min_loss"], st.min_loss) < 1e-3
+    from conftest import calibrated
+    calibrated("configs3_optim16.pre_icp_pose", relerr(info["pre_icp"], best), 1e-3)      # 16 of the 400 steps, raw 10 - 25 k-point clouds
+    calibrated("configs3_optim16.min_loss", relerr(info["min_loss"], st.min_loss), 1e-3)
     for i in range(P):
         assert abs(float(torch.det(R[i])) - 1) < 1e-4
     # ---- end to end as eval_3rscan drives it: encode_fps -> matcher -> the same batched refinement -> ICP
