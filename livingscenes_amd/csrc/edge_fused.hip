@@ -1,0 +1,503 @@
+// edge_fused.hip -- attention layers with FEW points per instance (released encoder: layers 5 and 6, 32 destination points, 128 / 32 source
+// points, 128 -> 256 and 256 -> 512 channels): the folded VN-Linear tables are never written to memory.
+//
+// Replaces, for those layers, the table GEMM (gemm.hip) + edge_attn_v4_kernel (edge.hip) pair behind
+//   /root/reference/lib_shape_prior/core/lib/vec_sim3/vec_dgcnn_atten.py:196-219   (get_graph_feature, V / K / Q VecLNA, QK soft-max attention)
+//   /root/reference/lib_shape_prior/core/lib/vec_sim3/vec_layers.py:24-31,121-136,241-268   (cevn, VecLinear, VecActivation)
+//
+// Round 3 measured those two layers at 270 us of a 1.3 ms step: the table of layer 6 is 6 144 rows x 5 120 columns = 126 MB written by a
+// K = 256 GEMM (96 us: short main loop, 256 KB epilogue per tile, 20 % of the matrix peak) and read back once by the attention kernel
+// (54 us); layer 5 the same with 138 MB.  An instance of these layers is 32 x 3 (or 128 x 3) feature rows: a workgroup that owns
+// (instance, HG heads) can form its table slice -- [rows] x [lin 16 | dir 16] columns per head and column-group pair -- with the f16 matrix
+// cores straight into LDS and consume it there.  What keeps one workgroup from doing the whole layer is channel_equi_vec_normalize: the K
+// feature of an edge is normalised by its Frobenius norm over ALL channels (vec_layers.py:24-31), i.e. over all heads.  Hence two launches:
+//   edge_ft_qk_kernel   q = VecLNA_Q(dst), k = VecLNA_K(edge): per head the raw scores sum_c <k_c, q_c> and the partial squared norms |k|^2_head,
+//                       |q|^2_head -> small global arrays [instance][head][point][neighbour]
+//   edge_ft_v_kernel    sums the partial norms over the heads (ascending head order: deterministic), soft-max over the 16 neighbours,
+//                       v = VecLNA_V(edge) from its own table slice, weighted sum -> out [B, Nd, 3, Co] (+ per-head-group row maxima for the
+//                       GEMM that reads `out`)
+// Operands: both MFMA operands arrive FRAGMENT-MAJOR (one coalesced 1 KB load per 32 x 16 operand block): the weights are split once per model
+// (edge_ft_presplit_w_kernel: tile = (head, column-group pair), rows [lin 16 | dir 16], per-row power-of-two scale), the feature rows once per
+// layer call (edge_ft_prep_a_kernel: per-row power-of-two scale, (hi, lo) f16 planes) -- the same two-piece split, the same three products per
+// 16 k in the same order (l_a h_w, h_a h_w, h_a l_w) into one fp32 accumulator, ascending k, and the same integer-exponent scale in the epilogue as
+// gemm.hip, so a table entry formed here is bit-identical to the one a non-split-K table GEMM writes.  The attention arithmetic uses the
+// helpers of edge.hip (vn_act, dot43, fma43: every multiply-add spelled as an fma); what differs from edge_attn_v4_kernel is the ORDER in which
+// the squared norms are summed over the channels (per head by a DPP quad sum, then over the heads ascending, instead of one 64-lane tree).
+#include "ls_common.h"
+
+namespace ls {
+
+constexpr int FK = 16;            // neighbours per point
+constexpr int FND = 32;           // destination points per instance (the fused path's shape: layers 5 / 6 of the released schedule)
+typedef _Float16 fh8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 fh2_t __attribute__((ext_vector_type(2)));
+typedef float ff2_t __attribute__((ext_vector_type(2)));
+typedef float ff16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void fsplit_pair(ff2_t v, unsigned& h, unsigned& l) {
+    const fh2_t hv = __builtin_convertvector(v, fh2_t);
+    const fh2_t lv = __builtin_convertvector(v - __builtin_convertvector(hv, ff2_t), fh2_t);
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, lv);
+}
+// exact powers of two: s * amax in [2^14, 2^15), e = exponent of 1 / s  (gemm.hip: pow2_scale / pow2_e)
+__device__ __forceinline__ void fpow2(float amax, float& s, int& e_inv) {
+    unsigned be = (__float_as_uint(amax) >> 23) & 0xffu;
+    be = be < 15u ? 15u : be;
+    s = __uint_as_float((268u - be) << 23);
+    e_inv = (int)be - 14 - 127;
+}
+template <int CTRL>
+__device__ __forceinline__ float fdpp_max(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
+template <int CTRL>
+__device__ __forceinline__ float fdpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float fquad_sum(float v) { return fdpp_add<0x4E>(fdpp_add<0xB1>(v)); }
+__device__ __forceinline__ float fquad_max(float v) { return fdpp_max<0x4E>(fdpp_max<0xB1>(v)); }
+__device__ __forceinline__ float finv_fro(float ss) { return __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f)); }
+
+// ---------------------------------------------------------------------------------------------------------------- operand images
+// Weight tiles.  W [10 Co][Cin] (column groups PV_lin PV_dir PK_lin PK_dir QV_lin QV_dir QK_lin QK_dir Qq_lin Qq_dir, edge.hip header).
+// Tile T = head * 5 + p, p in {0 PV, 1 PK, 2 QV, 3 QK, 4 Qq}: its 32 rows are [lin: W row 2p Co + 16 head + 0..15 | dir: W row (2p+1) Co + 16 head + 0..15].
+// planes [T][ks][hi, lo][64 lanes] x 16 B (lane = row + 32 (k / 8 & 1), eight consecutive k), wexp [T * 32] = exponent of the row's inverse scale.
+__global__ __launch_bounds__(64) void edge_ft_presplit_w_kernel(const float* __restrict__ W, int Co, int Cin, int KS, uint4* __restrict__ planes,
+                                                                int* __restrict__ wexp) {
+    const int T = blockIdx.x / KS, ks = blockIdx.x % KS, lane = threadIdx.x;
+    const int head = T / 5, p = T % 5, r = lane & 31;
+    const float* wr = W + ((size_t)(2 * p + (r >> 4)) * Co + 16 * head + (r & 15)) * Cin;
+    float am = 0.f;
+    for (int c = 0; c < Cin; ++c) am = fmaxf(am, fabsf(wr[c]));
+    float sc;
+    int e;
+    fpow2(am, sc, e);
+    if (ks == 0 && lane < 32) wexp[T * 32 + r] = e;
+    const int k = ks * 16 + 8 * (lane >> 5);
+    uint4 h, l;
+    fsplit_pair(ff2_t{wr[k] * sc, wr[k + 1] * sc}, h.x, l.x);
+    fsplit_pair(ff2_t{wr[k + 2] * sc, wr[k + 3] * sc}, h.y, l.y);
+    fsplit_pair(ff2_t{wr[k + 4] * sc, wr[k + 5] * sc}, h.z, l.z);
+    fsplit_pair(ff2_t{wr[k + 6] * sc, wr[k + 7] * sc}, h.w, l.w);
+    planes[((size_t)blockIdx.x * 2) * 64 + lane] = h;
+    planes[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = l;
+}
+size_t edge_ft_w_bytes(int Co, int Cin) { return (size_t)(Co / 16) * 5 * (Cin / 16) * 2 * 64 * sizeof(uint4) + (size_t)(Co / 16) * 5 * 32 * sizeof(int); }
+int edge_ft_presplit_w_launch(const float* W, int Co, int Cin, void* planes, hipStream_t st) {
+    const int tiles = (Co / 16) * 5, KS = Cin / 16;
+    hipLaunchKernelGGL(edge_ft_presplit_w_kernel, dim3(tiles * KS), dim3(64), 0, st, W, Co, Cin, KS, (uint4*)planes,
+                       (int*)((uint4*)planes + (size_t)tiles * KS * 128));
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+
+// Feature rows -> A planes.  Output row R (tile R / 32): source row = rows ? (b Ns + rows[b Nd + n]) 3 + x with (b, n, x) from R : R.
+// One workgroup per 32-row tile, its four waves take KS / 4 k-steps each (every load up front, the row maximum combined through LDS).
+// planes [tile][ks][hi, lo][64 lanes] x 16 B, aexp [tile * 32 + row] = exponent of the row's inverse power-of-two scale.
+template <int KS>
+__global__ __launch_bounds__(256) void edge_ft_prep_a_kernel(const float* __restrict__ cur, const int32_t* __restrict__ rows, int Ns, int Nd,
+                                                             uint4* __restrict__ planes, int* __restrict__ aexp) {
+    constexpr int CIN = KS * 16, KPW = KS / 4;
+    __shared__ float lmax[4][32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int R = blockIdx.x * 32 + j;
+    size_t src = (size_t)R;
+    if (rows) {
+        const int x = R % 3, pn = R / 3, b = pn / Nd;
+        src = ((size_t)b * Ns + rows[pn]) * 3 + x;
+    }
+    const float* rp = cur + src * CIN + (w * KPW) * 16 + h * 8;
+    float4 v[KPW][2];
+    float am = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+        v[kk][0] = *reinterpret_cast<const float4*>(rp + kk * 16);
+        v[kk][1] = *reinterpret_cast<const float4*>(rp + kk * 16 + 4);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(v[kk][u].x), fabsf(v[kk][u].y)), fmaxf(fabsf(v[kk][u].z), fabsf(v[kk][u].w))));
+    am = fmaxf(am, __shfl_xor(am, 32, 64));
+    if (h == 0) lmax[w][j] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(lmax[0][j], lmax[1][j]), fmaxf(lmax[2][j], lmax[3][j]));
+    float sc;
+    int e;
+    fpow2(am, sc, e);
+    if (w == 0 && h == 0) aexp[R] = e;
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+        uint4 hh, ll;
+        fsplit_pair(ff2_t{v[kk][0].x * sc, v[kk][0].y * sc}, hh.x, ll.x);
+        fsplit_pair(ff2_t{v[kk][0].z * sc, v[kk][0].w * sc}, hh.y, ll.y);
+        fsplit_pair(ff2_t{v[kk][1].x * sc, v[kk][1].y * sc}, hh.z, ll.z);
+        fsplit_pair(ff2_t{v[kk][1].z * sc, v[kk][1].w * sc}, hh.w, ll.w);
+        uint4* op = planes + (((size_t)blockIdx.x * KS + w * KPW + kk) * 2) * 64 + lane;
+        op[0] = hh;
+        op[64] = ll;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- shared pieces
+struct FT43 { float4 x, y, z; };
+__device__ __forceinline__ FT43 ft_lds43(const float* p, int sld) {
+    FT43 r;
+    r.x = *reinterpret_cast<const float4*>(p);
+    r.y = *reinterpret_cast<const float4*>(p + sld);
+    r.z = *reinterpret_cast<const float4*>(p + 2 * sld);
+    return r;
+}
+__device__ __forceinline__ FT43 ft_add43(const FT43& a, const FT43& b) {
+    FT43 r;
+    r.x = make_float4(a.x.x + b.x.x, a.x.y + b.x.y, a.x.z + b.x.z, a.x.w + b.x.w);
+    r.y = make_float4(a.y.x + b.y.x, a.y.y + b.y.y, a.y.z + b.y.z, a.y.w + b.y.w);
+    r.z = make_float4(a.z.x + b.z.x, a.z.y + b.z.y, a.z.z + b.z.z, a.z.w + b.z.w);
+    return r;
+}
+__device__ __forceinline__ void ft_act43(FT43& y, const FT43& k, float oms) {
+    vn_act(y.x.x, y.y.x, y.z.x, k.x.x, k.y.x, k.z.x, oms);
+    vn_act(y.x.y, y.y.y, y.z.y, k.x.y, k.y.y, k.z.y, oms);
+    vn_act(y.x.z, y.y.z, y.z.z, k.x.z, k.y.z, k.z.z, oms);
+    vn_act(y.x.w, y.y.w, y.z.w, k.x.w, k.y.w, k.z.w, oms);
+}
+// (explicit fma chain, the order of edge.hip's dot43)
+__device__ __forceinline__ float ft_dot43(const FT43& a, const FT43& b) {
+    float s = a.x.x * b.x.x;
+    s = __builtin_fmaf(a.y.x, b.y.x, s); s = __builtin_fmaf(a.z.x, b.z.x, s);
+    s = __builtin_fmaf(a.x.y, b.x.y, s); s = __builtin_fmaf(a.y.y, b.y.y, s); s = __builtin_fmaf(a.z.y, b.z.y, s);
+    s = __builtin_fmaf(a.x.z, b.x.z, s); s = __builtin_fmaf(a.y.z, b.y.z, s); s = __builtin_fmaf(a.z.z, b.z.z, s);
+    s = __builtin_fmaf(a.x.w, b.x.w, s); s = __builtin_fmaf(a.y.w, b.y.w, s); s = __builtin_fmaf(a.z.w, b.z.w, s);
+    return s;
+}
+__device__ __forceinline__ void ft_fma43(FT43& acc, float w, const FT43& y) {
+    acc.x.x = __builtin_fmaf(w, y.x.x, acc.x.x); acc.x.y = __builtin_fmaf(w, y.x.y, acc.x.y); acc.x.z = __builtin_fmaf(w, y.x.z, acc.x.z); acc.x.w = __builtin_fmaf(w, y.x.w, acc.x.w);
+    acc.y.x = __builtin_fmaf(w, y.y.x, acc.y.x); acc.y.y = __builtin_fmaf(w, y.y.y, acc.y.y); acc.y.z = __builtin_fmaf(w, y.y.z, acc.y.z); acc.y.w = __builtin_fmaf(w, y.y.w, acc.y.w);
+    acc.z.x = __builtin_fmaf(w, y.z.x, acc.z.x); acc.z.y = __builtin_fmaf(w, y.z.y, acc.z.y); acc.z.z = __builtin_fmaf(w, y.z.z, acc.z.z); acc.z.w = __builtin_fmaf(w, y.z.w, acc.z.w);
+}
+
+// One "job" of a phase: slab[rows of the instance][HG heads x (lin 16 | dir 16)] = A rows . W tile^T for weight pair `p` of the workgroup's heads.
+//   A: the instance's M-tiles mt0 .. mt0 + MT of an A-plane image; W: tile (head0 + hl) * 5 + p.
+// The flattened (head-local, M-tile) list of every job of a phase is cut into four contiguous pieces, one per wave; a wave keeps the W
+// fragments of its current tile in registers (KS x 8 VGPRs) and streams the A fragments (2 KB per k-step, coalesced, L2-resident).
+template <int KS>
+struct FtJob { const uint4* a_planes; const int* a_exp; int mt0; int MT; int p; float* slab; int sld; };
+
+template <int KS, int HG, int NJ>
+__device__ __forceinline__ void ft_gemm_phase(const FtJob<KS> (&jobs)[NJ], const uint4* __restrict__ wplanes, const int* __restrict__ wexp, int head0,
+                                              int wave, int lane) {
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) total += jobs[j].MT * HG;
+    const int per = (total + 3) / 4;
+    const int lo = wave * per, hi = min(total, lo + per);
+    fh8_t bh[KS], bl[KS];
+    int cur_tile = -1;
+    int we = 0;
+    for (int t = lo; t < hi; ++t) {
+        // locate (job, head-local, M-tile) of flat item t: jobs in order, inside a job head-major
+        int j = 0, off = t;
+#pragma unroll
+        for (int q = 0; q < NJ - 1; ++q)
+            if (j == q && off >= jobs[q].MT * HG) { off -= jobs[q].MT * HG; j = q + 1; }
+        FtJob<KS> jb = jobs[0];
+#pragma unroll
+        for (int q = 1; q < NJ; ++q)
+            if (j == q) jb = jobs[q];
+        const int hl = off / jb.MT, mt = off - hl * jb.MT;
+        const int T = (head0 + hl) * 5 + jb.p;
+        if (T != cur_tile) {   // wave-uniform
+            cur_tile = T;
+            const uint4* wp = wplanes + ((size_t)T * KS * 2) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bh[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2) * 64]);
+                bl[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2 + 1) * 64]);
+            }
+            we = wexp[T * 32 + (lane & 31)];
+        }
+        const uint4* ap = jb.a_planes + ((size_t)(jb.mt0 + mt) * KS * 2) * 64 + lane;
+        ff16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const fh8_t ah = __builtin_bit_cast(fh8_t, ap[(size_t)(ks * 2) * 64]);
+            const fh8_t al = __builtin_bit_cast(fh8_t, ap[(size_t)(ks * 2 + 1) * 64]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+        }
+        // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const int row0 = 32 * mt + 4 * (lane >> 5);
+        float* sp = jb.slab + (size_t)row0 * jb.sld + hl * 32 + (lane & 31);
+        const int* ae = jb.a_exp + (jb.mt0 + mt) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            sp[dr * jb.sld] = __builtin_ldexpf(acc[r], ae[dr] + we);
+        }
+    }
+}
+
+// thread -> (point, head-local, quad lane, neighbour range) of the attention phases: 256 threads = 32 points x HG heads x 4 lanes x (2 / HG) neighbour halves
+template <int HG>
+struct FtMap {
+    int n, hl, ql, k0, kn;
+    __device__ __forceinline__ FtMap(int tid) {
+        ql = tid & 3;
+        const int idx = tid >> 2;   // 0 .. 63
+        n = idx >> 1;
+        if constexpr (HG == 2) { hl = idx & 1; k0 = 0; kn = FK; }
+        else { hl = 0; k0 = (idx & 1) * (FK / 2); kn = FK / 2; }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- kernel 1: q and k
+// grid = (Co / 16 / HG) x B workgroups, head-group major (the workgroups of one head group -- one W slice -- are neighbours on an XCD).
+// NS = source points per instance (32: destination set == source set, one A image; 128: destination points selected by dst_rows, own A image).
+template <int CIN, int NS, int HG>
+__global__ __launch_bounds__(256) void edge_ft_qk_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
+                                                         const int* __restrict__ ae_q, const uint4* __restrict__ wplanes, const int* __restrict__ wexp,
+                                                         const int32_t* __restrict__ knn, int B, int H, float oms, float* __restrict__ scores,
+                                                         float* __restrict__ sskp, float* __restrict__ ssqp) {
+    constexpr int KS = CIN / 16, MTP = NS * 3 / 32, MTQ = FND * 3 / 32, SLD = HG * 32 + 4;
+    __shared__ __attribute__((aligned(16))) float slab_q[FND * 3 * SLD];    // q phase: Qq (lin | dir); k phase: QK (lin | dir) of the destination points
+    __shared__ __attribute__((aligned(16))) float slab_p[NS * 3 * SLD];     // k phase: PK (lin | dir) of the source points
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int hg = logical / B, b = logical - hg * B, head0 = hg * HG;
+    const FtMap<HG> mp(tid);
+    const int head = head0 + mp.hl;
+
+    // ---- q = VecLNA_Q(dst_f[n]) of the workgroup's heads (vec_dgcnn_atten.py:207,210)
+    {
+        const FtJob<KS> jq[1] = {{a_q, ae_q, b * MTQ, MTQ, 4, slab_q, SLD}};
+        ft_gemm_phase<KS, HG, 1>(jq, wplanes, wexp, head0, wave, lane);
+    }
+    __syncthreads();
+    const int c4 = mp.hl * 32 + mp.ql * 4;
+    FT43 qf = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4, SLD);
+    {
+        const FT43 kd = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4 + 16, SLD);
+        ft_act43(qf, kd, oms);
+    }
+    const float ssq = fquad_sum(ft_dot43(qf, qf));
+    if (mp.ql == 0 && mp.k0 == 0) ssqp[((size_t)b * H + head) * FND + mp.n] = ssq;
+    int nb[FK];
+    {
+        const int4* kp = reinterpret_cast<const int4*>(knn + ((size_t)b * FND + mp.n) * FK + mp.k0);
+#pragma unroll
+        for (int u = 0; u < FK / 4; ++u)
+            if (4 * u < mp.kn) { const int4 v = kp[u]; nb[4 * u] = v.x; nb[4 * u + 1] = v.y; nb[4 * u + 2] = v.z; nb[4 * u + 3] = v.w; }
+    }
+    __syncthreads();   // every thread holds its q: slab_q may be overwritten
+
+    // ---- k = VecLNA_K(E[n, k]) = act(PK_lin[nbr] + QK_lin[n], PK_dir[nbr] + QK_dir[n])  (:206,209)
+    {
+        const FtJob<KS> jk[2] = {{a_p, ae_p, b * MTP, MTP, 1, slab_p, SLD}, {a_q, ae_q, b * MTQ, MTQ, 3, slab_q, SLD}};
+        ft_gemm_phase<KS, HG, 2>(jk, wplanes, wexp, head0, wave, lane);
+    }
+    __syncthreads();
+    {
+        const FT43 ql = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4, SLD), qd = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4 + 16, SLD);
+        float* so = scores + (((size_t)b * H + head) * FND + mp.n) * FK + mp.k0;
+        float* ko = sskp + (((size_t)b * H + head) * FND + mp.n) * FK + mp.k0;
+#pragma unroll
+        for (int k = 0; k < FK; ++k) {
+            if (k < mp.kn) {
+                const float* pr = slab_p + (size_t)(3 * nb[k]) * SLD + c4;
+                FT43 y = ft_add43(ft_lds43(pr, SLD), ql);
+                const FT43 kd = ft_add43(ft_lds43(pr + 16, SLD), qd);
+                ft_act43(y, kd, oms);
+                const float s2 = fquad_sum(ft_dot43(y, y));
+                const float a = fquad_sum(ft_dot43(y, qf));
+                if (mp.ql == 0) { so[k] = a; ko[k] = s2; }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- kernel 2: soft-max and v
+template <int CIN, int NS, int HG>
+__global__ __launch_bounds__(256) void edge_ft_v_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
+                                                        const int* __restrict__ ae_q, const uint4* __restrict__ wplanes, const int* __restrict__ wexp,
+                                                        const int32_t* __restrict__ knn, int B, int H, float oms, float inv_sqrt_dk,
+                                                        const float* __restrict__ scores, const float* __restrict__ sskp, const float* __restrict__ ssqp,
+                                                        float* __restrict__ out, int Co, float* __restrict__ rowmax, int rm_parts) {
+    constexpr int KS = CIN / 16, MTP = NS * 3 / 32, MTQ = FND * 3 / 32, SLD = HG * 32 + 4;
+    __shared__ __attribute__((aligned(16))) float slab_q[FND * 3 * SLD];    // QV (lin | dir) of the destination points
+    __shared__ __attribute__((aligned(16))) float slab_p[NS * 3 * SLD];     // PV (lin | dir) of the source points
+    __shared__ float l_invk[FND * FK];
+    __shared__ float l_invq[FND];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int hg = logical / B, b = logical - hg * B, head0 = hg * HG;
+    const FtMap<HG> mp(tid);
+    const int head = head0 + mp.hl;
+
+    // ---- Frobenius norms over ALL channels: the per-head partial sums of kernel 1, added in ascending head order (deterministic)
+    for (int e = tid; e < FND * FK; e += 256) {
+        const float* sp = sskp + (size_t)b * H * FND * FK + e;
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += sp[(size_t)h * FND * FK];
+        l_invk[e] = finv_fro(s);
+    }
+    if (tid < FND) {
+        const float* sp = ssqp + (size_t)b * H * FND + tid;
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += sp[(size_t)h * FND];
+        l_invq[tid] = finv_fro(s);
+    }
+    // ---- v tables of the workgroup's heads
+    {
+        const FtJob<KS> jv[2] = {{a_p, ae_p, b * MTP, MTP, 0, slab_p, SLD}, {a_q, ae_q, b * MTQ, MTQ, 2, slab_q, SLD}};
+        ft_gemm_phase<KS, HG, 2>(jv, wplanes, wexp, head0, wave, lane);
+    }
+    __syncthreads();
+    // ---- soft-max over the 16 neighbours of (point, head) (:211-215); every lane of the (point, head) group computes it for itself
+    float wgt[FK];
+    float sum = 0.f;
+    {
+        const float4* sp = reinterpret_cast<const float4*>(scores + (((size_t)b * H + head) * FND + mp.n) * FK);
+        const float iq = l_invq[mp.n] * inv_sqrt_dk;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < FK / 4; ++u) {
+            const float4 v = sp[u];
+            wgt[4 * u] = v.x * iq * l_invk[mp.n * FK + 4 * u];
+            wgt[4 * u + 1] = v.y * iq * l_invk[mp.n * FK + 4 * u + 1];
+            wgt[4 * u + 2] = v.z * iq * l_invk[mp.n * FK + 4 * u + 2];
+            wgt[4 * u + 3] = v.w * iq * l_invk[mp.n * FK + 4 * u + 3];
+        }
+#pragma unroll
+        for (int k = 0; k < FK; ++k) mx = fmaxf(mx, wgt[k]);
+#pragma unroll
+        for (int k = 0; k < FK; ++k) { wgt[k] = expf(wgt[k] - mx); sum += wgt[k]; }
+    }
+    // ---- out = sum_k softmax_k * VecLNA_V(E[n, k])  (:208,216-219)
+    const int c4 = mp.hl * 32 + mp.ql * 4;
+    FT43 acc;
+    acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const FT43 ql = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4, SLD), qd = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4 + 16, SLD);
+        const int32_t* ki = knn + ((size_t)b * FND + mp.n) * FK;
+#pragma unroll
+        for (int k = 0; k < FK; ++k) {
+            if (k >= mp.k0 && k < mp.k0 + mp.kn) {
+                const float* pr = slab_p + (size_t)(3 * ki[k]) * SLD + c4;
+                FT43 y = ft_add43(ft_lds43(pr, SLD), ql);
+                const FT43 kd = ft_add43(ft_lds43(pr + 16, SLD), qd);
+                ft_act43(y, kd, oms);
+                ft_fma43(acc, wgt[k], y);
+            }
+        }
+    }
+    if constexpr (HG == 1) {   // the two neighbour halves of a point sit four lanes apart: lower half + upper half (fixed order)
+        auto comb = [&](float v) { const float o = __shfl_xor(v, 4, 64); return (tid & 4) ? o + v : v + o; };
+        acc.x = make_float4(comb(acc.x.x), comb(acc.x.y), comb(acc.x.z), comb(acc.x.w));
+        acc.y = make_float4(comb(acc.y.x), comb(acc.y.y), comb(acc.y.z), comb(acc.y.w));
+        acc.z = make_float4(comb(acc.z.x), comb(acc.z.y), comb(acc.z.z), comb(acc.z.w));
+    }
+    const float inv = 1.0f / sum;
+    const float4 ox = make_float4(acc.x.x * inv, acc.x.y * inv, acc.x.z * inv, acc.x.w * inv);
+    const float4 oy = make_float4(acc.y.x * inv, acc.y.y * inv, acc.y.z * inv, acc.y.w * inv);
+    const float4 oz = make_float4(acc.z.x * inv, acc.z.y * inv, acc.z.z * inv, acc.z.w * inv);
+    const bool writer = HG == 2 || (tid & 4) == 0;
+    if (writer) {
+        float* op = out + ((size_t)b * FND + mp.n) * 3 * Co + head * 16 + mp.ql * 4;
+        *reinterpret_cast<float4*>(op) = ox;
+        *reinterpret_cast<float4*>(op + Co) = oy;
+        *reinterpret_cast<float4*>(op + 2 * Co) = oz;
+    }
+    if (rowmax) {   // max |out[row, the workgroup's 16 HG channels]| -> part hg of the row's maxima (GemmAux: a_parts = Co / (16 HG))
+        auto amax4 = [](const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+        float rx = fquad_max(amax4(ox)), ry = fquad_max(amax4(oy)), rz = fquad_max(amax4(oz));
+        if constexpr (HG == 2) {   // the two heads of a point sit four lanes apart
+            rx = fmaxf(rx, __shfl_xor(rx, 4, 64)); ry = fmaxf(ry, __shfl_xor(ry, 4, 64)); rz = fmaxf(rz, __shfl_xor(rz, 4, 64));
+        }
+        if ((tid & 7) == 0) {
+            float* rp = rowmax + (((size_t)b * FND + mp.n) * 3) * rm_parts + hg;
+            rp[0] = rx; rp[rm_parts] = ry; rp[2 * rm_parts] = rz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+bool edge_ft_supported(int Co, int Cin, int Ns, int Nd, int head_c, bool has_rows) {
+    if (head_c != 16 || Nd != FND) return false;
+    if (Cin == 128 && Ns == 128 && has_rows && Co % 16 == 0) return true;         // layer 5 of the released schedule
+    if (Cin == 256 && Ns == 32 && !has_rows && Co % 32 == 0) return true;         // layer 6
+    return false;
+}
+int edge_ft_heads_per_group(int Cin) { return Cin == 256 ? 2 : 1; }
+// scratch of one fused layer call (inside the layer's table area): A planes + exponents (source rows, and the selected destination rows
+// when the layer down-samples), raw scores, partial norms
+size_t edge_ft_scratch_bytes(int B, int Ns, int Nd, int Cin, int Co, bool has_rows) {
+    const size_t rp = (size_t)B * Ns * 3, rq = (size_t)B * Nd * 3, H = Co / 16;
+    size_t s = rp * Cin * 4 + rp * 4 + 512;
+    if (has_rows) s += rq * Cin * 4 + rq * 4 + 512;
+    s += 2 * ((size_t)B * H * Nd * FK * 4 + 256) + (size_t)B * H * Nd * 4 + 256;
+    return s;
+}
+struct FtScratch { uint4* a_p; int* ae_p; uint4* a_q; int* ae_q; float* scores; float* sskp; float* ssqp; };
+static FtScratch ft_layout(void* scratch, int B, int Ns, int Nd, int Cin, int Co, bool has_rows) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t rp = (size_t)B * Ns * 3, rq = (size_t)B * Nd * 3, H = Co / 16;
+    char* c = (char*)scratch;
+    FtScratch s;
+    size_t off = 0;
+    s.a_p = (uint4*)(c + off); off = up(off + rp * Cin * 4);
+    s.ae_p = (int*)(c + off); off = up(off + rp * 4);
+    if (has_rows) {
+        s.a_q = (uint4*)(c + off); off = up(off + rq * Cin * 4);
+        s.ae_q = (int*)(c + off); off = up(off + rq * 4);
+    } else { s.a_q = s.a_p; s.ae_q = s.ae_p; }
+    s.scores = (float*)(c + off); off = up(off + (size_t)B * H * Nd * FK * 4);
+    s.sskp = (float*)(c + off); off = up(off + (size_t)B * H * Nd * FK * 4);
+    s.ssqp = (float*)(c + off);
+    return s;
+}
+// the layer's operand image (launched where the table GEMM was: it depends on the features only, not on the graph)
+int edge_ft_prep_launch(const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, int Cin, int Co, void* scratch, hipStream_t st) {
+    const bool has_rows = dst_rows != nullptr;
+    LS_REQUIRE(edge_ft_supported(Co, Cin, Ns, Nd, 16, has_rows), "edge_ft_prep: unsupported shape (Co=%d Cin=%d Ns=%d Nd=%d)", Co, Cin, Ns, Nd);
+    const FtScratch s = ft_layout(scratch, B, Ns, Nd, Cin, Co, has_rows);
+    if (Cin == 128) {
+        hipLaunchKernelGGL(edge_ft_prep_a_kernel<8>, dim3(B * Ns * 3 / 32), dim3(256), 0, st, cur, (const int32_t*)nullptr, Ns, Nd, s.a_p, s.ae_p);
+        LS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(edge_ft_prep_a_kernel<8>, dim3(B * Nd * 3 / 32), dim3(256), 0, st, cur, dst_rows, Ns, Nd, s.a_q, s.ae_q);
+    } else {
+        hipLaunchKernelGGL(edge_ft_prep_a_kernel<16>, dim3(B * Ns * 3 / 32), dim3(256), 0, st, cur, (const int32_t*)nullptr, Ns, Nd, s.a_p, s.ae_p);
+    }
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, int B, int Ns, int Nd, int Cin, int Co, float neg_slope, void* scratch,
+                        float* out, float* rowmax, hipStream_t st) {
+    LS_REQUIRE(edge_ft_supported(Co, Cin, Ns, Nd, 16, has_rows) && wplanes, "edge_ft_attn: unsupported shape (Co=%d Cin=%d Ns=%d Nd=%d)", Co, Cin, Ns, Nd);
+    const FtScratch s = ft_layout(scratch, B, Ns, Nd, Cin, Co, has_rows);
+    const int H = Co / 16, HG = edge_ft_heads_per_group(Cin), KS = Cin / 16;
+    const uint4* wp = (const uint4*)wplanes;
+    const int* we = (const int*)(wp + (size_t)H * 5 * KS * 128);
+    const float oms = 1.0f - neg_slope, isd = 1.0f / sqrtf(3.0f * 16);
+    const dim3 grid((H / HG) * B);
+    if (Cin == 128) {
+        hipLaunchKernelGGL((edge_ft_qk_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp);
+        LS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((edge_ft_v_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.sskp,
+                           s.ssqp, out, Co, rowmax, H / HG);
+    } else {
+        hipLaunchKernelGGL((edge_ft_qk_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp);
+        LS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((edge_ft_v_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.sskp,
+                           s.ssqp, out, Co, rowmax, H / HG);
+    }
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
+int edge_ft_rowmax_parts(int Co, int Cin) { return Co / 16 / edge_ft_heads_per_group(Cin); }
+
+}  // namespace ls

@@ -41,6 +41,15 @@ bool edge_attn_emits_rowmax(int Co, int ldt, int ldq);
 bool edge_attn_fq_supported(int Co, int Cin);
 int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
 size_t edge_wq_planes_bytes(int Co, int Cin);
+// edge_fused.hip: attention layers with 32 destination points (released layers 5 / 6) -- table slices formed and consumed in LDS
+bool edge_ft_supported(int Co, int Cin, int Ns, int Nd, int head_c, bool has_rows);
+size_t edge_ft_w_bytes(int Co, int Cin);
+int edge_ft_presplit_w_launch(const float* W, int Co, int Cin, void* planes, hipStream_t st);
+size_t edge_ft_scratch_bytes(int B, int Ns, int Nd, int Cin, int Co, bool has_rows);
+int edge_ft_prep_launch(const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, int Cin, int Co, void* scratch, hipStream_t st);
+int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, int B, int Ns, int Nd, int Cin, int Co, float neg_slope, void* scratch,
+                        float* out, float* rowmax, hipStream_t st);
+int edge_ft_rowmax_parts(int Co, int Cin);
 int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipStream_t st);
 int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t, GemmAux aux = GemmAux());
@@ -91,6 +100,8 @@ struct ProfRec { int kind, layer; hipEvent_t a, b; };
 struct ls_model {
     ls_model_desc d;
     float* blob = nullptr;
+    void* wt_planes[LS_MAX_LAYERS] = {};   // attention layers whose input has 128 / 256 channels (released layers 5, 6): ALL table weights as per-head f16
+                                           // MFMA fragment tiles (edge_fused.hip); used when the call's point counts fit the fused kernels
     void* wq_planes[LS_MAX_LAYERS] = {};   // attention layers 2 - 4: destination-side weights as f16 MFMA fragments (edge.hip, edge_attn_fq_kernel)
     float* dec_wt = nullptr;            // transposed decoder weights [kin_l][out_l], built by the first backward call
     size_t dec_wt_off[12] = {};
@@ -245,7 +256,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     maxGws = std::max(maxGws, gemm_scratch_floats(B * p.NP * 3, p.Cdp, p.Co[p.L - 1]));
     p.o_gws = take(maxGws * 4 + 256);
     // row maxima of the messages / layer outputs, chained into the GEMMs that read them (gemm.hip, GemmAux)
-    p.o_rm_msg = take((size_t)B * maxRm * 3 * 4);
+    p.o_rm_msg = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);   // (the table-free 32-point layers emit one maximum per head group: <= C / 32 parts)
     p.o_rm_out[0] = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);
     p.o_rm_out[1] = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);
     // staging of the captured-graph path: the graph reads x from / writes the codes to FIXED addresses inside the workspace
@@ -313,7 +324,8 @@ static size_t edge_table_floats(const ls_model_desc& d, int i, int B, int Ns, in
     const int nc = layer_ncols(d, i), pc = layer_pcols(d, i);
     return rows ? (size_t)B * 3 * ((size_t)Ns * pc + (size_t)Nd * (nc - pc)) : (size_t)B * Ns * 3 * nc;
 }
-struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; const float* cur = nullptr; const void* Wq = nullptr; int Cin = 0; };   // cur != null: destination side fused into the edge kernel
+struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; const float* cur = nullptr; const void* Wq = nullptr; int Cin = 0;
+                    const void* Wt = nullptr; };   // Wt != null: no table at all (edge_fused.hip); the table area holds that path's scratch   // cur != null: destination side fused into the edge kernel
 
 // where the table(s) of layer i live in T and how the edge kernel reads them (no launch)
 static bool edge_fused(const ls_model* m, int i) {
@@ -325,9 +337,22 @@ static bool edge_fused(const ls_model* m, int i) {
                                !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
     return fuse_q && m->wq_planes[i];
 }
+// table-free path of the 32-point attention layers (edge_fused.hip).  LS_EDGE_FUSE_T=0: the table GEMM + edge_attn_v4_kernel pair (A/B); like the
+// destination-side fusion it forms its products from f16 pieces, so the table path is kept under LS_GEMM_MODE=bf16x3 / LS_GEMM_BF16X3=0.
+static bool edge_fused_t(const ls_model* m, int i, int B, int Ns, int Nd, bool has_rows) {
+    static const bool on = !(getenv("LS_EDGE_FUSE_T") && atoi(getenv("LS_EDGE_FUSE_T")) == 0) &&
+                           !(getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) &&
+                           !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
+    const ls_model_desc& d = m->d;
+    if (!on || !m->wt_planes[i] || i < d.atten_start_layer) return false;
+    const int Cin = layer_cin(d, i), Co = d.feat_dim[i];
+    return edge_ft_supported(Co, Cin, Ns, Nd, d.atten_head_c, has_rows) &&
+           edge_ft_scratch_bytes(B, Ns, Nd, Cin, Co, has_rows) <= edge_table_floats(d, i, B, Ns, Nd, has_rows) * sizeof(float);
+}
 static EdgeTables edge_tables_layout(const ls_model* m, int i, const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, float* T) {
     const ls_model_desc& d = m->d;
     const int Cin = layer_cin(d, i), nc = layer_ncols(d, i), pc = layer_pcols(d, i);
+    if (edge_fused_t(m, i, B, Ns, Nd, dst_rows != nullptr)) { EdgeTables e{nullptr, 0, 0, 0, 0, cur, nullptr, Cin}; e.Wt = m->wt_planes[i]; return e; }
     if (edge_fused(m, i)) return EdgeTables{nullptr, pc, 0, 0, 0, cur, m->wq_planes[i], Cin};
     if (dst_rows) return EdgeTables{T + (size_t)B * Ns * 3 * pc, pc, nc - pc, Nd, 0};
     return EdgeTables{T + pc, nc, nc, Ns, 1};
@@ -341,6 +366,8 @@ static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_
     const float* W = m->blob + d.off_edge[i];
     et = edge_tables_layout(m, i, cur, dst_rows, B, Ns, Nd, T);
     PROF(LS_K_GEMM_EDGE, i, gs);
+    // 32-point attention layers (edge_fused.hip): no table -- only the operand image of the feature rows (f16 fragment planes) is formed here
+    if (et.Wt) return edge_ft_prep_launch(cur, dst_rows, B, Ns, Nd, Cin, d.feat_dim[i], T, gs);
     // attention layers 2 - 4 (fused): only the neighbour-side table; the destination side is computed inside the edge kernel (edge.hip)
     GemmAux ax = aux_w(m, W, nc, Cin);
     ax.a_rowmax = a_rowmax; ax.a_parts = a_parts;
@@ -359,12 +386,18 @@ static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_
 // gather + VN activation + mean-pool | attention of layer i >= 1 over the tables
 // rm_out (nullable) [B*Nd*3]: receives max|out[row, :]| when the kernel taken can write it; *rm_written says whether it did
 static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, const int32_t* knn, const int32_t* dst_rows, int B, int Nd,
-                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr) {
+                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr, int* rm_parts = nullptr) {
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
     if (rm_written) *rm_written = false;
+    if (rm_parts) *rm_parts = 1;
     if (i >= d.atten_start_layer) {
         PROF(LS_K_EDGE_ATTN, i, st);
+        if (et.Wt) {   // rm_out (if any) must hold [B*Nd*3][edge_ft_rowmax_parts] floats: one maximum per head group and row
+            if (rm_written) *rm_written = rm_out != nullptr;
+            if (rm_parts) *rm_parts = edge_ft_rowmax_parts(Co, et.Cin);
+            return edge_ft_attn_launch(et.Wt, knn, dst_rows != nullptr, B, Ns, Nd, et.Cin, Co, d.neg_slope, const_cast<float*>(T), out, rm_out, st);
+        }
         if (et.cur) {
             if (rm_written) *rm_written = rm_out != nullptr;
             return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
@@ -384,7 +417,7 @@ static size_t global_conv_gws_floats(const ls_model_desc& d, int i, int B, int N
 // rm_msg (nullable) [B*Nd*3]: row maxima of msg from the kernel that wrote it; rm_out (nullable) [B*Nd*3][Co/32]: receives those of `out`
 // (*rm_written: whether the path taken wrote them) -- gemm.hip, GemmAux
 static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, float* g, float* G, float* TG, float* gws, float* out, hipStream_t st,
-                       const float* rm_msg = nullptr, float* rm_out = nullptr, bool* rm_written = nullptr) {
+                       const float* rm_msg = nullptr, float* rm_out = nullptr, bool* rm_written = nullptr, int rm_msg_parts = 1) {
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
     const float* Wg = m->blob + d.off_glob[i];
@@ -398,7 +431,7 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
         // ... then ONE launch for the per-point contraction + the VN activation (gemm.hip: gemm_vn_kernel)
         PROF(LS_K_GEMM_GLOB, i, st);
         GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
-        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? 1 : 0;
+        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? rm_msg_parts : 0;
         ax.out_rowmax = rm_out;
         if (rm_written) *rm_written = rm_out != nullptr;
         return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st, ax);
@@ -411,7 +444,7 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
         rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, gws, st);
         if (rc != LS_OK) return rc;
         GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
-        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? 1 : 0;
+        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? rm_msg_parts : 0;
         ax.out_rowmax = rm_out;
         if (rm_written) *rm_written = rm_out != nullptr;
         return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st, ax);
@@ -419,7 +452,7 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
     {
         PROF(LS_K_GEMM_GLOB, i, st);
         GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
-        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? 1 : 0;
+        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? rm_msg_parts : 0;
         rc = gemm_dispatch_ws(msg, Co, Wg, Co, nullptr, TG, 2 * Co, B * Nd * 3, 2 * Co, Co, 0, gws, st, ax);
         if (rc == LS_OK) rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, gws, st);
     }
@@ -608,6 +641,14 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     if (e == hipSuccess) e = hipMalloc((void**)&m->knn_stats, sizeof(unsigned long long) * 2 * LS_MAX_LAYERS);
     if (e == hipSuccess) e = hipMemset(m->knn_stats, 0, sizeof(unsigned long long) * 2 * LS_MAX_LAYERS);
     if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
+    for (int i = desc->atten_start_layer; i < desc->num_layers && i >= 1; ++i) {   // table-free 32-point layers (edge_fused.hip): the shapes it has kernels for
+        const int Co = desc->feat_dim[i], Cin = layer_cin(*desc, i);
+        if (desc->atten_head_c != 16 || !((Cin == 128 && Co % 16 == 0) || (Cin == 256 && Co % 32 == 0))) continue;
+        e = hipMalloc(&m->wt_planes[i], edge_ft_w_bytes(Co, Cin));
+        if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
+        const int rc = edge_ft_presplit_w_launch(m->blob + desc->off_edge[i], Co, Cin, m->wt_planes[i], nullptr);
+        if (rc != LS_OK || hipDeviceSynchronize() != hipSuccess) { ls_model_destroy(m); return LS_ERR_HIP; }
+    }
     for (int i = desc->atten_start_layer; i < desc->num_layers && i >= 1; ++i) {
         const int Co = desc->feat_dim[i], Cin = layer_cin(*desc, i);
         if (desc->atten_head_c != 16 || !edge_attn_fq_supported(Co, Cin)) continue;
@@ -647,8 +688,10 @@ void ls_model_destroy(ls_model_t* m) {
     if (m->wmax_pool_t) (void)hipFree(m->wmax_pool_t);
     if (m->wplanes_pool) (void)hipFree(m->wplanes_pool);
     if (m->wplanes_pool_t) (void)hipFree(m->wplanes_pool_t);
-    for (int i = 0; i < LS_MAX_LAYERS; ++i)
+    for (int i = 0; i < LS_MAX_LAYERS; ++i) {
         if (m->wq_planes[i]) (void)hipFree(m->wq_planes[i]);
+        if (m->wt_planes[i]) (void)hipFree(m->wt_planes[i]);
+    }
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->side2) (void)hipStreamDestroy(m->side2);
     for (int i = 0; i < LS_MAX_LAYERS; ++i) {
@@ -773,6 +816,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
         const bool glob = i >= d.res_global_start_layer;
         float* mp = glob ? msg : nxt;
         bool msg_rm = false;
+        int msg_rm_parts = 1;
         if (i == 0) {
             { PROF(LS_K_KNN, i, st); rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
             if (rc != LS_OK) return rc;
@@ -817,7 +861,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             }
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if (skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) rc = LS_OK;
-            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm);
+            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts);
             if (rc != LS_OK) return rc;
         }
         cur_rm = nullptr; cur_rm_parts = 0;
@@ -825,7 +869,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             bool out_rm = false;
             if (skip & SK_GLOB) rc = LS_OK;
             else rc = global_conv(m, i, msg, B, Nd, F(p.o_g), F(p.o_G), F(p.o_TG), F(p.o_gws), nxt, st, msg_rm ? F(p.o_rm_msg) : nullptr,
-                             F(p.o_rm_out[i & 1]), &out_rm);
+                             F(p.o_rm_out[i & 1]), &out_rm, msg_rm_parts);
             if (rc != LS_OK) return rc;
             if (out_rm) { cur_rm = F(p.o_rm_out[i & 1]); cur_rm_parts = Co / 32; }
         }

@@ -11,6 +11,14 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle (torch) is the slow side of most GPU tests: on the GPU box's 2 x 64-core host its op sequence peaks at ~16 threads and is
+    # 2.5 - 9x slower with all 256 logical cores (tests/tools/cpu_threads_probe.py; bench.py's cpu_baseline uses 16 for the same reason)
+    try:
+        import torch
+        if (os.cpu_count() or 1) > 32:
+            torch.set_num_threads(16)
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")
