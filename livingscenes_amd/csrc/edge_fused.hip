@@ -196,40 +196,37 @@ __device__ __forceinline__ void ft_gemm_phase(const FtJob<KS> (&jobs)[NJ], const
     fh8_t bh[KS], bl[KS];
     int cur_tile = -1;
     int we = 0;
-    for (int t = lo; t < hi; ++t) {
-        // locate (job, head-local, M-tile) of flat item t: jobs in order, inside a job head-major
+    // (job, head-local, M-tile) of flat item t: jobs in order, inside a job head-major
+    auto decode = [&](int t, FtJob<KS>& jb, int& hl, int& mt) {
         int j = 0, off = t;
 #pragma unroll
         for (int q = 0; q < NJ - 1; ++q)
             if (j == q && off >= jobs[q].MT * HG) { off -= jobs[q].MT * HG; j = q + 1; }
-        FtJob<KS> jb = jobs[0];
+        jb = jobs[0];
 #pragma unroll
         for (int q = 1; q < NJ; ++q)
             if (j == q) jb = jobs[q];
-        const int hl = off / jb.MT, mt = off - hl * jb.MT;
-        const int T = (head0 + hl) * 5 + jb.p;
-        if (T != cur_tile) {   // wave-uniform
-            cur_tile = T;
-            const uint4* wp = wplanes + ((size_t)T * KS * 2) * 64 + lane;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bh[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2) * 64]);
-                bl[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2 + 1) * 64]);
-            }
-            we = wexp[T * 32 + (lane & 31)];
-        }
-        const uint4* ap = jb.a_planes + ((size_t)(jb.mt0 + mt) * KS * 2) * 64 + lane;
-        ff16_t acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        hl = off / jb.MT;
+        mt = off - hl * jb.MT;
+    };
+    auto a_ptr = [&](int t) {
+        FtJob<KS> jb;
+        int hl, mt;
+        decode(t, jb, hl, mt);
+        return jb.a_planes + ((size_t)(jb.mt0 + mt) * KS * 2) * 64 + lane;
+    };
+    auto load_w = [&](int T) {   // wave-uniform
+        if (T == cur_tile) return;
+        cur_tile = T;
+        const uint4* wp = wplanes + ((size_t)T * KS * 2) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const fh8_t ah = __builtin_bit_cast(fh8_t, ap[(size_t)(ks * 2) * 64]);
-            const fh8_t al = __builtin_bit_cast(fh8_t, ap[(size_t)(ks * 2 + 1) * 64]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+            bh[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2) * 64]);
+            bl[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2 + 1) * 64]);
         }
+        we = wexp[T * 32 + (lane & 31)];
+    };
+    auto store_tile = [&](const FtJob<KS>& jb, int hl, int mt, const ff16_t& acc) {
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const int row0 = 32 * mt + 4 * (lane >> 5);
         float* sp = jb.slab + (size_t)row0 * jb.sld + hl * 32 + (lane & 31);
@@ -238,6 +235,76 @@ __device__ __forceinline__ void ft_gemm_phase(const FtJob<KS> (&jobs)[NJ], const
         for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
             sp[dr * jb.sld] = __builtin_ldexpf(acc[r], ae[dr] + we);
+        }
+    };
+    // A k-step is 96 matrix-pipe cycles, an L2 round trip ~1 500: the A fragments must be in flight LONG before their MFMAs.  Written as load,
+    // load, three MFMAs per k-step the compiler put an s_waitcnt vmcnt(0) in front of every MFMA group (105 us per launch at layer 6).
+    if constexpr (KS <= 8) {
+        // whole tiles (KS x 2 loads = 64 VGPRs at KS = 8), double-buffered: tile t + 1 is requested before tile t's MFMAs start
+        fh8_t a0h[KS], a0l[KS], a1h[KS], a1l[KS];
+        auto load_a = [&](int t, fh8_t (&h)[KS], fh8_t (&l)[KS]) {
+            const uint4* ap = a_ptr(t);
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                h[u] = __builtin_bit_cast(fh8_t, ap[(size_t)(u * 2) * 64]);
+                l[u] = __builtin_bit_cast(fh8_t, ap[(size_t)(u * 2 + 1) * 64]);
+            }
+        };
+        auto tile = [&](int t, const fh8_t (&h)[KS], const fh8_t (&l)[KS]) {
+            FtJob<KS> jb;
+            int hl, mt;
+            decode(t, jb, hl, mt);
+            load_w((head0 + hl) * 5 + jb.p);
+            ff16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(l[u], bh[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h[u], bh[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h[u], bl[u], acc, 0, 0, 0);
+            }
+            store_tile(jb, hl, mt, acc);
+        };
+        if (lo < hi) load_a(lo, a0h, a0l);
+        for (int t = lo; t < hi; t += 2) {
+            if (t + 1 < hi) load_a(t + 1, a1h, a1l);
+            __builtin_amdgcn_sched_barrier(0);   // (requests above, matrix work below: the scheduler must not sink a load to its first use)
+            tile(t, a0h, a0l);
+            if (t + 2 < hi) load_a(t + 2, a0h, a0l);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < hi) tile(t + 1, a1h, a1l);
+        }
+    } else {
+        // KS = 16: the W fragments already take 128 VGPRs, so the A fragments come in batches of 8 k-steps (64 VGPRs), single-buffered; the other
+        // workgroup on the CU covers the wait
+        constexpr int AB = 8;
+        for (int t = lo; t < hi; ++t) {
+            FtJob<KS> jb;
+            int hl, mt;
+            decode(t, jb, hl, mt);
+            load_w((head0 + hl) * 5 + jb.p);
+            const uint4* ap = jb.a_planes + ((size_t)(jb.mt0 + mt) * KS * 2) * 64 + lane;
+            ff16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int k0 = 0; k0 < KS; k0 += AB) {
+                fh8_t ah[AB], al[AB];
+#pragma unroll
+                for (int u = 0; u < AB; ++u) {
+                    ah[u] = __builtin_bit_cast(fh8_t, ap[(size_t)((k0 + u) * 2) * 64]);
+                    al[u] = __builtin_bit_cast(fh8_t, ap[(size_t)((k0 + u) * 2 + 1) * 64]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < AB; ++u) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u], bh[k0 + u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bh[k0 + u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bl[k0 + u], acc, 0, 0, 0);
+                }
+            }
+            store_tile(jb, hl, mt, acc);
         }
     }
 }
@@ -256,19 +323,20 @@ struct FtMap {
 };
 
 // ---------------------------------------------------------------------------------------------------------------- kernel 1: q and k
-// grid = (Co / 16 / HG) x B workgroups, head-group major (the workgroups of one head group -- one W slice -- are neighbours on an XCD).
+// grid = (Co / 16 / HG) x B workgroups, instance major by default (edge_ft_attn_launch).
 // NS = source points per instance (32: destination set == source set, one A image; 128: destination points selected by dst_rows, own A image).
 template <int CIN, int NS, int HG>
-__global__ __launch_bounds__(256) void edge_ft_qk_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
+__global__ __launch_bounds__(256, 2) void edge_ft_qk_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
                                                          const int* __restrict__ ae_q, const uint4* __restrict__ wplanes, const int* __restrict__ wexp,
                                                          const int32_t* __restrict__ knn, int B, int H, float oms, float* __restrict__ scores,
-                                                         float* __restrict__ sskp, float* __restrict__ ssqp) {
+                                                         float* __restrict__ sskp, float* __restrict__ ssqp, int inst_major) {
     constexpr int KS = CIN / 16, MTP = NS * 3 / 32, MTQ = FND * 3 / 32, SLD = HG * 32 + 4;
     __shared__ __attribute__((aligned(16))) float slab_q[FND * 3 * SLD];    // q phase: Qq (lin | dir); k phase: QK (lin | dir) of the destination points
     __shared__ __attribute__((aligned(16))) float slab_p[NS * 3 * SLD];     // k phase: PK (lin | dir) of the source points
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int hg = logical / B, b = logical - hg * B, head0 = hg * HG;
+    const int ngroups = H / HG;
+    const int hg = inst_major ? logical % ngroups : logical / B, b = inst_major ? logical / ngroups : logical % B, head0 = hg * HG;
     const FtMap<HG> mp(tid);
     const int head = head0 + mp.hl;
 
@@ -320,36 +388,67 @@ __global__ __launch_bounds__(256) void edge_ft_qk_kernel(const uint4* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- between the two: the norms
+// Frobenius norms over ALL channels (channel_equi_vec_normalize, vec_layers.py:24-31): the per-head partial sums of kernel 1 added in ascending
+// head order (deterministic), once per instance -- inside kernel 2 every one of an instance's 16 workgroups repeated these 32-term sums, and a
+// loop over a run-time head count serialised its loads (one L2 round trip per term: 45 us of a 91 us launch).
+// invk [B][Nd][16] = 1 / max(|k(n, k)|_F, 1e-12), invq [B][Nd]; grid = B, 256 threads.
+__global__ __launch_bounds__(256) void edge_ft_norms_kernel(const float* __restrict__ sskp, const float* __restrict__ ssqp, int H, float* __restrict__ invk,
+                                                            float* __restrict__ invq) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < FND * FK + FND; e += 256) {
+        const bool isk = e < FND * FK;
+        const int stride = isk ? FND * FK : FND;
+        const float* sp = isk ? sskp + (size_t)b * H * FND * FK + e : ssqp + (size_t)b * H * FND + (e - FND * FK);
+        float s = 0.f;
+        int h = 0;
+        for (; h + 8 <= H; h += 8) {        // eight loads in flight, added in ascending head order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(h + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; h < H; ++h) s += sp[(size_t)h * stride];
+        if (isk) invk[(size_t)b * FND * FK + e] = finv_fro(s);
+        else invq[(size_t)b * FND + (e - FND * FK)] = finv_fro(s);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- kernel 2: soft-max and v
 template <int CIN, int NS, int HG>
-__global__ __launch_bounds__(256) void edge_ft_v_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
+__global__ __launch_bounds__(256, 2) void edge_ft_v_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
                                                         const int* __restrict__ ae_q, const uint4* __restrict__ wplanes, const int* __restrict__ wexp,
                                                         const int32_t* __restrict__ knn, int B, int H, float oms, float inv_sqrt_dk,
-                                                        const float* __restrict__ scores, const float* __restrict__ sskp, const float* __restrict__ ssqp,
-                                                        float* __restrict__ out, int Co, float* __restrict__ rowmax, int rm_parts) {
+                                                        const float* __restrict__ scores, const float* __restrict__ invk, const float* __restrict__ invq,
+                                                        float* __restrict__ out, int Co, float* __restrict__ rowmax, int rm_parts, int inst_major) {
     constexpr int KS = CIN / 16, MTP = NS * 3 / 32, MTQ = FND * 3 / 32, SLD = HG * 32 + 4;
     __shared__ __attribute__((aligned(16))) float slab_q[FND * 3 * SLD];    // QV (lin | dir) of the destination points
     __shared__ __attribute__((aligned(16))) float slab_p[NS * 3 * SLD];     // PV (lin | dir) of the source points
-    __shared__ float l_invk[FND * FK];
-    __shared__ float l_invq[FND];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int hg = logical / B, b = logical - hg * B, head0 = hg * HG;
+    const int ngroups = H / HG;
+    const int hg = inst_major ? logical % ngroups : logical / B, b = inst_major ? logical / ngroups : logical % B, head0 = hg * HG;
     const FtMap<HG> mp(tid);
     const int head = head0 + mp.hl;
 
-    // ---- Frobenius norms over ALL channels: the per-head partial sums of kernel 1, added in ascending head order (deterministic)
-    for (int e = tid; e < FND * FK; e += 256) {
-        const float* sp = sskp + (size_t)b * H * FND * FK + e;
-        float s = 0.f;
-        for (int h = 0; h < H; ++h) s += sp[(size_t)h * FND * FK];
-        l_invk[e] = finv_fro(s);
-    }
-    if (tid < FND) {
-        const float* sp = ssqp + (size_t)b * H * FND + tid;
-        float s = 0.f;
-        for (int h = 0; h < H; ++h) s += sp[(size_t)h * FND];
-        l_invq[tid] = finv_fro(s);
+    // the point's neighbour list, raw scores and norms: issued before anything else, consumed after the v tables are formed (a load per
+    // neighbour inside the weighted-sum loop would expose one L2 round trip each)
+    int nb[FK];
+    float4 sraw[FK / 4], ik4[FK / 4];
+    float iq;
+    {
+        const int4* kp = reinterpret_cast<const int4*>(knn + ((size_t)b * FND + mp.n) * FK);
+        const float4* sp = reinterpret_cast<const float4*>(scores + (((size_t)b * H + head) * FND + mp.n) * FK);
+        const float4* ip = reinterpret_cast<const float4*>(invk + ((size_t)b * FND + mp.n) * FK);
+#pragma unroll
+        for (int u = 0; u < FK / 4; ++u) {
+            const int4 v = kp[u];
+            nb[4 * u] = v.x; nb[4 * u + 1] = v.y; nb[4 * u + 2] = v.z; nb[4 * u + 3] = v.w;
+            sraw[u] = sp[u];
+            ik4[u] = ip[u];
+        }
+        iq = invq[(size_t)b * FND + mp.n] * inv_sqrt_dk;
     }
     // ---- v tables of the workgroup's heads
     {
@@ -361,16 +460,14 @@ __global__ __launch_bounds__(256) void edge_ft_v_kernel(const uint4* __restrict_
     float wgt[FK];
     float sum = 0.f;
     {
-        const float4* sp = reinterpret_cast<const float4*>(scores + (((size_t)b * H + head) * FND + mp.n) * FK);
-        const float iq = l_invq[mp.n] * inv_sqrt_dk;
         float mx = -INFINITY;
 #pragma unroll
         for (int u = 0; u < FK / 4; ++u) {
-            const float4 v = sp[u];
-            wgt[4 * u] = v.x * iq * l_invk[mp.n * FK + 4 * u];
-            wgt[4 * u + 1] = v.y * iq * l_invk[mp.n * FK + 4 * u + 1];
-            wgt[4 * u + 2] = v.z * iq * l_invk[mp.n * FK + 4 * u + 2];
-            wgt[4 * u + 3] = v.w * iq * l_invk[mp.n * FK + 4 * u + 3];
+            const float4 v = sraw[u], ik = ik4[u];
+            wgt[4 * u] = v.x * iq * ik.x;
+            wgt[4 * u + 1] = v.y * iq * ik.y;
+            wgt[4 * u + 2] = v.z * iq * ik.z;
+            wgt[4 * u + 3] = v.w * iq * ik.w;
         }
 #pragma unroll
         for (int k = 0; k < FK; ++k) mx = fmaxf(mx, wgt[k]);
@@ -383,11 +480,10 @@ __global__ __launch_bounds__(256) void edge_ft_v_kernel(const uint4* __restrict_
     acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
     {
         const FT43 ql = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4, SLD), qd = ft_lds43(slab_q + (size_t)(3 * mp.n) * SLD + c4 + 16, SLD);
-        const int32_t* ki = knn + ((size_t)b * FND + mp.n) * FK;
 #pragma unroll
         for (int k = 0; k < FK; ++k) {
             if (k >= mp.k0 && k < mp.k0 + mp.kn) {
-                const float* pr = slab_p + (size_t)(3 * ki[k]) * SLD + c4;
+                const float* pr = slab_p + (size_t)(3 * nb[k]) * SLD + c4;
                 FT43 y = ft_add43(ft_lds43(pr, SLD), ql);
                 const FT43 kd = ft_add43(ft_lds43(pr + 16, SLD), qd);
                 ft_act43(y, kd, oms);
@@ -440,9 +536,10 @@ size_t edge_ft_scratch_bytes(int B, int Ns, int Nd, int Cin, int Co, bool has_ro
     size_t s = rp * Cin * 4 + rp * 4 + 512;
     if (has_rows) s += rq * Cin * 4 + rq * 4 + 512;
     s += 2 * ((size_t)B * H * Nd * FK * 4 + 256) + (size_t)B * H * Nd * 4 + 256;
+    s += (size_t)B * Nd * FK * 4 + 256 + (size_t)B * Nd * 4 + 256;       // the summed norms (invk, invq)
     return s;
 }
-struct FtScratch { uint4* a_p; int* ae_p; uint4* a_q; int* ae_q; float* scores; float* sskp; float* ssqp; };
+struct FtScratch { uint4* a_p; int* ae_p; uint4* a_q; int* ae_q; float* scores; float* sskp; float* ssqp; float* invk; float* invq; };
 static FtScratch ft_layout(void* scratch, int B, int Ns, int Nd, int Cin, int Co, bool has_rows) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t rp = (size_t)B * Ns * 3, rq = (size_t)B * Nd * 3, H = Co / 16;
@@ -457,7 +554,9 @@ static FtScratch ft_layout(void* scratch, int B, int Ns, int Nd, int Cin, int Co
     } else { s.a_q = s.a_p; s.ae_q = s.ae_p; }
     s.scores = (float*)(c + off); off = up(off + (size_t)B * H * Nd * FK * 4);
     s.sskp = (float*)(c + off); off = up(off + (size_t)B * H * Nd * FK * 4);
-    s.ssqp = (float*)(c + off);
+    s.ssqp = (float*)(c + off); off = up(off + (size_t)B * H * Nd * 4);
+    s.invk = (float*)(c + off); off = up(off + (size_t)B * Nd * FK * 4);
+    s.invq = (float*)(c + off);
     return s;
 }
 // the layer's operand image (launched where the table GEMM was: it depends on the features only, not on the graph)
@@ -484,16 +583,24 @@ int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, 
     const int* we = (const int*)(wp + (size_t)H * 5 * KS * 128);
     const float oms = 1.0f - neg_slope, isd = 1.0f / sqrtf(3.0f * 16);
     const dim3 grid((H / HG) * B);
+    // workgroup order: instance major (an instance's head groups side by side on an XCD: its A image stays in that XCD's L2 and is read by all of
+    // them) or head-group major (the 64 instances of one W slice side by side).  Measured (us per launch, q/k | v): layer 5 36.9 | 41.6 instance
+    // major vs 54.9 | 60.6 head major; layer 6 59.2 | 46.6 vs 65.9 | 48.1 -- the A fragments are the stream that matters.  LS_FT_ORDER=0: head major (A/B).
+    const int im = order_env >= 0 ? order_env : 1;
     if (Cin == 128) {
-        hipLaunchKernelGGL((edge_ft_qk_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp);
+        hipLaunchKernelGGL((edge_ft_qk_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp, im);
         LS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((edge_ft_v_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.sskp,
-                           s.ssqp, out, Co, rowmax, H / HG);
+        hipLaunchKernelGGL(edge_ft_norms_kernel, dim3(B), dim3(256), 0, st, s.sskp, s.ssqp, H, s.invk, s.invq);
+        LS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((edge_ft_v_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.invk,
+                           s.invq, out, Co, rowmax, H / HG, im);
     } else {
-        hipLaunchKernelGGL((edge_ft_qk_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp);
+        hipLaunchKernelGGL((edge_ft_qk_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp, im);
         LS_LAUNCH_CHECK();
-        hipLaunchKernelGGL((edge_ft_v_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.sskp,
-                           s.ssqp, out, Co, rowmax, H / HG);
+        hipLaunchKernelGGL(edge_ft_norms_kernel, dim3(B), dim3(256), 0, st, s.sskp, s.ssqp, H, s.invk, s.invq);
+        LS_LAUNCH_CHECK();
+        hipLaunchKernelGGL((edge_ft_v_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.invk,
+                           s.invq, out, Co, rowmax, H / HG, im);
     }
     LS_LAUNCH_CHECK();
     return LS_OK;
