@@ -85,6 +85,18 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     # attention layers with C_out in {64, 128} compute the destination side inside the edge kernel (edge.hip, edge_attn_fq_kernel): the
     # table holds the neighbour-side columns only; the edge kernel reads the destination points' feature rows + the weights instead
     fused = L["attn"] and os.environ.get("LS_EDGE_FUSE_Q", "1") != "0" and ((Co == 64 and Cin in (32, 64)) or (Co == 128 and Cin == 64))
+    # attention layers with 32 destination points and 128 / 256 input channels (released layers 5, 6): NO table (csrc/edge_fused.hip) -- "gemm_edge" is
+    # the operand image of the feature rows (f16 fragment planes), "edge_attn" forms its table slices in LDS on the matrix cores and consumes them there
+    fused_t = (L["attn"] and bf16x3 and os.environ.get("LS_EDGE_FUSE_T", "1") != "0" and os.environ.get("LS_GEMM_MODE") != "bf16x3" and Nd == 32
+               and ((Cin == 128 and Ns == 128 and down) or (Cin == 256 and Ns == 32 and not down)))
+    if fused_t and kind == "gemm_edge":
+        rows = B * 3 * (Ns + (Nd if down else 0))
+        return 2 * rows * Cin * f4 + rows * 4, 0.0, FP32_PEAK_TFLOPS, "no arithmetic to speak of: feature rows in, (hi, lo) f16 fragment planes out"
+    if fused_t and kind == "edge_attn":
+        rows = B * 3 * (Ns + (Nd if down else 0))
+        flops_tab = mm_mult * 2.0 * B * 3 * (Ns * pc + Nd * (nc - pc)) * Cin           # the same products the table GEMM formed, as executed
+        byts = rows * Cin * f4 + nc * Cin * f4 + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4 + 3 * B * (Co // 16) * Nd * 16 * 4   # planes + W + graph + out + scores / norms
+        return byts, flops_tab, mm_peak, mm_what + "; table slices formed in LDS (edge_fused.hip: q/k launch, norm sums, soft-max/v launch); the VN activation / score / weighted-sum VALU work (~" + f"{2.0 * B * Nd * 16 * Co * 60 / 1e9:.1f}" + " GFLOP fp32) rides beside it"
     table_floats = B * Ns * 3 * pc if fused else (B * 3 * (Ns * pc + Nd * (nc - pc)) if down else B * Ns * 3 * nc)
     q_side_in = (B * Nd * 3 * Cin + (nc - pc) * Cin) if fused else 0          # floats the fused edge kernel reads instead of Q columns
     q_side_flops = mm_mult * 2.0 * B * Nd * 3 * Cin * (nc - pc) if fused else 0.0

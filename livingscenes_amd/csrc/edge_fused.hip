@@ -10,19 +10,24 @@
 // (54 us); layer 5 the same with 138 MB.  An instance of these layers is 32 x 3 (or 128 x 3) feature rows: a workgroup that owns
 // (instance, HG heads) can form its table slice -- [rows] x [lin 16 | dir 16] columns per head and column-group pair -- with the f16 matrix
 // cores straight into LDS and consume it there.  What keeps one workgroup from doing the whole layer is channel_equi_vec_normalize: the K
-// feature of an edge is normalised by its Frobenius norm over ALL channels (vec_layers.py:24-31), i.e. over all heads.  Hence two launches:
-//   edge_ft_qk_kernel   q = VecLNA_Q(dst), k = VecLNA_K(edge): per head the raw scores sum_c <k_c, q_c> and the partial squared norms |k|^2_head,
-//                       |q|^2_head -> small global arrays [instance][head][point][neighbour]
-//   edge_ft_v_kernel    sums the partial norms over the heads (ascending head order: deterministic), soft-max over the 16 neighbours,
-//                       v = VecLNA_V(edge) from its own table slice, weighted sum -> out [B, Nd, 3, Co] (+ per-head-group row maxima for the
-//                       GEMM that reads `out`)
+// feature of an edge is normalised by its Frobenius norm over ALL channels (vec_layers.py:24-31), i.e. over all heads.  Hence three launches:
+//   edge_ft_qk_kernel     q = VecLNA_Q(dst), k = VecLNA_K(edge): per head the raw scores sum_c <k_c, q_c> and the partial squared norms
+//                         |k|^2_head, |q|^2_head -> small global arrays [instance][head][point][neighbour]
+//   edge_ft_norms_kernel  the partial norms summed over the heads in ascending head order (deterministic), once per instance -> 1 / |k|_F, 1 / |q|_F
+//   edge_ft_v_kernel      soft-max over the 16 neighbours, v = VecLNA_V(edge) from its own table slice, weighted sum -> out [B, Nd, 3, Co]
+//                         (+ one row maximum per head group for the GEMM that reads `out`: GemmAux a_parts)
 // Operands: both MFMA operands arrive FRAGMENT-MAJOR (one coalesced 1 KB load per 32 x 16 operand block): the weights are split once per model
 // (edge_ft_presplit_w_kernel: tile = (head, column-group pair), rows [lin 16 | dir 16], per-row power-of-two scale), the feature rows once per
 // layer call (edge_ft_prep_a_kernel: per-row power-of-two scale, (hi, lo) f16 planes) -- the same two-piece split, the same three products per
 // 16 k in the same order (l_a h_w, h_a h_w, h_a l_w) into one fp32 accumulator, ascending k, and the same integer-exponent scale in the epilogue as
-// gemm.hip, so a table entry formed here is bit-identical to the one a non-split-K table GEMM writes.  The attention arithmetic uses the
-// helpers of edge.hip (vn_act, dot43, fma43: every multiply-add spelled as an fma); what differs from edge_attn_v4_kernel is the ORDER in which
-// the squared norms are summed over the channels (per head by a DPP quad sum, then over the heads ascending, instead of one 64-lane tree).
+// gemm.hip (the row scales come from the exact row maxima; the table GEMM may be handed an upper bound by its producer, so the two paths agree
+// to fp32 round-off, not bit for bit).  The attention arithmetic uses the helpers of edge.hip (vn_act, dot43, fma43: every multiply-add spelled
+// as an fma); what differs from edge_attn_v4_kernel is the ORDER in which the squared norms are summed over the channels (per head by a DPP quad
+// sum, then over the heads ascending, instead of one 64-lane tree).
+// Measured (MI355X, B = 64, one step in flight, us per launch): layer 5 image 11 + q/k 37 + norms 6 + v 42 = 96 (table path 83 + 37 = 120);
+// layer 6 image 5 + q/k 59 + norms 6 + v 47 = 117 (96 + 54 = 150); whole bench 48.1k -> 50.0k object-instances/s.  What bounds the two big
+// kernels is the latency of the fragment streams (a k-step is 96 matrix-pipe cycles, an L2 round trip ~1 500) at two waves per SIMD, then the VN
+// activation's VALU work (~130 instructions per neighbour and lane); see DESIGN.md.
 #include "ls_common.h"
 
 namespace ls {

@@ -717,23 +717,40 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
         for (int kk = 0; kk < KK; ++kk) a[u][kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
     }
     // drop  <=>  d^ - eps nn > kth  <=>  S~ < ((1-eps)(nq + ns) - kth) / 2 = A[row] + Bc[candidate];  S~ = S / (s_q s_c) (the rows' scales)
+    // (Round 4: branch-free, in two batches -- row indices, then everything that depends on them.  Written as `if (q < Nd) { load; load;
+    //  load }` per row the compiler emitted sixteen blocks with an s_waitcnt vmcnt(0) inside each: ~2 dependent L2 round trips x 16 rows = 11 us of a
+    //  44 us launch before the first tile.)
     float A[QG][16], IQ[QG][16];
+    {
+        int rowi[QG][16];
 #pragma unroll
-    for (int u = 0; u < QG; ++u)
+        for (int u = 0; u < QG; ++u)
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int q = q0 + 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-            float v = INFINITY, iq = 0.f;                              // padding query: 0 < inf, always dropped
-            if (q < Nd) {
-                const int row = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
-                const unsigned hi = (unsigned)(seedkeys[((size_t)b * Nd + q) * 16 + (K - 1)] >> 32);
-                const float kth = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);   // fewer than K distinct hints: nothing is dropped
-                v = 0.5f * (om * nrm_dst[(size_t)b * dst_n + row] - kth);
-                iq = isc_dst[(size_t)b * dst_n + row];
+            for (int rr = 0; rr < 16; ++rr) {
+                const int qc = min(q0 + 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * lh, Nd - 1);
+                rowi[u][rr] = dst_rows ? dst_rows[(size_t)b * Nd + qc] : qc;
             }
-            A[u][rr] = v;
-            IQ[u][rr] = iq;
-        }
+        unsigned khi[QG][16];
+        float nd[QG][16];
+#pragma unroll
+        for (int u = 0; u < QG; ++u)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int qc = min(q0 + 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * lh, Nd - 1);
+                khi[u][rr] = reinterpret_cast<const unsigned*>(seedkeys + ((size_t)b * Nd + qc) * 16 + (K - 1))[1];   // high word = the K-th distance's bits
+                nd[u][rr] = nrm_dst[(size_t)b * dst_n + rowi[u][rr]];
+                IQ[u][rr] = isc_dst[(size_t)b * dst_n + rowi[u][rr]];
+            }
+#pragma unroll
+        for (int u = 0; u < QG; ++u)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int q = q0 + 32 * u + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                const float kth = khi[u][rr] == 0xFFFFFFFFu ? INFINITY : __uint_as_float(khi[u][rr]);   // fewer than K distinct hints: nothing is dropped
+                A[u][rr] = q < Nd ? 0.5f * (om * nd[u][rr] - kth) : INFINITY;                             // padding query: 0 < inf, always dropped
+                IQ[u][rr] = q < Nd ? IQ[u][rr] : 0.f;
+            }
+    }
     // hint bitmap of the wave's queries.  The keys are loaded BEFORE the LDS clear (the wave barriers are scheduling fences: the
     // loads would otherwise be issued only after the clear, one more exposed memory round trip per wave)
     uint4 hk[QG][4];
@@ -964,18 +981,22 @@ __global__ __launch_bounds__(256) void knn_sweep_store_kernel(const unsigned sho
     }
     float rq[16];          // 32767 / |q'| of the lane's 16 query rows (0: padding query or a row at the centre)
     short* orow[16];       // where the row's cosines go (null: padding query)
+    {   // branch-free, in two batches (row indices, then the norms and scales): see knn_sweep_f16_kernel
+        int rowi[16];
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const int q = q0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-        float v = 0.f;
-        orow[rr] = nullptr;
-        if (q < Nd) {
-            const int row = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
-            const float nq = nrm_dst[(size_t)b * dst_n + row];
-            v = nq > 0.f ? 32767.0f * __builtin_amdgcn_rsqf(nq) * isc_dst[(size_t)b * dst_n + row] : 0.f;   // (the row's image scale folded in)
-            orow[rr] = cosq + ((size_t)b * Nd + q) * ns_pad;
+        for (int rr = 0; rr < 16; ++rr) {
+            const int qc = min(q0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh, Nd - 1);
+            rowi[rr] = dst_rows ? dst_rows[(size_t)b * Nd + qc] : qc;
         }
-        rq[rr] = v;
+        float nq[16], is[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) { nq[rr] = nrm_dst[(size_t)b * dst_n + rowi[rr]]; is[rr] = isc_dst[(size_t)b * dst_n + rowi[rr]]; }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int q = q0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            rq[rr] = (q < Nd && nq[rr] > 0.f) ? 32767.0f * __builtin_amdgcn_rsqf(nq[rr]) * is[rr] : 0.f;   // (the row's image scale folded in)
+            orow[rr] = q < Nd ? cosq + ((size_t)b * Nd + q) * ns_pad : nullptr;
+        }
     }
     const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
     const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
