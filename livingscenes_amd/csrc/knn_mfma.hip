@@ -776,22 +776,29 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
 
     const int ntiles = ns_pad >> 5, tps = (ntiles + nsplit - 1) / nsplit;
     const int t0 = sp * tps, t1 = min(ntiles, t0 + tps);
-#pragma unroll 2
-    for (int t = t0; t < t1; ++t) {
-        const unsigned short* bp = sqb + ((size_t)t * KK * 64 + lane) * 8;
-        f16x8k bf[KK];
+    // Round 4: the candidate fragments of tile t + 1 are REQUESTED before tile t's MFMAs start (two fragment sets, the loop unrolled by two so
+    // that no register moves are needed; clamped unconditional loads).  With `load 6 fragments, 6 MFMAs, filter` per tile every wave exposed one L2
+    // round trip (~1 500 cycles) per tile against ~190 matrix-pipe + ~400 VALU cycles of work; +24 VGPRs keep the kernel at three waves per SIMD.
+    struct TileIn { f16x8k bf[KK]; float Bc, ic; };
+    auto load_tile = [&](int t, TileIn& ti) {
+        const int tc = min(t, t1 - 1);
+        const unsigned short* bp = sqb + ((size_t)tc * KK * 64 + lane) * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bf[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        for (int kk = 0; kk < KK; ++kk) ti.bf[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        const int cg = tc * 32 + l31;
+        ti.Bc = 0.5f * om * nsb[min(cg, Ns - 1)];
+        ti.ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)];
+    };
+    auto do_tile = [&](int t, const TileIn& ti) {
         const int cg = t * 32 + l31;
-        const float Bc = 0.5f * om * nsb[min(cg, Ns - 1)];
-        const float ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)];
+        const float Bc = ti.Bc, ic = ti.ic;
 #pragma unroll
         for (int u = 0; u < QG; ++u) {
             f32x16 S;
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][kk], bf[kk], S, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][kk], ti.bf[kk], S, 0, 0, 0);
             unsigned mask = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) mask |= (S[r] * (IQ[u][r] * ic) < A[u][r] + Bc) ? 0u : (1u << r);
@@ -813,6 +820,18 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
                     }
                 }
             }
+        }
+    };
+    {
+        TileIn ta, tb;
+        if (t0 < t1) load_tile(t0, ta);
+        for (int t = t0; t < t1; t += 2) {
+            load_tile(t + 1, tb);
+            __builtin_amdgcn_sched_barrier(0);
+            do_tile(t, ta);
+            load_tile(t + 2, ta);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < t1) do_tile(t + 1, tb);
         }
     }
     // flush: one global atomic per query reserves the wave's slots

@@ -38,12 +38,14 @@ def transformation_residuals(x1, x2, R, t):
 
 
 def solve_R(f1, f2):
-    """pose_estimation.py:11-27: un-weighted, un-centred rotation fit (f [b,m,3])."""
-    H = f1.transpose(-1, -2) @ f2
-    U, _, V = torch.svd(H.cpu())
-    d = torch.linalg.det(V @ U.transpose(-1, -2))
-    D = torch.diag_embed(torch.stack([torch.ones_like(d), torch.ones_like(d), d], -1))
-    return (V @ D @ U.transpose(-1, -2)).to(f1.device)
+    """pose_estimation.py:11-27: un-weighted, un-centred rotation fit (f [(b,) m, 3]): H = f1^T f2 = U S V^T, R = V diag(1, 1, det(V U^T)) U^T.
+    Runs on the device's batched Kabsch kernel (the reference's torch.svd would be a host round trip here): the point sets are mirrored
+    (x, -x), which makes both centroids zero, so the kernel's centred covariance IS 2 f1^T f2 / (2m) -- a positive multiple of H, same rotation."""
+    squeeze = f1.dim() == 2
+    if squeeze:
+        f1, f2 = f1[None], f2[None]
+    R, _, _ = ops.kabsch(torch.cat([f1, -f1], 1), torch.cat([f2, -f2], 1))
+    return R[0] if squeeze else R
 
 
 def inverse_3d_transform(tsfm):

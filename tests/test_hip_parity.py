@@ -699,6 +699,37 @@ def test_icp_vs_oracle():
     assert exact >= P - 1, f"only {exact} of {P} problems ended on the oracle's nearest-neighbour assignment"
 
 
+def test_solve_R_on_the_device_vs_the_reference_formula():
+    """pose_estimation.solve_R (pose_estimation.py:11-27; used by solve_transform_from_latent) no longer goes through torch.svd on the host: the
+    mirrored point sets through the device Kabsch kernel against the reference's formula evaluated in fp64 -- rotations of noisy z_so3-like
+    sets, a reflection case (det < 0 before the fix-up) and the un-batched [m, 3] call."""
+    from livingscenes_amd.lib_more.pose_estimation import solve_R, solve_transform_from_latent
+    g = torch.Generator().manual_seed(3)
+    b, m = 6, 256
+    f1 = torch.randn(b, m, 3, generator=g)
+    rng = np.random.default_rng(5)
+    Rt = torch.from_numpy(np.stack([synth._rand_rot(rng) for _ in range(b)]).astype(np.float32))
+    f2 = f1 @ Rt.transpose(1, 2) + 0.01 * torch.randn(b, m, 3, generator=g)
+    f2[1] = f2[1] * torch.tensor([1.0, 1.0, -1.0])        # a mirrored target: the SVD solution has det < 0 before the diag(1, 1, d) fix-up
+
+    def ref(a, c):
+        H = a.double().transpose(-1, -2) @ c.double()
+        U, _, Vh = torch.linalg.svd(H)
+        V = Vh.transpose(-1, -2)
+        d = torch.linalg.det(V @ U.transpose(-1, -2))
+        D = torch.diag_embed(torch.stack([torch.ones_like(d), torch.ones_like(d), d], -1))
+        return V @ D @ U.transpose(-1, -2)
+    R = solve_R(f1.to(_dev()), f2.to(_dev()))
+    assert R.shape == (b, 3, 3) and R.is_cuda
+    assert relerr(R, ref(f1, f2)) < TOL
+    assert (torch.linalg.det(R.cpu().double()) - 1).abs().max() < 1e-5
+    assert relerr(solve_R(f1[0].to(_dev()), f2[0].to(_dev())), ref(f1[0], f2[0])) < TOL
+    c1 = {"z_so3": f1[:1].to(_dev()), "t": torch.randn(1, 1, 3, generator=g).to(_dev())}
+    c2 = {"z_so3": f2[:1].to(_dev()), "t": torch.randn(1, 1, 3, generator=g).to(_dev())}
+    T = solve_transform_from_latent(c1, c2)
+    assert T.shape == (1, 4, 4) and relerr(T[:, :3, :3], ref(f1[:1], f2[:1])) < TOL
+
+
 def test_deepsdf_decoder_direct_forward_vs_oracle():
     """DeepSDF_Decoder.forward(input [B,M,513], 'val') -- the reference class's own call surface (deepsdf_decoder.py:78-123), not
     only the fused FieldWrapper route -- against oracle.net.decoder_forward, released widths and the small config."""
