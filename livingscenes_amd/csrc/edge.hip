@@ -33,12 +33,13 @@ constexpr int EK = 16;  // neighbours per point (num_knn)
 // pts [B,N,3]; w0 [6][Co] = {W[:,0], W[:,1], W[:,2], (Wd W)[:,0], (Wd W)[:,1], (Wd W)[:,2]}; out [B,N,3,Co]
 __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ pts, const int32_t* __restrict__ knn,
                                                       const float* __restrict__ w0, int N, int Co, float oms,
-                                                      float* __restrict__ out, int total) {
+                                                      float* __restrict__ out, int total, const int32_t* __restrict__ perm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 5, o = lane & 31;  // two points per wave, 32 lanes each (Co <= 32 per pass)
     int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 2 + sub;
     const bool live = pid < total;
     if (!live) pid = total - 1;
+    if (perm) pid = perm[pid];      // processing order (pointwise.hip: morton_order_kernel): which point this slot works on; results do not depend on it
     const int b = pid / N;
     const float* P = pts + (size_t)b * N * 3;
     const float cx = pts[(size_t)pid * 3 + 0], cy = pts[(size_t)pid * 3 + 1], cz = pts[(size_t)pid * 3 + 2];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
                                                         int NQ, int q_via_rows, const int32_t* __restrict__ knn,
                                                         const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
-                                                        float oms, float* __restrict__ out, int total) {
+                                                        float oms, float* __restrict__ out, int total, const int32_t* __restrict__ perm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lpp = Co <= 32 ? 32 : 64;         // lanes per point
     const int ppw = 64 / lpp;                   // points per wave
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict_
     int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * ppw + sub;
     const bool live = pid < total;
     if (!live) pid = total - 1;
+    if (perm) pid = perm[pid];      // processing order (morton_order_kernel)
     const int b = pid / Nd;
     const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
     const float* Tb = T + (size_t)b * Ns * 3 * ldt;
@@ -505,7 +507,7 @@ template <int LPP, int CIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
                                                            const uint4* __restrict__ Wp, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, float oms, float inv_sqrt_dk,
-                                                           float* __restrict__ out, int total, float* __restrict__ rowmax) {
+                                                           float* __restrict__ out, int total, float* __restrict__ rowmax, const int32_t* __restrict__ perm) {
     constexpr int PPW = 64 / LPP, PW = 4 * PPW, ROWS = 3 * PW, MT = (ROWS + 31) / 32, Co = LPP * 4, SC = 2 * Co, NT = SC / 32, SLD = SC + 4,
                   KS = CIN / 16, ASTR = CIN * 2 + 16;   // A plane row stride in bytes (+16: conflict-free 16-byte fragment reads)
     static_assert(MT * NT == 8, "two output tiles per wave");
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     int pid = pid0 + pwl;
     const bool live = pid < total;
     if (!live) pid = total - 1;
+    if (perm) pid = perm[pid];      // processing order (pointwise.hip: morton_order_kernel): the workgroup's PW slots -> PW spatially adjacent points
     const int b = pid / Nd;
     const float* Tb = T + (size_t)b * Ns * 3 * ldt;
     const int32_t* ki = knn + (size_t)pid * EK;
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < ROWS) {
             const int pw = r / 3, x = r - 3 * pw;
-            const int pa = min(pid0 + pw, total - 1), ba = pa / Nd;
+            const int ps = min(pid0 + pw, total - 1), pa = perm ? perm[ps] : ps, ba = pa / Nd;
             const int sp = dst_rows ? dst_rows[pa] : pa - ba * Nd;
             v = *reinterpret_cast<const float4*>(cur + (((size_t)ba * Ns + sp) * 3 + x) * CIN + kq * 4);
         }
@@ -603,6 +606,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     const float inv_q = inv_fro(group_sum<LPP>(dot43(qf, qf)));
     __syncthreads();   // every wave has its q: the slab may be overwritten
 
+    // Where the time goes (round 4, timing variants, 12 steps in flight; layers 2 / 3 / 4 = 111 / 110 / 81 us): with the gathers of both loops
+    // removed 56 / 64 / 38 us (arithmetic, the three destination-side products, LDS); with the arithmetic removed and the gathers kept 120 / 124 / 77 us.
+    // The gathers alone take as long as the kernel: it is bound by the vector-memory path, not by the VALU -- and NOT by L2 traffic either (handing
+    // the points out in Morton order cuts the distinct neighbour rows per workgroup from ~230 to 62 - 90 and changes nothing): 1.6 GB per launch have
+    // to be DELIVERED by the L1s, 6.1 MB per CU at 64 B/clk = 46 us, and the two-deep pipeline of 16-byte loads does not overlap that with the arithmetic.
     // ---- B: K branch -> per-head scores for the 16 neighbours, normalised by the Frobenius norm of k
     // The gathers are a two-deep software pipeline (round 3): the 16 neighbour indices sit in registers (four 16-byte loads up front
     // instead of a dependent index load in front of every row gather) and the rows of neighbours k+1, k+2 are in flight while
@@ -692,11 +700,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
 // can this layer shape take the fused kernel?
 bool edge_attn_fq_supported(int Co, int Cin) { return (Co == 64 && (Cin == 32 || Cin == 64)) || (Co == 128 && Cin == 64); }
 int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, const void* wq_planes, const int32_t* knn, const int32_t* dst_rows, int B,
-                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax) {
+                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax, const int32_t* perm) {
     LS_REQUIRE(head_c == 16 && edge_attn_fq_supported(Co, Cin) && ldt % 4 == 0 && wq_planes, "edge_attn_fq: unsupported shape (Co=%d Cin=%d ldt=%d)", Co, Cin, ldt);
     const float isd = 1.0f / sqrtf(3.0f * head_c), oms = 1.0f - neg_slope;
     const int total = B * Nd;
-#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax)
+#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax, perm)
     if (Co == 64 && Cin == 32) LS_FQ(16, 32);
     else if (Co == 64) LS_FQ(16, 64);
     else LS_FQ(32, 64);
@@ -719,19 +727,19 @@ static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int
 }
 
 int edge_l0_launch(const float* pts, const int32_t* knn, const float* w0, int B, int N, int Co, float neg_slope, float* out,
-                   hipStream_t st) {
+                   hipStream_t st, const int32_t* perm) {
     const int total = B * N;
-    hipLaunchKernelGGL(edge_l0_kernel, dim3(cdiv(total, 8)), dim3(256), 0, st, pts, knn, w0, N, Co, 1.0f - neg_slope, out, total);
+    hipLaunchKernelGGL(edge_l0_kernel, dim3(cdiv(total, 8)), dim3(256), 0, st, pts, knn, w0, N, Co, 1.0f - neg_slope, out, total, perm);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
 
 int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
-                     const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st) {
+                     const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st, const int32_t* perm) {
     const int total = B * Nd;
     const int ppb = (Co <= 32) ? 8 : 4;
     hipLaunchKernelGGL(edge_pool_kernel, dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns,
-                       Co, 1.0f - neg_slope, out, total);
+                       Co, 1.0f - neg_slope, out, total, perm);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

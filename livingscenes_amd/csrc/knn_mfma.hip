@@ -779,6 +779,9 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
     // Round 4: the candidate fragments of tile t + 1 are REQUESTED before tile t's MFMAs start (two fragment sets, the loop unrolled by two so
     // that no register moves are needed; clamped unconditional loads).  With `load 6 fragments, 6 MFMAs, filter` per tile every wave exposed one L2
     // round trip (~1 500 cycles) per tile against ~190 matrix-pipe + ~400 VALU cycles of work; +24 VGPRs keep the kernel at three waves per SIMD.
+    // Where the layer-1 launch's 42 us go (timing variants, 12 steps in flight): without the survivor loop 35, without filter arithmetic and loop 28,
+    // without the MFMAs 32 -- i.e. MFMA ~10, filter ~7, survivor bookkeeping ~7, and ~18 that are the fragment stream (403 MB through the L1 path
+    // = 11.7 us at 64 B/clk/CU), the per-wave set-up and the flush: no single lever is left in this kernel.
     struct TileIn { f16x8k bf[KK]; float Bc, ic; };
     auto load_tile = [&](int t, TileIn& ti) {
         const int tc = min(t, t1 - 1);

@@ -34,12 +34,13 @@ size_t gemm_w_planes_bytes(size_t rows, int K);
 bool gemm_w_planes_useful(int K);
 int gemm_presplit_w_launch(const float* W, int rows, int K, int ldw, const float* rowmax, void* planes, hipStream_t st);
 int sdf_affine_rowmax_parts(int out_dim);
-int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
-int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
+int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t, const int32_t* perm = nullptr);
+int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t, const int32_t* perm = nullptr);
 int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
 bool edge_attn_emits_rowmax(int Co, int ldt, int ldq);
 bool edge_attn_fq_supported(int Co, int Cin);
-int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
+int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr, const int32_t* perm = nullptr);
+int morton_order_launch(const float* pts, int B, int N, int32_t* perm, hipStream_t st);
 size_t edge_wq_planes_bytes(int Co, int Cin);
 // edge_fused.hip: attention layers with 32 destination points (released layers 5 / 6) -- table slices formed and consumed in LDS
 bool edge_ft_supported(int Co, int Cin, int Ns, int Nd, int head_c, bool has_rows);
@@ -136,6 +137,10 @@ struct ls_model {
     bool graph_broken = false;     // a capture / instantiate failed once on this handle: stay on the direct path
     int debug_layers = -1;         // LS_DEBUG_LAYERS=n: ls_encode stops after n layers (outputs undefined) and prints the workspace plan:
                                    // race hunting by comparing workspaces (scripts/diag/)
+    bool order_pts = false;        // LS_ORDER=1: the gather kernels take their points in Morton order of their xyz instead of storage (FPS) order (same
+                                   // results).  OFF: measured neutral -- 16 Morton-adjacent points share their neighbours (62 - 90 distinct rows of 256, against
+                                   // ~230 in FPS order), yet the attention kernels did not move (110 / 109 / 81 us either way; bench 51.0k vs 50.8k): they are
+                                   // not bound by L2 -> L1 traffic but by L1 delivery (6.1 MB per CU at 64 B/clk = 46 us) next to ~60 us of arithmetic
     bool fps_side = true;          // LS_FPS_SIDE=0 runs the FPS chain on the caller's stream (A/B timing, race hunting)
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     unsigned skip_mask = 0;        // (always 0 unless built with -DLS_DEV_KNOBS) LS_SKIP=knn,attn,...: dev timing knob -- after LS_SKIP_AFTER (default 3) ls_encode calls on this handle the named
@@ -179,6 +184,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
+    size_t o_perm[LS_MAX_LAYERS + 1];   // processing order of each level's points (Morton order of their xyz; pointwise.hip)
     size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_hint, o_inv, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], total;
 };
 
@@ -236,6 +242,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     for (int l = 0; l <= p.nlevels; ++l) {
         p.o_pts[l] = take((size_t)B * p.levelN[l] * 3 * 4);
         p.o_fps[l] = take((size_t)B * p.levelN[l] * 4);
+        p.o_perm[l] = take((size_t)B * p.levelN[l] * 4);
     }
     p.o_centroid = take((size_t)B * 3 * 4);
     p.o_scale0 = take((size_t)B * 4);
@@ -386,7 +393,8 @@ static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_
 // gather + VN activation + mean-pool | attention of layer i >= 1 over the tables
 // rm_out (nullable) [B*Nd*3]: receives max|out[row, :]| when the kernel taken can write it; *rm_written says whether it did
 static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, const int32_t* knn, const int32_t* dst_rows, int B, int Nd,
-                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr, int* rm_parts = nullptr) {
+                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr, int* rm_parts = nullptr,
+                      const int32_t* perm = nullptr) {   // perm (nullable) [B*Nd]: processing order of the destination points (morton_order_kernel)
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
     if (rm_written) *rm_written = false;
@@ -400,14 +408,14 @@ static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, 
         }
         if (et.cur) {
             if (rm_written) *rm_written = rm_out != nullptr;
-            return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
+            return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out, perm);
         }
         if (!edge_attn_emits_rowmax(Co, et.ldp, et.ldq)) rm_out = nullptr;
         if (rm_written) *rm_written = rm_out != nullptr;
         return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
     }
     PROF(LS_K_EDGE_POOL, i, st);
-    return edge_pool_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, out, st);
+    return edge_pool_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, out, st, perm);
 }
 // residual global conv of layer i (vec_dgcnn_atten.py:222-225): out = VecLNA_G(cat(msg, mean_n msg))
 static size_t global_conv_gws_floats(const ls_model_desc& d, int i, int B, int Nd) {
@@ -619,6 +627,7 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     if (const char* ev = getenv("LS_KNN_HINTS")) m->hint_policy = !strcmp(ev, "prev") ? 1 : (!strcmp(ev, "auto") ? 2 : 0);
     if (const char* ev = getenv("LS_SDF_BF16X2")) m->sdf_bf16x2 = atoi(ev) != 0;
     if (const char* ev = getenv("LS_KNN_FILTER")) m->knn_filter = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_ORDER")) m->order_pts = atoi(ev) != 0;
 #ifdef LS_DEV_KNOBS   // only in the variant library scripts/dev/marginal_cost.sh builds (-DLS_DEV_KNOBS): the release library cannot be made to skip work
     if (const char* ev = getenv("LS_SKIP")) {
         const char* names[] = {"knn", "attn", "pool", "l0", "tables", "glob", "fps", "tail", "prologue"};
@@ -759,6 +768,13 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
         else rc = prologue_launch(x, B, N, pts0, centroid, scale0, F(p.o_pro), st);
     }
     if (rc != LS_OK) return rc;
+    // processing order of each level's points for the gather kernels (levels of at least 64 and at most 1024 points): level 0 here, the others
+    // behind their FPS launch on the side stream
+    auto ordered = [&](int level) { return m->order_pts && p.levelN[level] >= 64 && p.levelN[level] <= 1024; };
+    if (ordered(0)) {
+        rc = morton_order_launch(pts0, B, p.levelN[0], I(p.o_perm[0]), st);
+        if (rc != LS_OK) return rc;
+    }
 
     // ---- FPS chain on the side stream: depends on xyz only, overlaps with layers 0..first down-sample
     hipStream_t fs = m->fps_side ? m->side : st;
@@ -776,6 +792,10 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 rc = (skip & SK_FPS) ? LS_OK : fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), nullptr, 0, fs);
             }
             if (rc != LS_OK) return rc;
+            if (ordered(l + 1) && !(skip & SK_FPS)) {
+                rc = morton_order_launch(F(p.o_pts[l + 1]), B, p.levelN[l + 1], I(p.o_perm[l + 1]), fs);
+                if (rc != LS_OK) return rc;
+            }
             if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_fps[l], fs));
         }
         if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_join, fs));
@@ -791,6 +811,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
     const int32_t* prev_rows = nullptr;   // the previous layer's FPS selection (rows of its source set), if it down-sampled
     const float* cur_rm = nullptr;        // row maxima of `cur` ([rows][cur_rm_parts]) when the kernel that wrote it emitted them (GemmAux)
     int cur_rm_parts = 0;
+    int dst_level = 0;      // level of the current layer's destination points (0 = the input cloud)
     for (int i = 0; i < p.L; ++i) {
         if (i == m->debug_layers) {
             static bool printed = false;
@@ -809,7 +830,9 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             joined = p.level[i] == p.nlevels - 1;                                            // the last level joins the whole side chain
             dst_rows = trace_fps ? trace_fps + fps_off : I(p.o_fps[p.level[i] + 1]);
             fps_off += (size_t)B * Nd;
+            dst_level = p.level[i] + 1;
         }
+        const int32_t* perm = ordered(dst_level) ? I(p.o_perm[dst_level]) : nullptr;   // processing order of the destination points (same results either way)
         int32_t* knn = trace_knn ? trace_knn + knn_off : I((i & 1) ? p.o_knn2 : p.o_knn);  // ping-pong: layer i+1 is seeded by layer i
         knn_off += (size_t)B * Nd * 16;
         const bool attn = i >= d.atten_start_layer;
@@ -821,7 +844,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             { PROF(LS_K_KNN, i, st); rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
             if (rc != LS_OK) return rc;
             LS_REQUIRE(!attn, "encoder: attention at layer 0 unsupported (atten_start_layer >= 1)");
-            { PROF(LS_K_EDGE_L0, i, st); rc = (skip & SK_L0) ? LS_OK : edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
+            { PROF(LS_K_EDGE_L0, i, st); rc = (skip & SK_L0) ? LS_OK : edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st, perm); }
             if (rc != LS_OK) return rc;
         } else {
             const int Cin = p.Cin[i];
@@ -861,7 +884,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             }
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if (skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) rc = LS_OK;
-            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts);
+            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts, perm);
             if (rc != LS_OK) return rc;
         }
         cur_rm = nullptr; cur_rm_parts = 0;
