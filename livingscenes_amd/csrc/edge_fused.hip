@@ -26,8 +26,10 @@
 // sum, then over the heads ascending, instead of one 64-lane tree).
 // Measured (MI355X, B = 64, one step in flight, us per launch): layer 5 image 11 + q/k 37 + norms 6 + v 42 = 96 (table path 83 + 37 = 120);
 // layer 6 image 5 + q/k 59 + norms 6 + v 47 = 117 (96 + 54 = 150); whole bench 48.1k -> 50.0k object-instances/s.  What bounds the two big
-// kernels is the latency of the fragment streams (a k-step is 96 matrix-pipe cycles, an L2 round trip ~1 500) at two waves per SIMD, then the VN
-// activation's VALU work (~130 instructions per neighbour and lane); see DESIGN.md.
+// kernels (timing variants, 12 steps in flight, us: whole | attention loops only | GEMM phases only): layer 6 q/k 56 | 18 | 45, v 50 | 18 | 31;
+// layer 5 q/k 35 | 12 | 29, v 43 | 19 | 27.  The GEMM phases run at 20 - 30 % of the matrix peak: every wave streams its own copy of the A tiles
+// through the L1 (layer 6, k phase: 4 waves x (96 KB of A + 32 KB of W) per 576 MFMAs = 28 B/clk per wave against 64 B/clk per CU).  Sharing the A
+// image through LDS would cut that 2.3x, but 96 KB of planes + 52 KB of slabs leave one workgroup per CU; not built.
 #include "ls_common.h"
 
 namespace ls {
