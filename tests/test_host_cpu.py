@@ -552,7 +552,7 @@ def test_3rscan_reader_matches_the_reference_loader(golden):
 
 
 def test_packed_fp32_build_guard_fires_without_the_flag(tmp_path):
-    """build.py's determinism pin (DESIGN.md 10): edge.hip compiled WITHOUT -fno-slp-vectorize carries compiler-formed v_pk_*_f32 in the
+    """build.py's determinism pin (DESIGN.md 4.3): edge.hip compiled WITHOUT -fno-slp-vectorize carries compiler-formed v_pk_*_f32 in the
     gather kernels and the guard must refuse it; the objects of the real build pass."""
     import subprocess
     from livingscenes_amd import build as B
@@ -561,7 +561,9 @@ def test_packed_fp32_build_guard_fires_without_the_flag(tmp_path):
     flags = [f for f in B.FLAGS if f != "-fno-slp-vectorize"]
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-x", "hip", "-c", os.path.join(B.CSRC, "edge.hip"), "-o", str(tmp_path / "edge.o")])
     import shutil
-    shutil.copy(os.path.join(B.LIBDIR, "obj", "pointwise.o"), tmp_path / "pointwise.o")
+    for src in B.PACKED_FP32_GUARD:                                     # every other guarded object: the real build's (they pass)
+        if src != "edge.hip":
+            shutil.copy(os.path.join(B.LIBDIR, "obj", src.replace(".hip", ".o")), tmp_path / src.replace(".hip", ".o"))
     with pytest.raises(RuntimeError, match="packed fp32"):
         B.check_packed_fp32(str(tmp_path))
 
