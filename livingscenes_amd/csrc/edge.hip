@@ -611,6 +611,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     // The gathers alone take as long as the kernel: it is bound by the vector-memory path, not by the VALU -- and NOT by L2 traffic either (handing
     // the points out in Morton order cuts the distinct neighbour rows per workgroup from ~230 to 62 - 90 and changes nothing): 1.6 GB per launch have
     // to be DELIVERED by the L1s, 6.1 MB per CU at 64 B/clk = 46 us, and the two-deep pipeline of 16-byte loads does not overlap that with the arithmetic.
+    // Three workgroups per CU for the <16, 64> instance (hipcc's "desired occupancy was 3, final occupancy is 2": 172 VGPRs and 60 416 bytes of LDS)
+    // were BUILT in round 4 -- planes cut to the ROWS rows that exist, 128-byte rows XOR-swizzled instead of padded: 54 208 bytes, 168 VGPRs with 11
+    // spilled -- and measured SLOWER (116 vs 110 us at layer 3, 84 vs 81 us at layer 4 where the same edit cost 10 more spills): the third workgroup
+    // does not buy overlap that the spills do not take back.  Kept at two.
     // ---- B: K branch -> per-head scores for the 16 neighbours, normalised by the Frobenius norm of k
     // The gathers are a two-deep software pipeline (round 3): the 16 neighbour indices sit in registers (four 16-byte loads up front
     // instead of a dependent index load in front of every row gather) and the rows of neighbours k+1, k+2 are in flight while
