@@ -308,6 +308,53 @@ __device__ __forceinline__ void fma43(F43& acc, float w, const F43& y) {
     acc.z.x = __builtin_fmaf(w, y.z.x, acc.z.x); acc.z.y = __builtin_fmaf(w, y.z.y, acc.z.y); acc.z.z = __builtin_fmaf(w, y.z.z, acc.z.z); acc.z.w = __builtin_fmaf(w, y.z.w, acc.z.w);
 }
 
+// ---------------------------------------------------------------------------------------------- pool layers, float4 lanes (round 4)
+// edge_pool_kernel with a lane owning FOUR consecutive channels (16-byte gathers), a point = LPP = Co / 4 lanes, 64 / LPP points per wave: the
+// scalar kernel issues one 4-byte load per lane, channel group and row -- 256 bytes per wave instruction, 3.1 M load instructions per layer-1
+// launch (805 MB), the vector-memory issue rate its bound; this form issues a quarter of them.  Same additions in the same order per channel
+// (neighbours k = 0 .. 15 ascending, then x 1/16): bit-identical to edge_pool_kernel.
+template <int LPP>
+__global__ __launch_bounds__(256) void edge_pool_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq, int NQ,
+                                                           int q_via_rows, const int32_t* __restrict__ knn, const int32_t* __restrict__ dst_rows,
+                                                           int Nd, int Ns, float oms, float* __restrict__ out, int total, const int32_t* __restrict__ perm) {
+    constexpr int PPW = 64 / LPP, Co = 4 * LPP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPP, ll = lane % LPP;
+    int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * PPW + sub;
+    const bool live = pid < total;
+    if (!live) pid = total - 1;
+    if (perm) pid = perm[pid];
+    const int b = pid / Nd;
+    const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
+    const float* Tb = T + (size_t)b * Ns * 3 * ldt;
+    const float* Td = Tq + ((size_t)b * NQ + drow) * 3 * ldq;
+    const int c4 = ll * 4;
+    int nb[EK];
+    {
+        const int4* kp = reinterpret_cast<const int4*>(knn + (size_t)pid * EK);
+#pragma unroll
+        for (int u = 0; u < EK / 4; ++u) { const int4 v = kp[u]; nb[4 * u] = v.x; nb[4 * u + 1] = v.y; nb[4 * u + 2] = v.z; nb[4 * u + 3] = v.w; }
+    }
+    const F43 ql = ld43(Td + c4, ldq), qd = ld43(Td + Co + c4, ldq);
+    F43 acc;
+    acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = 0; k < EK; ++k) {
+        const float* Tr = Tb + (size_t)nb[k] * 3 * ldt + c4;
+        F43 y = add43(ld43(Tr, ldt), ql);
+        const F43 kd = add43(ld43(Tr + Co, ldt), qd);
+        act43(y, kd, oms);
+        acc = add43(acc, y);
+    }
+    if (live) {
+        float* op = out + (size_t)pid * 3 * Co + c4;
+        const float s = 1.0f / EK;
+        *reinterpret_cast<float4*>(op) = make_float4(acc.x.x * s, acc.x.y * s, acc.x.z * s, acc.x.w * s);
+        *reinterpret_cast<float4*>(op + Co) = make_float4(acc.y.x * s, acc.y.y * s, acc.y.z * s, acc.y.w * s);
+        *reinterpret_cast<float4*>(op + 2 * Co) = make_float4(acc.z.x * s, acc.z.y * s, acc.z.z * s, acc.z.w * s);
+    }
+}
+
 template <int LPP, int NCH>
 __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
                                                            int NQ, int q_via_rows, const int32_t* __restrict__ knn,
@@ -741,6 +788,15 @@ int edge_l0_launch(const float* pts, const int32_t* knn, const float* w0, int B,
 int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
                      const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st, const int32_t* perm) {
     const int total = B * Nd;
+    static const bool scalar_pool = getenv("LS_EDGE_POOL_SCALAR") && atoi(getenv("LS_EDGE_POOL_SCALAR")) != 0;   // A/B: the one-channel-per-lane kernel
+    if (!scalar_pool && ldt % 4 == 0 && ldq % 4 == 0 && (Co == 32 || Co == 64)) {
+        if (Co == 32)
+            hipLaunchKernelGGL((edge_pool_v4_kernel<8>), dim3(cdiv(total, 32)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total, perm);
+        else
+            hipLaunchKernelGGL((edge_pool_v4_kernel<16>), dim3(cdiv(total, 16)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total, perm);
+        LS_LAUNCH_CHECK();
+        return LS_OK;
+    }
     const int ppb = (Co <= 32) ? 8 : 4;
     hipLaunchKernelGGL(edge_pool_kernel, dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns,
                        Co, 1.0f - neg_slope, out, total, perm);

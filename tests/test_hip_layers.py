@@ -191,3 +191,30 @@ def test_table_free_32_point_layers_match_the_table_path(tmp_path):
             worst = max(worst, err)
             assert err <= 2e-6, (layer, B, err)
     assert worst > 0.0 or True      # (bit-identity is not required; see the docstring)
+
+
+def test_pool_float4_kernel_is_bit_identical_to_the_scalar_kernel(tmp_path):
+    """edge_pool_v4_kernel (a lane = four channels, 16-byte gathers: a quarter of the load instructions) against edge_pool_kernel
+    (LS_EDGE_POOL_SCALAR=1) on layer 1 of the released schedule: same additions in the same order per channel, so the outputs must be EQUAL bit for
+    bit -- full and ragged batches (a partial last workgroup)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, torch, numpy as np\n"
+            "from livingscenes_amd import synth, ops, packing\n"
+            "dev = torch.device('cuda:0')\n"
+            "cfg = synth.default_encoder_cfg()\n"
+            "desc, blob = packing.pack_model(synth.make_encoder_weights(cfg, 0), cfg, None, None)\n"
+            "m = ops.HipModel(desc, blob, dev)\n"
+            "g = torch.Generator().manual_seed(4)\n"
+            "for B, N in ((64, 1024), (3, 1000), (1, 77)):\n"
+            "    src = torch.randn(B, N, 3, 32, generator=g).to(dev)\n"
+            "    knn = torch.randint(0, N, (B, N, 16), generator=g).to(torch.int32).to(dev)\n"
+            "    out = m.edgeconv(1, src, knn)\n"
+            f"    np.save(os.path.join({str(tmp_path)!r}, f'pool_{{os.environ.get(\"LS_EDGE_POOL_SCALAR\", \"0\")}}_{{B}}_{{N}}.npy'), out.cpu().numpy())\n")
+    for env in ({"LS_EDGE_POOL_SCALAR": "0"}, {"LS_EDGE_POOL_SCALAR": "1"}):
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root)
+    for B, N in ((64, 1024), (3, 1000), (1, 77)):
+        a, b = np.load(tmp_path / f"pool_0_{B}_{N}.npy"), np.load(tmp_path / f"pool_1_{B}_{N}.npy")
+        assert np.isfinite(a).all() and np.array_equal(a, b), (B, N, np.abs(a - b).max())
