@@ -29,7 +29,13 @@
 // kernels (timing variants, 12 steps in flight, us: whole | attention loops only | GEMM phases only): layer 6 q/k 56 | 18 | 45, v 50 | 18 | 31;
 // layer 5 q/k 35 | 12 | 29, v 43 | 19 | 27.  The GEMM phases run at 20 - 30 % of the matrix peak: every wave streams its own copy of the A tiles
 // through the L1 (layer 6, k phase: 4 waves x (96 KB of A + 32 KB of W) per 576 MFMAs = 28 B/clk per wave against 64 B/clk per CU).  Sharing the A
-// image through LDS would cut that 2.3x, but 96 KB of planes + 52 KB of slabs leave one workgroup per CU; not built.
+// image through LDS would cut that 2.3x, but 96 KB of planes + 52 KB of slabs leave one workgroup per CU.  BUILT AND MEASURED instead (round 4, not
+// kept): (i) layer 6 with every A batch (4 k-steps, 8 KB) staged once per workgroup in a double-buffered 16 KB LDS ring and each wave keeping one
+// W tile: q/k 56 -> 59 us, v 50 -> 46 us; (ii) two interleaved accumulator chains per tile (even / odd k-steps): no change -- a dependent MFMA chain is
+// not what holds the phases back.  SQ counters (scripts/dev/sq_counters.sh, layer-6 q/k): a wave is parked on s_waitcnt / barriers 43 % of its
+// life, issue-stalled behind its own MFMAs 28 %, issuing 28 %; the matrix pipes are busy 20 % of the launch.  With 8 waves per CU (242 - 254 VGPRs, 52 - 69 KB
+// of LDS) nothing overlaps a workgroup's GEMM phase with another's attention phase except by chance; the structural remedy -- a persistent
+// workgroup per instance whose MFMA waves run one head group ahead of its VALU waves -- is the next step, not a tweak of this one.
 #include "ls_common.h"
 
 namespace ls {
