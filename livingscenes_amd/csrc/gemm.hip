@@ -698,7 +698,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 // redoes on data that 2 047 / 5 other workgroups also split), 32 KB of L1 fill and 96 KB of LDS traffic per 96 MFMAs.  A 256 x 256
 // tile halves the global bytes, the LDS writes and the split work per MFMA, the 4 x 2 wave tile takes a quarter off the LDS operand
 // reads.  The accumulators of a 4 x 2 wave tile fit only if the main and the cross terms share them: 128 VGPRs.
-template <bool MASKED, bool WPL>
+// PP ("ping-pong", round 4, LS_GEMM_W2_PP=1; OFF by default): the two waves that share a SIMD (w and w + 4) run half a slab step apart.  A
+// step is cut into a MEMORY phase (the 12 ds_read_b128 of the step's operand fragments, the split + LDS stores of the next slab, the
+// global loads of the slab after it) and a COMPUTE phase (the step's 24 MFMAs and nothing else), with a workgroup barrier after each;
+// waves 4 - 7 pass one extra barrier before the loop and waves 0 - 3 one after it, so at any time one wave per SIMD is in its compute
+// phase while the other fills its registers.  Same products in the same order: bit-identical.  Buffer hand-over: slab s + 1 is written in
+// the four phases in which slab s is read (the last readers of the old content finished one barrier earlier) and first read after the
+// barrier that closes them.
+// MEASURED (decoder shape 262 144 x 768 x 768, scripts/dev/w2_variants.sh, w2_clock.sh; profiles/r4_final/gemm_w2_power.txt): 957 us
+// against 928 us for the in-step loop -- and the reason the answer is not "fewer stalls": this GEMM runs at the SOCKET POWER CAP.
+// rocm-smi while it runs back to back: 1 400 W (the TDP), shader clock 1.70 GHz (in-step) / 1.82 GHz (ping-pong) instead of 2.39 GHz;
+// the timing variants that remove the MFMAs, the LDS reads or the producer work run at 2.39 GHz and 975 - 1 255 W.  Under the cap the
+// firmware trades every removed stall for clock: ping-pong needs 10 % MORE cycles (four barriers per slab) at a 7 % higher clock.  What
+// is left to gain is energy per tile (fewer bytes moved per MFMA), not issue slots; "matrix pipe 55 % busy" is 55 % of the cycles of a
+// clock the matrix pipe itself pulled down.
+template <bool MASKED, bool WPL, bool PP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_w2_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc,
     int M, int N, int K, int relu, int ntiles_n, int ntiles, const float* __restrict__ mask, GemmAux aux) {
@@ -727,10 +741,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 
     // staging map: 256 rows x 8 float4 (32 k) per operand slab over 512 threads: four per thread (rows sr0 + 64 h)
     const int sr0 = tid >> 3, sk = (tid & 7) * 4;
+    // (operand addresses = a wave-uniform base + a 32-bit byte offset per staged row: the launch keeps operands below 4 GB; the A rows' power
+    // of two as an exponent applied by v_ldexp_f32 -- a packed multiply keeps every scale twice; both save registers the ping-pong loop needs)
     float4 ra[4], rb[4];
-    const float* arow[4];
-    const float* brow[4];
-    float sa[4] = {1.f, 1.f, 1.f, 1.f}, sw[4] = {1.f, 1.f, 1.f, 1.f};
+    unsigned aoff[4], boff[4];
+    float sw[4] = {1.f, 1.f, 1.f, 1.f};
+    int ea[4] = {0, 0, 0, 0};
     int swz[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -739,43 +755,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        arow[h] = A + (size_t)min(m0 + sr0 + h * 64, M - 1) * lda + sk;
-        brow[h] = W + (size_t)min(n0 + sr0 + h * 64, N - 1) * ldw + sk;
+        aoff[h] = ((unsigned)min(m0 + sr0 + h * 64, M - 1) * (unsigned)lda + sk) * 4u;
+        boff[h] = ((unsigned)min(n0 + sr0 + h * 64, N - 1) * (unsigned)ldw + sk) * 4u;
     }
     auto gload_a = [&](int k0) {
         const int ko = min(k0, K - 32);
 #pragma unroll
-        for (int h = 0; h < 4; ++h) ra[h] = *reinterpret_cast<const float4*>(arow[h] + ko);
+        for (int h = 0; h < 4; ++h) {
+            asm volatile("" : "+v"(aoff[h]));   // (keeps the zero-extension next to the load: hoisted out of the loop it becomes a 64-bit register pair per row instead of the scalar-base addressing mode)
+            ra[h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A + ko) + aoff[h]);
+        }
     };
     // WPL (GemmAux::w_planes): a W row's slab is one 128-byte line [hi | lo]; thread -> chunk tid & 7 of rows (tid >> 3) + 64 u
-    const char* prow[4];
+    unsigned poff[4];
     int pswz[4];
     float4 pb0, pb1, pb2, pb3;
     if constexpr (WPL) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = sr0 + 64 * u, c8 = tid & 7;
-            prow[u] = static_cast<const char*>(aux.w_planes) + (size_t)min(n0 + r, N - 1) * ((size_t)K * 4) + c8 * 16;
+            poff[u] = (unsigned)min(n0 + r, N - 1) * ((unsigned)K * 4u) + c8 * 16;
             pswz[u] = (c8 >> 2) * PLANE + r * 64 + (((c8 & 3) ^ ((r >> 2) & 3)) << 4);
         }
     }
     auto gload_b = [&](int k0) {
         const int ko = min(k0, K - 32);
         if constexpr (WPL) {
-            pb0 = *reinterpret_cast<const float4*>(prow[0] + ko * 4); pb1 = *reinterpret_cast<const float4*>(prow[1] + ko * 4);
-            pb2 = *reinterpret_cast<const float4*>(prow[2] + ko * 4); pb3 = *reinterpret_cast<const float4*>(prow[3] + ko * 4);
+            const char* pk = static_cast<const char*>(aux.w_planes) + ko * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(poff[u]));
+            pb0 = *reinterpret_cast<const float4*>(pk + poff[0]); pb1 = *reinterpret_cast<const float4*>(pk + poff[1]);
+            pb2 = *reinterpret_cast<const float4*>(pk + poff[2]); pb3 = *reinterpret_cast<const float4*>(pk + poff[3]);
             return;
         }
 #pragma unroll
-        for (int h = 0; h < 4; ++h) rb[h] = *reinterpret_cast<const float4*>(brow[h] + ko);
+        for (int h = 0; h < 4; ++h) {
+            asm volatile("" : "+v"(boff[h]));
+            rb[h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W + ko) + boff[h]);
+        }
     };
     auto stage_w = [&](char* Bp, int h) {
         if constexpr (WPL) *reinterpret_cast<float4*>(Bp + pswz[h]) = h == 0 ? pb0 : (h == 1 ? pb1 : (h == 2 ? pb2 : pb3));   // (named registers: as an array these went to scratch)
         else { uint2 ph, pl; split2_f16s<1>(rb[h], sw[h], ph, pl); *reinterpret_cast<uint2*>(Bp + swz[h]) = ph; *reinterpret_cast<uint2*>(Bp + PLANE + swz[h]) = pl; }
     };
-    auto lstore2 = [&](char* plane_hi, const float4& v, float sc, int off) {
+    auto lstore2 = [&](char* plane_hi, const float4& v, int e, int off) {
         uint2 ph, pl;
-        split2_f16s<0>(v, sc, ph, pl);
+        split2_f16_pair(f32x2_t{__builtin_ldexpf(v.x, e), __builtin_ldexpf(v.y, e)}, ph.x, pl.x);   // == v * 2^e, as split2_f16s
+        split2_f16_pair(f32x2_t{__builtin_ldexpf(v.z, e), __builtin_ldexpf(v.w, e)}, ph.y, pl.y);
         *reinterpret_cast<uint2*>(plane_hi + off) = ph;
         *reinterpret_cast<uint2*>(plane_hi + PLANE + off) = pl;
     };
@@ -811,9 +837,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            float ia, iw;
-            pow2_scale(ma[h], sa[h], ia);
+            float ia, iw, sah;
+            pow2_scale(ma[h], sah, ia);
             pow2_scale(mw[h], sw[h], iw);
+            ea[h] = pow2_e(sah);
             if ((tid & 7) == 0) { rsc[sr0 + h * 64] = pow2_e(ia); rsc[TM + sr0 + h * 64] = pow2_e(iw); }
         }
     }
@@ -826,11 +853,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 
     gload_a(0); gload_b(0);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], sa[h], swz[h]); stage_w(smem + 2 * PLANE, h); }
+    for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], ea[h], swz[h]); stage_w(smem + 2 * PLANE, h); }
     gload_a(32); gload_b(32);
     __syncthreads();
 
     int cur = 0;
+    const bool late_half = __builtin_amdgcn_readfirstlane(wave) >= 4;   // (waves w and w + 4 share a SIMD: the other pairings measured 1 064 - 1 083 us)
+    if constexpr (PP) { if (late_half) __builtin_amdgcn_s_barrier(); }
     for (int k0 = 0; k0 < K; k0 += 32, cur ^= 1) {
         const char* Ac = smem + cur * BUF;
         const char* Bc = Ac + 2 * PLANE;
@@ -847,26 +876,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + offa[i] + ((q ^ xa[i]) << 4)));
             }
+            if constexpr (PP) {
+                // memory phase: the producer work of this half step, then the barrier; compute phase: MFMAs only
+                if (s2 == 0) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) lstore2(An, ra[h], ea[h], swz[h]);
+                    gload_a(k0 + 64);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) stage_w(Bn, h);
+                    gload_b(k0 + 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS stores have landed, its fragments have arrived
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             // per accumulator and 16-k step: lo(a) hi(w), hi(a) hi(w), hi(a) lo(w) -- the order every unified-accumulator kernel uses
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[0], sa[0], swz[0]); lstore2(An, ra[1], sa[1], swz[1]); }
+            if (s2 == 0) { lstore2(An, ra[0], ea[0], swz[0]); lstore2(An, ra[1], ea[1], swz[1]); }
             else { stage_w(Bn, 0); stage_w(Bn, 1); }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[2], sa[2], swz[2]); lstore2(An, ra[3], sa[3], swz[3]); gload_a(k0 + 64); }
+            if (s2 == 0) { lstore2(An, ra[2], ea[2], swz[2]); lstore2(An, ra[3], ea[3], swz[3]); gload_a(k0 + 64); }
             else { stage_w(Bn, 2); stage_w(Bn, 3); gload_b(k0 + 64); }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
+        if constexpr (!PP) __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
     }
+    if constexpr (PP) { if (!late_half) __builtin_amdgcn_s_barrier(); }   // the barrier counts of the two halves match again
 
     // (Not kept: s_setprio(1) around the MFMA groups: 930 -> 1 055 us.  The operand fragments as an explicit four-sub-phase software pipeline -- every LDS read batch one sub-phase ahead of its
     // MFMAs, the barrier in front of the last sub-phase.  Unfenced, the scheduler sinks the loads back to their uses: same time; fenced
@@ -1787,7 +1851,8 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         if (K == 32) { if (a_rows) LS_H2SK(32, true); else LS_H2SK(32, false); }
         else { if (a_rows) LS_H2SK(64, true); else LS_H2SK(64, false); }
 #undef LS_H2SK
-    } else if (split && pieces == 22 && wide_on && !a_rows && K % 32 == 0 && K >= 128) {
+    } else if (split && pieces == 22 && wide_on && !a_rows && K % 32 == 0 && K >= 128 && (unsigned long long)M * lda < (1ull << 30) &&
+               (unsigned long long)N * std::max(ldw, K) < (1ull << 30)) {   // (the wide kernel addresses its operands by 32-bit byte offsets)
         const int wtm = cdiv(M, 256), wtn = cdiv(N, 256);
         const size_t lds = 2 * 4 * 256 * 64 + 512 * sizeof(float);
         // the dynamic-LDS opt-in is a per-DEVICE function attribute: one flag per device ordinal (a process may drive several GPUs)
@@ -1796,19 +1861,22 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         LS_HIP_CHECK(hipGetDevice(&dev_ord));
         const unsigned long long dev_bit = 1ull << (dev_ord & 63);
         if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
-            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define LS_W2_ATTR(MK, PL, PG) LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<MK, PL, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            LS_W2_ATTR(false, false, false); LS_W2_ATTR(true, false, false); LS_W2_ATTR(false, true, false); LS_W2_ATTR(true, true, false);
+            LS_W2_ATTR(false, false, true); LS_W2_ATTR(true, false, true); LS_W2_ATTR(false, true, true); LS_W2_ATTR(true, true, true);
+#undef LS_W2_ATTR
             attr_devices.fetch_or(dev_bit, std::memory_order_release);
         }
         // LS_GEMM_W2_PERSIST=1: one workgroup per CU walking the tiles (measured: 942 - 944 vs 950 - 956 us at the decoder shape, but 73 -> 79 us at
         // 480 tiles, where the static assignment balances worse than the dispatcher) -- off by default
         static const bool w2_persist = getenv("LS_GEMM_W2_PERSIST") && atoi(getenv("LS_GEMM_W2_PERSIST")) != 0;
         const int w2_grid = w2_persist ? std::min(wtm * wtn, 256) : wtm * wtn;
-#define LS_W2(MK, PL) hipLaunchKernelGGL((gemm_w2_kernel<MK, PL>), dim3(w2_grid), dim3(512), lds, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, wtn, wtm * wtn, mask, aux)
-        if (mask) { if (wpl) LS_W2(true, true); else LS_W2(true, false); }
-        else { if (wpl) LS_W2(false, true); else LS_W2(false, false); }
+        static const bool w2_pp = getenv("LS_GEMM_W2_PP") && atoi(getenv("LS_GEMM_W2_PP")) != 0;   // A/B: the two waves of a SIMD half a step apart (bit-identical, measured slower: see the kernel)
+#define LS_W2(MK, PL, PG) hipLaunchKernelGGL((gemm_w2_kernel<MK, PL, PG>), dim3(w2_grid), dim3(512), lds, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, wtn, wtm * wtn, mask, aux)
+#define LS_W2P(MK, PL) do { if (w2_pp) LS_W2(MK, PL, true); else LS_W2(MK, PL, false); } while (0)
+        if (mask) { if (wpl) LS_W2P(true, true); else LS_W2P(true, false); }
+        else { if (wpl) LS_W2P(false, true); else LS_W2P(false, false); }
+#undef LS_W2P
 #undef LS_W2
     } else if (split && pieces == 22)
         hipLaunchKernelGGL(LS_H2_KERNEL, dim3(tm * tn), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, tn, a_rows,
