@@ -712,10 +712,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 // firmware trades every removed stall for clock: ping-pong needs 10 % MORE cycles (four barriers per slab) at a 7 % higher clock.  What
 // is left to gain is energy per tile (fewer bytes moved per MFMA), not issue slots; "matrix pipe 55 % busy" is 55 % of the cycles of a
 // clock the matrix pipe itself pulled down.
-template <bool MASKED, bool WPL, bool PP>
+template <bool MASKED, int WPLM, bool PP>   // WPLM: 0 = W rows split here, 1 = pre-split planes staged through registers, 2 = planes by LDS-direct loads
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_w2_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias, float* __restrict__ out, int ldc,
     int M, int N, int K, int relu, int ntiles_n, int ntiles, const float* __restrict__ mask, GemmAux aux) {
+    constexpr bool WPL = WPLM != 0, WDIR = WPLM == 2;
+    static_assert(!(WDIR && PP), "the LDS-direct W path belongs to the in-step loop");
     constexpr int TM = 256, TN = 256;
     constexpr int STG = 32 * 68;
     constexpr int PLANE = TM * 64;         // one f16 plane: 256 rows x 32 k
@@ -778,8 +780,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
             pswz[u] = (c8 >> 2) * PLANE + r * 64 + (((c8 & 3) ^ ((r >> 2) & 3)) << 4);
         }
     }
+    // WDIR (round 4): the W planes go global -> LDS without passing through registers (global_load_lds_dwordx4: the wave's 64 lanes fill
+    // 1 KB of LDS starting at M0, lane l -> LDS slot l, so the slot swizzle is applied on the GLOBAL side: lane l of the instruction for
+    // plane p, rows r0 .. r0 + 15 fetches chunk (l & 3) ^ ((r >> 2) & 3) of row r = r0 + (l >> 2)).  Wave w owns rows 32 w .. 32 w + 31:
+    // four instructions per slab instead of four 16-byte register loads + four ds_write_b128, and 16 VGPRs fewer.  A slab's loads are
+    // issued during the slab BEFORE it (their buffer was released by the barrier just passed), right after that slab's A rows left their
+    // registers and right before the next A rows are requested, and awaited by s_waitcnt vmcnt(4) in front of the closing barrier -- the
+    // four younger loads are those A rows (a sched_barrier pins them above the wait).  The loads are INLINE ASM on purpose: told about an
+    // LDS-direct load (the builtin), hipcc answers every workgroup barrier and every use of a register load with s_waitcnt vmcnt(0) --
+    // i.e. waits for the A rows it has just requested, once per slab.  Unknown to the compiler they only make its own waits for the A
+    // rows wait for older loads as well, which by then have been awaited here.
+    unsigned doff[4];
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (WDIR) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = wave * 32 + (u & 1) * 16 + (lane >> 2), pl = u >> 1;
+            doff[u] = (unsigned)min(n0 + r, N - 1) * ((unsigned)K * 4u) + pl * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+        }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dload_w = [&](char* Bp, int k0) {   // W slab k0 -> the planes at Bp.  Inline asm: see the ordering note above
+        const int ko = min(k0, K - 32);
+        const char* pk = static_cast<const char*>(aux.w_planes) + ko * 4;
+        const unsigned l0 = lds0 + (unsigned)(Bp - smem) + wave_s * (32 * 64);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l0 + (u >> 1) * PLANE + (u & 1) * (16 * 64)), "v"(doff[u]), "s"(pk) : "memory", "m0");
+#pragma clang diagnostic pop
+    };
     auto gload_b = [&](int k0) {
         const int ko = min(k0, K - 32);
+        if constexpr (WDIR) return;
         if constexpr (WPL) {
             const char* pk = static_cast<const char*>(aux.w_planes) + ko * 4;
 #pragma unroll
@@ -795,6 +829,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
     };
     auto stage_w = [&](char* Bp, int h) {
+        if constexpr (WDIR) return;
         if constexpr (WPL) *reinterpret_cast<float4*>(Bp + pswz[h]) = h == 0 ? pb0 : (h == 1 ? pb1 : (h == 2 ? pb2 : pb3));   // (named registers: as an array these went to scratch)
         else { uint2 ph, pl; split2_f16s<1>(rb[h], sw[h], ph, pl); *reinterpret_cast<uint2*>(Bp + swz[h]) = ph; *reinterpret_cast<uint2*>(Bp + PLANE + swz[h]) = pl; }
     };
@@ -851,10 +886,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
     for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; offb[j] = r * 64; xb[j] = (r >> 2) & 3; }
 
+    if constexpr (WDIR) dload_w(smem + 2 * PLANE, 0);
     gload_a(0); gload_b(0);
 #pragma unroll
     for (int h = 0; h < 4; ++h) { lstore2(smem, ra[h], ea[h], swz[h]); stage_w(smem + 2 * PLANE, h); }
     gload_a(32); gload_b(32);
+    if constexpr (WDIR) {   // vmcnt(4): everything but the A rows of slab 1
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0f74);
+    }
     __syncthreads();
 
     int cur = 0;
@@ -921,12 +961,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-            if (s2 == 0) { lstore2(An, ra[2], ea[2], swz[2]); lstore2(An, ra[3], ea[3], swz[3]); gload_a(k0 + 64); }
+            if (s2 == 0) {
+                lstore2(An, ra[2], ea[2], swz[2]); lstore2(An, ra[3], ea[3], swz[3]);
+                if constexpr (WDIR) dload_w(Bn, k0 + 32);   // (after the A rows have been consumed, before the next ones are requested: see dload_w)
+                gload_a(k0 + 64);
+            }
             else { stage_w(Bn, 2); stage_w(Bn, 3); gload_b(k0 + 64); }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (WDIR) {   // vmcnt(4): this slab's LDS-direct W loads have landed (younger: the A rows of slab + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0f74);
         }
         if constexpr (!PP) __syncthreads();   // buffer cur^1 is complete, and every wave is done reading buffer cur
     }
@@ -1862,8 +1910,9 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         const unsigned long long dev_bit = 1ull << (dev_ord & 63);
         if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
 #define LS_W2_ATTR(MK, PL, PG) LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<MK, PL, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-            LS_W2_ATTR(false, false, false); LS_W2_ATTR(true, false, false); LS_W2_ATTR(false, true, false); LS_W2_ATTR(true, true, false);
-            LS_W2_ATTR(false, false, true); LS_W2_ATTR(true, false, true); LS_W2_ATTR(false, true, true); LS_W2_ATTR(true, true, true);
+            LS_W2_ATTR(false, 0, false); LS_W2_ATTR(true, 0, false); LS_W2_ATTR(false, 1, false); LS_W2_ATTR(true, 1, false);
+            LS_W2_ATTR(false, 0, true); LS_W2_ATTR(true, 0, true); LS_W2_ATTR(false, 1, true); LS_W2_ATTR(true, 1, true);
+            LS_W2_ATTR(false, 2, false); LS_W2_ATTR(true, 2, false);
 #undef LS_W2_ATTR
             attr_devices.fetch_or(dev_bit, std::memory_order_release);
         }
@@ -1872,10 +1921,13 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         static const bool w2_persist = getenv("LS_GEMM_W2_PERSIST") && atoi(getenv("LS_GEMM_W2_PERSIST")) != 0;
         const int w2_grid = w2_persist ? std::min(wtm * wtn, 256) : wtm * wtn;
         static const bool w2_pp = getenv("LS_GEMM_W2_PP") && atoi(getenv("LS_GEMM_W2_PP")) != 0;   // A/B: the two waves of a SIMD half a step apart (bit-identical, measured slower: see the kernel)
+        // LS_GEMM_W2_DIRECT=1: the W planes by LDS-direct loads (bit-identical; measured 907 / 933 us against 915 / 925 us through registers on two
+        // boxes at the decoder shape: no difference -- the kernel is power-bound, see the kernel's header)
+        static const bool w2_direct = getenv("LS_GEMM_W2_DIRECT") && atoi(getenv("LS_GEMM_W2_DIRECT")) != 0;
 #define LS_W2(MK, PL, PG) hipLaunchKernelGGL((gemm_w2_kernel<MK, PL, PG>), dim3(w2_grid), dim3(512), lds, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, wtn, wtm * wtn, mask, aux)
-#define LS_W2P(MK, PL) do { if (w2_pp) LS_W2(MK, PL, true); else LS_W2(MK, PL, false); } while (0)
-        if (mask) { if (wpl) LS_W2P(true, true); else LS_W2P(true, false); }
-        else { if (wpl) LS_W2P(false, true); else LS_W2P(false, false); }
+#define LS_W2P(MK, PL) do { if (w2_pp) LS_W2(MK, PL, true); else if (PL == 1 && w2_direct) LS_W2(MK, 2, false); else LS_W2(MK, PL, false); } while (0)
+        if (mask) { if (wpl) LS_W2P(true, 1); else LS_W2P(true, 0); }
+        else { if (wpl) LS_W2P(false, 1); else LS_W2P(false, 0); }
 #undef LS_W2P
 #undef LS_W2
     } else if (split && pieces == 22)

@@ -1,5 +1,5 @@
 """gemm_w2_kernel (256 x 256 tiles) against gemm_h2_kernel (128 x 128): bit-identity and time per shape, the wide kernel with both waves of a SIMD in step
-(LS_GEMM_W2_PP=0, the default) and half a step apart (=1).  The switches are read once per process, so each setting runs in a child."""
+(LS_GEMM_W2_PP=0, the default) and half a step apart (=1), the pre-split W planes through registers (LS_GEMM_W2_DIRECT=0, the default) and by LDS-direct loads (=1).  The switches are read once per process, so each setting runs in a child."""
 import os, subprocess, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 CHILD = r'''
@@ -33,6 +33,6 @@ for (M, N, K) in [(1000, 300, 128), (777, 520, 256), (4096, 768, 768), (6144, 15
     t2 = min(timed(lambda: ops.gemm_chain(A, W, b, relu=True, a_rowmax=am, w_rowmax=wm, w_planes=planes)) for _ in range(2))
     print(f"{M:7d} {N:5d} {K:4d}  err {err:5.2f}  md5 {h}  {t:8.1f} us   W pre-split {t2:8.1f} us  (identical: {same})")
 ''' % ROOT
-for w, pp in (("0", "1"), ("1", "0"), ("1", "1")):
-    print("LS_GEMM_WIDE =", w, " LS_GEMM_W2_PP =", pp, flush=True)
-    subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, LS_GEMM_WIDE=w, LS_GEMM_W2_PP=pp))
+for w, pp, dw in (("0", "0", "1"), ("1", "0", "0"), ("1", "0", "1"), ("1", "1", "1")):
+    print("LS_GEMM_WIDE =", w, " LS_GEMM_W2_PP =", pp, " LS_GEMM_W2_DIRECT =", dw, flush=True)
+    subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, LS_GEMM_WIDE=w, LS_GEMM_W2_PP=pp, LS_GEMM_W2_DIRECT=dw))
