@@ -677,14 +677,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     qgemm(2 * Co);
     __syncthreads();
     {
-        F43 py0 = ld43(nrow(0) + 2 * Co, ldt), pd0 = ld43(nrow(0) + 3 * Co, ldt);
-        F43 py1 = ld43(nrow(1) + 2 * Co, ldt), pd1 = ld43(nrow(1) + 3 * Co, ldt);
+        // (DP = 3 / 4 -- 195 / 219 VGPRs, still two workgroups per CU -- measured in round 4: layers 2 / 3 / 4 at 120 / 114 / 81 and 120 / 113 / 82 us
+        //  against 110 / 111 / 84 us: a deeper prefetch does not deliver the rows faster, the vector-memory path is at its throughput)
+        constexpr int DP = 2;
+        F43 py[DP], pd[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) { py[d] = ld43(nrow(d) + 2 * Co, ldt); pd[d] = ld43(nrow(d) + 3 * Co, ldt); }
         const F43 ql = lds43(0), qd = lds43(Co);
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
-            F43 y = py0, kd = pd0;
-            py0 = py1; pd0 = pd1;
-            if (k + 2 < EK) { py1 = ld43(nrow(k + 2) + 2 * Co, ldt); pd1 = ld43(nrow(k + 2) + 3 * Co, ldt); }
+            F43 y = py[k % DP], kd = pd[k % DP];
+            if (k + DP < EK) { py[k % DP] = ld43(nrow(k + DP) + 2 * Co, ldt); pd[k % DP] = ld43(nrow(k + DP) + 3 * Co, ldt); }
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this neighbour's arithmetic (the scheduler would sink it to its first use)
             y = add43(y, ql);
             kd = add43(kd, qd);
@@ -716,13 +719,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         const F43 ql = lds43(0), qd = lds43(Co);
         F43 acc;
         acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
-        F43 py0 = ld43(nrow(0), ldt), pd0 = ld43(nrow(0) + Co, ldt);
-        F43 py1 = ld43(nrow(1), ldt), pd1 = ld43(nrow(1) + Co, ldt);
+        constexpr int DP = 2;
+        F43 py[DP], pd[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) { py[d] = ld43(nrow(d), ldt); pd[d] = ld43(nrow(d) + Co, ldt); }
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
-            F43 y = py0, kd = pd0;
-            py0 = py1; pd0 = pd1;
-            if (k + 2 < EK) { py1 = ld43(nrow(k + 2), ldt); pd1 = ld43(nrow(k + 2) + Co, ldt); }
+            F43 y = py[k % DP], kd = pd[k % DP];
+            if (k + DP < EK) { py[k % DP] = ld43(nrow(k + DP), ldt); pd[k % DP] = ld43(nrow(k + DP) + Co, ldt); }
             __builtin_amdgcn_sched_barrier(0);
             y = add43(y, ql);
             kd = add43(kd, qd);
