@@ -249,6 +249,22 @@ __device__ __forceinline__ void cx64(u64& v, int lane) {
 // ascending sort of one value per lane over the 64 lanes: bitonic network in the "flip" form (first step of every merge
 // pairs lane i with lane i ^ (k-1), the rest are plain half-cleaners), so that every exchange is a lane-xor and 13 of the 21
 // stages are DPP moves
+// An upper bound of the K-th smallest of the wave's 64 values v (bit patterns of non-negative floats, +inf = 0x7F800000 for "none"): the
+// smallest T whose low 15 bits are ones with at least K values <= T -- a radix select on bits 30 .. 15, one v_cmp per bit, the counting on
+// the scalar unit (ballot, s_bcnt1) -- at most 2^-8 above the K-th smallest itself.  The admission thresholds of knn_xyz_kernel and
+// knn_finish_select_kernel only have to be VALID (>= the K-th smallest) and tight; until round 4 they sorted the 64 values with the 21-stage
+// network below and read lane K - 1: ~125 VALU instructions per query against 16 here, in kernels that are VALU-issue-bound.
+__device__ __forceinline__ unsigned kth_smallest_upper_bound(unsigned v, int K) {
+    unsigned ans = 0;
+#pragma unroll
+    for (int bit = 30; bit >= 15; --bit) {
+        const unsigned t = ans | ((1u << bit) - 1u);
+        const int cnt = __builtin_popcountll(__ballot(v <= t));
+        ans |= cnt >= K ? 0u : (1u << bit);
+    }
+    return min(ans | 0x7FFFu, 0x7F800000u);
+}
+
 #define LS_SORT64(CX, v, lane)                                                                                         \
     CX<1>(v, lane);                                                                                                    \
     CX<3>(v, lane); CX<1>(v, lane);                                                                                    \

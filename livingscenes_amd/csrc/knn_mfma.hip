@@ -1088,9 +1088,7 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
         himin = fminf(himin, hi);
     }
     // 2. T = the K-th smallest of the 64 lane minima (non-negative floats order like their bit patterns)
-    unsigned hb = __float_as_uint(himin);
-    LS_SORT64(cx32, hb, lane)
-    const float T = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)hb, K - 1 < 63 ? K - 1 : 63));
+    const float T = __uint_as_float(kth_smallest_upper_bound(__float_as_uint(himin), K < 64 ? K : 64));   // (knn_common.h: a valid bound, <= 2^-8 above the K-th minimum)
     // 3. survivors -> the wave's LDS list
     unsigned short* sp = llist[wave];
     int cnt = 0;

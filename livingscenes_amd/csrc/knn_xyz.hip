@@ -7,8 +7,8 @@
 // incremental top-K insertion (an un-seeded query inserts ~16 (1 + ln(Ns/16)) = 83 candidates, one ballot round each) and in
 // the four workgroup barriers per 64 x 64 tile.  Here a WAVE owns a query and a lane owns 16 candidates (1024 per chunk):
 //   1. d[16] per lane in registers (same fp32 chain as knn.hip / the oracle: ((0 + dx^2) + dy^2) + dz^2, FMA flag honoured);
-//   2. the K-th smallest of the 64 per-lane minima (a 21-stage 64-lane sorting network on the float bits) is an upper bound of
-//      the K-th smallest distance -- 64 disjoint candidate groups contribute one candidate each -- and admits ~18 of 1024
+//   2. the K-th smallest of the 64 per-lane minima (round 4: a radix select on the float bits' top 16 bits, 2^-8 above it at most; before: a
+//      21-stage 64-lane sorting network) is an upper bound of the K-th smallest distance -- 64 disjoint candidate groups contribute one candidate each -- and admits ~18 of 1024
 //      candidates on average;
 //   3. the admitted (dist, idx) keys are compacted through LDS (ballot + mbcnt) and sorted by one 64-lane network on the
 //      u64 keys together with the list carried over from the previous chunk (more than 48 admitted keys -- exact ties, tiny
@@ -75,8 +75,7 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_kernel(const float* __restrict
             }
             // admission threshold: K-th smallest lane minimum, tightened by the carried list's K-th key; capped at the largest
             // finite float so that the +inf padding columns never pass
-            LS_SORT64(cx32, mn, lane)
-            unsigned thr = (unsigned)__builtin_amdgcn_readlane((int)mn, K - 1);
+            unsigned thr = kth_smallest_upper_bound(mn, K);   // (knn_common.h)
             thr = min(thr, (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best >> 32), K - 1));
             thr = min(thr, 0x7F7FFFFFu);
             int n = 0;
