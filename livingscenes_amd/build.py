@@ -23,7 +23,9 @@ SOURCES = ["model.hip", "knn.hip", "knn_mfma.hip", "knn_xyz.hip", "fps.hip", "ge
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
          "-ffp-contract=fast-honor-pragmas", "-fno-slp-vectorize"]
 # pointwise.hip: the LOOP vectoriser (VF = 2) also forms v_pk_*_f32 (15 in tail_kernel): off for that file
-EXTRA_FLAGS = {"pointwise.hip": ["-fno-vectorize"]}   # per-file additions: {"file.hip": [flags]}
+# per-file additions: {"file.hip": [flags]}.  knn_mfma.hip: the 32 x 32 MFMA results of the sweep kernels are consumed element by element by VALU
+# compares; in AGPRs (hipcc's default) every element costs a v_accvgpr_read first -- 16 extra VALU instructions per tile in VALU-bound kernels
+EXTRA_FLAGS = {"pointwise.hip": ["-fno-vectorize"], "knn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # Build-time pin of the determinism fix above: the device code of these files is disassembled after every compile and the build FAILS
 # if a packed fp32 instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) shows up in a kernel whose name contains none of the
 # allowed substrings -- a future hipcc, a dropped flag or an innocent float2 cannot silently bring the defect back.  Allowed: the

@@ -752,6 +752,17 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
                 A[u][rr] = q < Nd ? 0.5f * (om * nd[u][rr] - kth) : INFINITY;                             // padding query: 0 < inf, always dropped
                 IQ[u][rr] = q < Nd ? IQ[u][rr] : 0.f;
             }
+        // The test  S iq ic < A + Bc  with the row / column scales iq, ic exact powers of two, rearranged (round 4) so that a tile costs one
+        // multiply, one fma, one compare and one add-with-carry per pair instead of seven instructions:  S < (A / iq) (1 / ic) + (Bc / ic) (1 / iq).
+        // Scaling by powers of two commutes with the one rounding of the sum (A + Bc), so every decision is the one the old form took.
+#pragma unroll
+        for (int u = 0; u < QG; ++u)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const float inv = IQ[u][rr] > 0.f ? __uint_as_float(0x7F000000u - __float_as_uint(IQ[u][rr])) : 0.f;   // 1 / 2^e exactly (0 marks a padding query, whose A is +inf)
+                A[u][rr] = IQ[u][rr] > 0.f ? A[u][rr] * inv : INFINITY;
+                IQ[u][rr] = inv;
+            }
     }
     // hint bitmap of the wave's queries.  The keys are loaded BEFORE the LDS clear (the wave barriers are scheduling fences: the
     // loads would otherwise be issued only after the clear, one more exposed memory round trip per wave)
@@ -791,8 +802,9 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) ti.bf[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
         const int cg = tc * 32 + l31;
-        ti.Bc = 0.5f * om * nsb[min(cg, Ns - 1)];
-        ti.ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)];
+        const float ic = isc_src[(size_t)b * Ns + min(cg, Ns - 1)], iic = __uint_as_float(0x7F000000u - __float_as_uint(ic));   // 1 / 2^e exactly
+        ti.Bc = 0.5f * om * nsb[min(cg, Ns - 1)] * iic;
+        ti.ic = iic;
     };
     auto do_tile = [&](int t, const TileIn& ti) {
         const int cg = t * 32 + l31;
@@ -804,9 +816,18 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
             for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][kk], ti.bf[kk], S, 0, 0, 0);
-            unsigned mask = 0;
+            unsigned mask = 0;   // bit r: row r of this lane's column survives.  Compare + add-with-carry (mask = 2 mask + !(S < rhs)), spelled in
+                                 // asm: hipcc builds the same mask from v_cndmask / v_or / v_lshl, three to four instructions per pair.
+            // The right-hand sides first (they do not depend on S), then a fence that owns S: the hazard recogniser does not look into inline
+            // asm, so nothing would keep the compares the 18 wait states behind the last MFMA that a VALU read of its result needs -- found the
+            // hard way: with the results in VGPRs (build.py: -amdgpu-mfma-vgpr-form) the compares read them early and k-NN lists came out wrong.
+            float rhs[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mask |= (S[r] * (IQ[u][r] * ic) < A[u][r] + Bc) ? 0u : (1u << r);
+            for (int r = 0; r < 16; ++r) rhs[r] = __builtin_fmaf(A[u][r], ic, Bc * IQ[u][r]);
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(S));
+#pragma unroll
+            for (int r = 15; r >= 0; --r)
+                asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(S[r]), "v"(rhs[r]) : "vcc");
             if (cg >= Ns) mask = 0;
             while (mask) {
                 const int r = __builtin_ctz(mask);
@@ -1070,7 +1091,9 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
     qv.load(qrow, lane);
 
     // 1. two-sided bounds of every candidate's canonical distance (candidate j = 64 i + lane)
-    const float nq = nrm_dst[(size_t)b * dst_n + r], snq = sqrtf(nq);
+    // (v_sqrt_f32, 1 ulp, instead of the correctly rounded sqrtf -- ten instructions per candidate column in a VALU-bound kernel; its relative
+    //  error 2^-23 on |q'||s'| <= nn / 2 is covered by the 2^-21 the launch adds to epsS)
+    const float nq = nrm_dst[(size_t)b * dst_n + r], snq = __builtin_amdgcn_sqrtf(nq);
     const short* cp = cosq + (size_t)qg * ns_pad;
     const float* nsb = nrm_src + (size_t)b * Ns;
     float lo[NV];
@@ -1082,7 +1105,7 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
         const float c = (float)cp[min(j, ns_pad - 1)] * (1.0f / 32767.0f);
         const float ns = nsb[min(j, Ns - 1)];
         const float nn = nq + ns;
-        const float dh = nn - 2.0f * c * (snq * sqrtf(ns)), e = epsS * nn;
+        const float dh = nn - 2.0f * c * (snq * __builtin_amdgcn_sqrtf(ns)), e = epsS * nn;
         lo[i] = valid ? dh - e : INFINITY;
         const float hi = (valid && dh == dh) ? fmaxf(dh + e, 0.0f) : INFINITY;   // (a NaN bound never wins the minimum; its candidate survives below)
         himin = fminf(himin, hi);
@@ -1216,7 +1239,7 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
             hipLaunchKernelGGL((knn_sweep_store_kernel<D>), dim3(cdiv(total_waves, 4)), dim3(256), 0, st, dq, sq, dst_rows, ndst, nsrc, idst, isrc, Nd, dst_n, dst_npad,
                                Ns, ns_pad, qgroups, nsplit, total_waves, cosq);
             LS_LAUNCH_CHECK();
-            const float epsS = 1.02f * 0.0009765625f + 6.0f * (float)(D + 4) * 5.9604645e-8f + 6.103515625e-5f;   // f16 image + 2^-14 (fixed point, this kernel)
+            const float epsS = 1.02f * 0.0009765625f + 6.0f * (float)(D + 4) * 5.9604645e-8f + 6.103515625e-5f + 4.76837158203125e-7f;   // f16 image + 2^-14 (fixed point, this kernel) + 2^-21 (its 1-ulp square roots)
             const int wblocks = cdiv((long long)nq, 4);
             if (fma)
                 hipLaunchKernelGGL((knn_finish_select_kernel<CC, true>), dim3(wblocks), dim3(256), 0, st, dst, src, dst_rows, ndst, nsrc, Nd, dst_n, Ns, ns_pad,
