@@ -46,6 +46,20 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
     const float inv = 1.0f / fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-12f);
     const float ax = cx * inv, ay = cy * inv, az = cz * inv;
     const int32_t* ki = knn + (size_t)pid * EK;
+    // Round 4: what an edge contributes BEFORE the weights -- the cross product with the centre direction and the difference to the centre, six
+    // floats -- does not depend on the output channel, yet each of the 32 channel lanes of a point recomputed it (three loads, an index load and
+    // ~14 of the ~50 VALU instructions per edge, in a kernel that runs at 98 % of the VALU issue rate).  Lane o < 16 of a point now does it once
+    // for edge o and leaves it in a wave-private LDS slot; the edge loop reads it back with two broadcast loads.  Same operations per element.
+    __shared__ __attribute__((aligned(16))) float l_edge[4][2][EK][8];
+    if (o < EK) {
+        const int r = ki[o];
+        const float nx = P[(size_t)r * 3 + 0], ny = P[(size_t)r * 3 + 1], nz = P[(size_t)r * 3 + 2];
+        float* le = l_edge[wave][sub][o];
+        *reinterpret_cast<float4*>(le) = make_float4(ay * nz - az * ny, az * nx - ax * nz, ax * ny - ay * nx, nx - cx);
+        *reinterpret_cast<float2*>(le + 4) = make_float2(ny - cy, nz - cz);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the slots are wave-private, LDS operations of a wave complete in order
+    __builtin_amdgcn_wave_barrier();
     for (int c0 = 0; c0 < Co; c0 += 32) {
         const int oc = c0 + o;
         const bool on = oc < Co;
@@ -57,10 +71,9 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
         for (int k = 0; k < EK; ++k) {
-            const int r = ki[k];
-            const float nx = P[(size_t)r * 3 + 0], ny = P[(size_t)r * 3 + 1], nz = P[(size_t)r * 3 + 2];
-            const float crx = ay * nz - az * ny, cry = az * nx - ax * nz, crz = ax * ny - ay * nx;
-            const float dx = nx - cx, dy = ny - cy, dz = nz - cz;
+            const float4 e0 = *reinterpret_cast<const float4*>(l_edge[wave][sub][k]);
+            const float2 e1 = *reinterpret_cast<const float2*>(l_edge[wave][sub][k] + 4);
+            const float crx = e0.x, cry = e0.y, crz = e0.z, dx = e0.w, dy = e1.x, dz = e1.y;
             float y0 = a0 * crx + a1 * dx + yc0, y1 = a0 * cry + a1 * dy + yc1, y2 = a0 * crz + a1 * dz + yc2;
             const float k0 = d0 * crx + d1 * dx + kc0, k1 = d0 * cry + d1 * dy + kc1, k2 = d0 * crz + d1 * dz + kc2;
             vn_act(y0, y1, y2, k0, k1, k2, oms);
