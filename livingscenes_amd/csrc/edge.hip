@@ -686,7 +686,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
 #pragma unroll
         for (int u = 0; u < EK / 4; ++u) { const int4 v = kp[u]; nb[4 * u] = v.x; nb[4 * u + 1] = v.y; nb[4 * u + 2] = v.z; nb[4 * u + 3] = v.w; }
     }
-    auto nrow = [&](int k) { return Tb + (size_t)nb[k] * 3 * ldt + c4; };
+    // Row gathers as ONE uniform base + a 32-bit byte offset per neighbour (round 4): off = (instance row + neighbour) x row bytes + this lane's
+    // column bytes by a single full-rate v_mad_u32_u24, the x / y / z rows and the column groups as scalar bases / immediates.  The 64-bit
+    // pointer arithmetic it replaces cost eleven VALU instructions per neighbour and phase, three of them quarter-rate 32-bit multiplies
+    // (the launch checks that the table is below 4 GB and its rows below 2^24).
+    const unsigned row_bytes = 3u * (unsigned)ldt * 4u;
+    const unsigned lane_off = (unsigned)c4 * 4u;
+    const unsigned inst_row = (unsigned)b * (unsigned)Ns;
+    auto noff = [&](int k) { return __umul24(inst_row + (unsigned)nb[k], row_bytes) + lane_off; };
+    auto ldrow = [&](unsigned off, int col) {   // rows x, y, z of table columns col .. col + 3 (+ this lane's column offset, inside `off`)
+        asm volatile("" : "+v"(off));           // (keeps the zero-extension next to the loads: the scalar-base addressing mode, as in gemm.hip)
+        F43 r;
+        r.x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + col) + off);
+        r.y = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + ldt + col) + off);
+        r.z = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + 2 * ldt + col) + off);
+        return r;
+    };
     qgemm(2 * Co);
     __syncthreads();
     {
@@ -695,12 +710,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         constexpr int DP = 2;
         F43 py[DP], pd[DP];
 #pragma unroll
-        for (int d = 0; d < DP; ++d) { py[d] = ld43(nrow(d) + 2 * Co, ldt); pd[d] = ld43(nrow(d) + 3 * Co, ldt); }
+        for (int d = 0; d < DP; ++d) { const unsigned o = noff(d); py[d] = ldrow(o, 2 * Co); pd[d] = ldrow(o, 3 * Co); }
         const F43 ql = lds43(0), qd = lds43(Co);
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
             F43 y = py[k % DP], kd = pd[k % DP];
-            if (k + DP < EK) { py[k % DP] = ld43(nrow(k + DP) + 2 * Co, ldt); pd[k % DP] = ld43(nrow(k + DP) + 3 * Co, ldt); }
+            if (k + DP < EK) { const unsigned o = noff(k + DP); py[k % DP] = ldrow(o, 2 * Co); pd[k % DP] = ldrow(o, 3 * Co); }
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this neighbour's arithmetic (the scheduler would sink it to its first use)
             y = add43(y, ql);
             kd = add43(kd, qd);
@@ -735,11 +750,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         constexpr int DP = 2;
         F43 py[DP], pd[DP];
 #pragma unroll
-        for (int d = 0; d < DP; ++d) { py[d] = ld43(nrow(d), ldt); pd[d] = ld43(nrow(d) + Co, ldt); }
+        for (int d = 0; d < DP; ++d) { const unsigned o = noff(d); py[d] = ldrow(o, 0); pd[d] = ldrow(o, Co); }
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
             F43 y = py[k % DP], kd = pd[k % DP];
-            if (k + DP < EK) { py[k % DP] = ld43(nrow(k + DP), ldt); pd[k % DP] = ld43(nrow(k + DP) + Co, ldt); }
+            if (k + DP < EK) { const unsigned o = noff(k + DP); py[k % DP] = ldrow(o, 0); pd[k % DP] = ldrow(o, Co); }
             __builtin_amdgcn_sched_barrier(0);
             y = add43(y, ql);
             kd = add43(kd, qd);
@@ -770,6 +785,8 @@ bool edge_attn_fq_supported(int Co, int Cin) { return (Co == 64 && (Cin == 32 ||
 int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, const void* wq_planes, const int32_t* knn, const int32_t* dst_rows, int B,
                         int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax, const int32_t* perm) {
     LS_REQUIRE(head_c == 16 && edge_attn_fq_supported(Co, Cin) && ldt % 4 == 0 && wq_planes, "edge_attn_fq: unsupported shape (Co=%d Cin=%d ldt=%d)", Co, Cin, ldt);
+    LS_REQUIRE((unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24),
+               "edge_attn_fq: the table is addressed by 32-bit byte offsets (B=%d Ns=%d ldt=%d)", B, Ns, ldt);
     const float isd = 1.0f / sqrtf(3.0f * head_c), oms = 1.0f - neg_slope;
     const int total = B * Nd;
 #define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax, perm)
