@@ -339,7 +339,6 @@ __global__ __launch_bounds__(256) void edge_pool_v4_kernel(const float* __restri
     if (perm) pid = perm[pid];
     const int b = pid / Nd;
     const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
-    const float* Tb = T + (size_t)b * Ns * 3 * ldt;
     const float* Td = Tq + ((size_t)b * NQ + drow) * 3 * ldq;
     const int c4 = ll * 4;
     int nb[EK];
@@ -351,11 +350,21 @@ __global__ __launch_bounds__(256) void edge_pool_v4_kernel(const float* __restri
     const F43 ql = ld43(Td + c4, ldq), qd = ld43(Td + Co + c4, ldq);
     F43 acc;
     acc.x = acc.y = acc.z = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (row gathers from one scalar base + a 32-bit byte offset, as in edge_attn_fq_kernel; the launch checks the table size)
+    const unsigned row_bytes = 3u * (unsigned)ldt * 4u, lane_off = (unsigned)c4 * 4u, inst_row = (unsigned)b * (unsigned)Ns;
+    auto ldrow = [&](unsigned off, int col) {
+        asm volatile("" : "+v"(off));
+        F43 r;
+        r.x = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + col) + off);
+        r.y = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + ldt + col) + off);
+        r.z = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + 2 * ldt + col) + off);
+        return r;
+    };
 #pragma unroll 4
     for (int k = 0; k < EK; ++k) {
-        const float* Tr = Tb + (size_t)nb[k] * 3 * ldt + c4;
-        F43 y = add43(ld43(Tr, ldt), ql);
-        const F43 kd = add43(ld43(Tr + Co, ldt), qd);
+        const unsigned off = __umul24(inst_row + (unsigned)nb[k], row_bytes) + lane_off;
+        F43 y = add43(ldrow(off, 0), ql);
+        const F43 kd = add43(ldrow(off, Co), qd);
         act43(y, kd, oms);
         acc = add43(acc, y);
     }
@@ -823,7 +832,8 @@ int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, 
                      const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st, const int32_t* perm) {
     const int total = B * Nd;
     static const bool scalar_pool = getenv("LS_EDGE_POOL_SCALAR") && atoi(getenv("LS_EDGE_POOL_SCALAR")) != 0;   // A/B: the one-channel-per-lane kernel
-    if (!scalar_pool && ldt % 4 == 0 && ldq % 4 == 0 && (Co == 32 || Co == 64)) {
+    const bool off32 = (unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24);
+    if (!scalar_pool && off32 && ldt % 4 == 0 && ldq % 4 == 0 && (Co == 32 || Co == 64)) {   // (the float4 kernel addresses the table by 32-bit byte offsets)
         if (Co == 32)
             hipLaunchKernelGGL((edge_pool_v4_kernel<8>), dim3(cdiv(total, 32)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total, perm);
         else
