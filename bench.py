@@ -173,10 +173,17 @@ def roofline_entry(kind, layer, avg_s, cfg, B, N, bf16x3):
         e["traffic"] = None
     if "mfma_busy_frac" in pmc:
         e["mfma_busy_frac_pmc"] = pmc["mfma_busy_frac"]
+    if pmc and "valu_issue_frac" in pmc:   # share of the non-packed VALU issue slots (4 cycles per wave instruction) the operator's kernels use, run alone
+        e["valu_issue_frac_pmc"] = pmc["valu_issue_frac"]
+        e["wave_wait_frac_pmc"] = pmc.get("wave_wait_frac")
     return e
 
 
-VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 78.6 T fp32 lane-ops/s (256 CUs x 4 SIMD-32 at 2.4 GHz): the rate behind the 157.3 TFLOP/s FMA peak
+# NON-PACKED fp32 VALU rate: a wave64 instruction occupies its 16-lane SIMD for 4 cycles -> 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s
+# (the 157.3 TFLOP/s headline = packed v_pk_fma_f32: x2 lanes x2 flops).  Measured, not assumed: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel
+# cycles) reaches 0.98 on edge_l0_kernel and 0.6 - 0.8 on the k-NN exact phases (profiles/r4_final/sq_counters_all_kernels.txt); until this
+# round's counter sweep this constant was the packed 78.6 T, which made every VALU floor in this file half of what the chip can do.
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
 
 
 def knn_hw_utilisation(e, layer, avg_s, cfg, B, N, survivors_per_call, seeded):
@@ -185,7 +192,7 @@ def knn_hw_utilisation(e, layer, avg_s, cfg, B, N, survivors_per_call, seeded):
     over the measured build time:
       hbm   compulsory bytes / 8 TB/s
       mfma  EXECUTED f16 MFMA flops of the safe filter (every (query, candidate) pair once, padded to the 32-wide tiles) / 2.5 PF
-      valu  EXECUTED fp32 lane-operations of the exact phases / 78.6 T lane-ops/s: every candidate that gets a canonical distance (the 16 hints
+      valu  EXECUTED fp32 lane-operations of the exact phases / 39.3 T lane-ops/s (non-packed issue rate): every candidate that gets a canonical distance (the 16 hints
             of a seeded layer + the filter's survivors, counted on the device: ls_profile_knn_stats) costs D subtractions + D multiplications +
             4 D additions -- the canonical chain is serial, and the quad form that keeps the row gathers coalesced executes each add in four
             lanes (csrc/knn_mfma.hip: quad_pair_distance)."""
@@ -205,7 +212,7 @@ def knn_hw_utilisation(e, layer, avg_s, cfg, B, N, survivors_per_call, seeded):
         "executed_f16_mfma_flops": mfma_flops, "executed_exact_pairs": pairs, "exact_pairs_per_query": pairs / (B * L["Nd"]),
         "survivors_per_query": survivors_per_call / (B * L["Nd"]), "executed_valu_lane_ops": lane_ops,
         "useful_valu_lane_ops": pairs * 3.0 * D,
-        "note": "frac_hw = max(compulsory bytes / 8 TB/s, executed f16 MFMA flops / 2.5 PFLOP/s, executed exact-phase fp32 lane-ops / 78.6 T lane-ops/s) "
+        "note": "frac_hw = max(compulsory bytes / 8 TB/s, executed f16 MFMA flops / 2.5 PFLOP/s, executed exact-phase fp32 lane-ops / 39.3 T lane-ops/s non-packed) "
                 "/ measured duration of the whole build (image + seed + sweep + finish launches); `frac` keeps SURVEY 8(d)'s direct-difference-equivalent basis"}
     return e
 
@@ -478,7 +485,7 @@ def main():
             extra.append(fps_entry(q["layer"], q["total_ms"] / q["launches"] * 1e-3, ecfg, B, N))
         roof["other_kernels"] = extra
         # the whole step against its own floors: every profiled operator's compulsory bytes and max(bytes / HBM peak, flops / pipe peak)
-        ws_bytes = ws_floor = ws_floor_hw = ws_pmc = 0.0
+        ws_bytes = ws_floor = ws_floor_hw = ws_pmc = ws_valu = 0.0
         pmc_missing = []
         for q in prof:
             per = q["launches"] / prof_steps
@@ -506,6 +513,7 @@ def main():
                 pm, calls = ({"hbm_read_bytes": 0, "hbm_write_bytes": 0} if committed_pmc("tail[layer 0]") else {}), 1.0
             else:
                 pm, calls = committed_pmc(f"{q['kind']}[layer {q['layer']}]"), per
+            ws_valu += pm.get("valu_wave_insts", 0.0) * calls
             if "hbm_read_bytes" in pm and "hbm_write_bytes" in pm:
                 ws_pmc += (pm["hbm_read_bytes"] + pm["hbm_write_bytes"]) * calls
             else:
@@ -517,9 +525,14 @@ def main():
             "ms_per_step_one_in_flight_profiled": tot / prof_steps,
             "frac_of_sum_floor": ws_floor / (dt / args.steps), "frac_of_sum_floor_hw": ws_floor_hw / (dt / args.steps),
             "algorithmic_GBps": ws_bytes / (dt / args.steps) / 1e9, "algorithmic_frac_of_hbm_peak": ws_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            # executed VALU work (committed SQ_INSTS_VALU passes): wave-instructions x 64 lanes against the non-packed issue rate of the chip
+            "valu_wave_insts_pmc": ws_valu or None, "valu_issue_ms_pmc": (ws_valu * 64.0 / VALU_LANE_OPS_PER_S * 1e3) if ws_valu else None,
+            "valu_issue_frac_of_step": (ws_valu * 64.0 / VALU_LANE_OPS_PER_S / (dt / args.steps)) if ws_valu else None,
             "note": "sum over every launch of one step of max(compulsory bytes / 8 TB/s, flops / pipe peak) (sum_floor_ms: k-NN on the direct-difference-equivalent "
                     "basis; sum_floor_hw_ms: k-NN on executed work, FPS at 0.25 us per dependent step) against the timed ms_per_step; floors of kernels "
-                    "that run concurrently on different streams are still summed, so this is a lower bound on a serial schedule, not on the chip"}
+                    "that run concurrently on different streams are still summed, so this is a lower bound on a serial schedule, not on the chip; "
+                    "valu_issue_ms_pmc: the VALU instructions the step's kernels EXECUTE (counter passes, 4 issue cycles each) -- the part of the step that only "
+                    "fewer instructions can shorten"}
 
     cpu = None
     oracle_check = None

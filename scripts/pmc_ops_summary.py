@@ -4,7 +4,8 @@ counter_collection CSV) + its manifest: per (operator[layer]) HBM read / write b
 operator's kernels.  FETCH_SIZE is in KB and under-counts wide reads by 2x on gfx950 (MI355X_MICROARCH.md 'HBM'): x1024 x2;
 WRITE_SIZE KB x1024.  Matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES (pipe cycles summed over the chip's 1024 SIMDs: 32 per
 v_mfma_f32_32x32x16_bf16) / (GRBM_GUI_ACTIVE / 8 x 1024): rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (checked:
-value / 8 / hipEvent duration = 2.1-2.2 GHz on the table GEMMs)."""
+value / 8 / hipEvent duration = 2.1-2.2 GHz on the table GEMMs).  valu_issue_frac (round 4) = 4 x SQ_INSTS_VALU / the same denominator: the share of the
+chip's non-packed VALU issue slots the operator's kernels use, wave_wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES."""
 import collections
 import csv
 import glob
@@ -78,6 +79,13 @@ def main(root):
             e["mfma_busy_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]
             e["gui_active_cycles"] = c["GRBM_GUI_ACTIVE"]
             e["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        if "SQ_INSTS_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+            # VALU wave-instructions x 4 cycles (a wave64 instruction on a 16-lane SIMD; transcendental / 64-bit-integer ones take longer, so this
+            # is a lower bound of the busy share) over the chip's 1024 SIMDs x the operator's cycles
+            e["valu_wave_insts"] = c["SQ_INSTS_VALU"]
+            e["valu_issue_frac"] = 4.0 * c["SQ_INSTS_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            if c.get("SQ_WAVE_CYCLES"):
+                e["wave_wait_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
         kind, layer = lab[:-1].split("[")
         out[f"{kind}[layer {layer}]"] = e
     json.dump(out, sys.stdout, indent=1)
