@@ -795,11 +795,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
 
 // can this layer shape take the fused kernel?
 bool edge_attn_fq_supported(int Co, int Cin) { return (Co == 64 && (Cin == 32 || Cin == 64)) || (Co == 128 && Cin == 64); }
+bool edge_attn_fq_fits(int B, int Ns, int ldt) {   // the table is addressed by 32-bit byte offsets formed with a 24-bit multiply
+    return (unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24);
+}
 int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, const void* wq_planes, const int32_t* knn, const int32_t* dst_rows, int B,
                         int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax, const int32_t* perm) {
     LS_REQUIRE(head_c == 16 && edge_attn_fq_supported(Co, Cin) && ldt % 4 == 0 && wq_planes, "edge_attn_fq: unsupported shape (Co=%d Cin=%d ldt=%d)", Co, Cin, ldt);
-    LS_REQUIRE((unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24),
-               "edge_attn_fq: the table is addressed by 32-bit byte offsets (B=%d Ns=%d ldt=%d)", B, Ns, ldt);
+    LS_REQUIRE(edge_attn_fq_fits(B, Ns, ldt), "edge_attn_fq: the table is addressed by 32-bit byte offsets (B=%d Ns=%d ldt=%d)", B, Ns, ldt);
     const float isd = 1.0f / sqrtf(3.0f * head_c), oms = 1.0f - neg_slope;
     const int total = B * Nd;
 #define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax, perm)
@@ -836,7 +838,7 @@ int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, 
                      const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st, const int32_t* perm) {
     const int total = B * Nd;
     static const bool scalar_pool = getenv("LS_EDGE_POOL_SCALAR") && atoi(getenv("LS_EDGE_POOL_SCALAR")) != 0;   // A/B: the one-channel-per-lane kernel
-    const bool off32 = (unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24);
+    const bool off32 = edge_attn_fq_fits(B, Ns, ldt);
     if (!scalar_pool && off32 && ldt % 4 == 0 && ldq % 4 == 0 && (Co == 32 || Co == 64)) {   // (the float4 kernel addresses the table by 32-bit byte offsets)
         if (Co == 32)
             hipLaunchKernelGGL((edge_pool_v4_kernel<8>), dim3(cdiv(total, 32)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total, perm);

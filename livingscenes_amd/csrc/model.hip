@@ -39,6 +39,7 @@ int edge_pool_launch(const float*, int, const float*, int, int, int, const int32
 int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
 bool edge_attn_emits_rowmax(int Co, int ldt, int ldq);
 bool edge_attn_fq_supported(int Co, int Cin);
+bool edge_attn_fq_fits(int B, int Ns, int ldt);
 int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr, const int32_t* perm = nullptr);
 int morton_order_launch(const float* pts, int B, int N, int32_t* perm, hipStream_t st);
 size_t edge_wq_planes_bytes(int Co, int Cin);
@@ -360,7 +361,8 @@ static EdgeTables edge_tables_layout(const ls_model* m, int i, const float* cur,
     const ls_model_desc& d = m->d;
     const int Cin = layer_cin(d, i), nc = layer_ncols(d, i), pc = layer_pcols(d, i);
     if (edge_fused_t(m, i, B, Ns, Nd, dst_rows != nullptr)) { EdgeTables e{nullptr, 0, 0, 0, 0, cur, nullptr, Cin}; e.Wt = m->wt_planes[i]; return e; }
-    if (edge_fused(m, i)) return EdgeTables{nullptr, pc, 0, 0, 0, cur, m->wq_planes[i], Cin};
+    // (the fused kernel gathers table rows by 32-bit byte offsets: a batch whose neighbour-side table reaches 4 GB takes the table path)
+    if (edge_fused(m, i) && edge_attn_fq_fits(B, Ns, pc)) return EdgeTables{nullptr, pc, 0, 0, 0, cur, m->wq_planes[i], Cin};
     if (dst_rows) return EdgeTables{T + (size_t)B * Ns * 3 * pc, pc, nc - pc, Nd, 0};
     return EdgeTables{T + pc, nc, nc, Ns, 1};
 }
