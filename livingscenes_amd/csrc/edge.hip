@@ -331,7 +331,7 @@ __device__ __forceinline__ void fma43(F43& acc, float w, const F43& y) {
 // launch (805 MB), the vector-memory issue rate its bound; this form issues a quarter of them.  Same additions in the same order per channel
 // (neighbours k = 0 .. 15 ascending, then x 1/16): bit-identical to edge_pool_kernel.
 template <int LPP>
-__global__ __launch_bounds__(256) void edge_pool_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq, int NQ,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void edge_pool_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq, int NQ,
                                                            int q_via_rows, const int32_t* __restrict__ knn, const int32_t* __restrict__ dst_rows,
                                                            int Nd, int Ns, float oms, float* __restrict__ out, int total, const int32_t* __restrict__ perm) {
     constexpr int PPW = 64 / LPP, Co = 4 * LPP;
@@ -364,13 +364,31 @@ __global__ __launch_bounds__(256) void edge_pool_v4_kernel(const float* __restri
         r.z = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + 2 * ldt + col) + off);
         return r;
     };
-#pragma unroll 4
+    // two-deep gather pipeline, as edge_attn_fq_kernel (round 4): the rolled loop loaded a neighbour's three y rows, waited, loaded its three
+    // direction rows, waited, computed -- two dependent L2 round trips per neighbour with only the other waves of the SIMD to hide them
+    // (VALU issue 0.43, waves parked 62 % of their life)
+    constexpr int DP = 2;
+    F43 py[DP], pd[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) { const unsigned o = __umul24(inst_row + (unsigned)nb[d], row_bytes) + lane_off; py[d] = ldrow(o, 0); pd[d] = ldrow(o, Co); }
+    // (What keeps the order: the loads come from read-only no-alias memory and the loop has no store, so neither a sched_barrier nor a memory clobber
+    //  ties them to the arithmetic -- left free, hipcc issued all sixteen neighbours' loads first: 401 registers.  The empty asm below makes the
+    //  offset of neighbour k + DP depend on the accumulator as neighbour k - 1 left it, and neighbour k's arithmetic on that asm.)
+#pragma unroll
     for (int k = 0; k < EK; ++k) {
-        const unsigned off = __umul24(inst_row + (unsigned)nb[k], row_bytes) + lane_off;
-        F43 y = add43(ldrow(off, 0), ql);
-        const F43 kd = add43(ldrow(off, Co), qd);
+        F43 y = py[k % DP], kd = pd[k % DP];
+        if (k + DP < EK) {
+            unsigned o = __umul24(inst_row + (unsigned)nb[k + DP], row_bytes) + lane_off;
+            py[k % DP] = ldrow(o, 0); pd[k % DP] = ldrow(o, Co);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        y = add43(y, ql);
+        kd = add43(kd, qd);
         act43(y, kd, oms);
         acc = add43(acc, y);
+        asm volatile("" : "+v"(acc.x.x), "+v"(acc.x.y), "+v"(acc.x.z), "+v"(acc.x.w), "+v"(acc.y.x), "+v"(acc.y.y), "+v"(acc.y.z), "+v"(acc.y.w), "+v"(acc.z.x), "+v"(acc.z.y), "+v"(acc.z.z), "+v"(acc.z.w) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (live) {
         float* op = out + (size_t)pid * 3 * Co + c4;
