@@ -632,8 +632,8 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     if (const char* ev = getenv("LS_ORDER")) m->order_pts = atoi(ev) != 0;
 #ifdef LS_DEV_KNOBS   // only in the variant library scripts/dev/marginal_cost.sh builds (-DLS_DEV_KNOBS): the release library cannot be made to skip work
     if (const char* ev = getenv("LS_SKIP")) {
-        const char* names[] = {"knn", "attn", "pool", "l0", "tables", "glob", "fps", "tail", "prologue"};
-        for (int i = 0; i < 9; ++i) if (strstr(ev, names[i])) m->skip_mask |= 1u << i;
+        const char* names[] = {"knn", "attn", "pool", "l0", "tables", "glob", "fps", "tail", "prologue", "hi32"};   // hi32: the attention of the 32-point layers only (with their operand images)
+        for (int i = 0; i < 10; ++i) if (strstr(ev, names[i])) m->skip_mask |= 1u << i;
         if (const char* ea = getenv("LS_SKIP_AFTER")) m->skip_after = atoi(ea);
     }
 #endif
@@ -761,7 +761,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
     float* centroid = F(p.o_centroid);
     float* scale0 = F(p.o_scale0);
     const unsigned skip = (m->skip_mask && m->calls++ >= m->skip_after) ? m->skip_mask : 0u;   // dev timing knob (LS_SKIP), see ls_model
-    enum { SK_KNN = 1, SK_ATTN = 2, SK_POOL = 4, SK_L0 = 8, SK_TABLES = 16, SK_GLOB = 32, SK_FPS = 64, SK_TAIL = 128, SK_PROLOGUE = 256 };
+    enum { SK_KNN = 1, SK_ATTN = 2, SK_POOL = 4, SK_L0 = 8, SK_TABLES = 16, SK_GLOB = 32, SK_FPS = 64, SK_TAIL = 128, SK_PROLOGUE = 256, SK_HI32 = 512 };
 
     {
         PROF(LS_K_PROLOGUE, 0, st);
@@ -858,7 +858,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 LS_HIP_CHECK(hipStreamWaitEvent(gs, m->ev_feat[i], 0));
             }
             EdgeTables et;
-            if (skip & SK_TABLES) { et = edge_tables_layout(m, i, cur, dst_rows, B, Ns, Nd, T); rc = LS_OK; }
+            if ((skip & SK_TABLES) || ((skip & SK_HI32) && Nd == 32)) { et = edge_tables_layout(m, i, cur, dst_rows, B, Ns, Nd, T); rc = LS_OK; }
             else rc = edge_tables(m, i, cur, dst_rows, B, Ns, Nd, T, gs, et, cur_rm, cur_rm_parts);
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
@@ -885,7 +885,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 if (rc != LS_OK) return rc;
             }
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
-            if (skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) rc = LS_OK;
+            if ((skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) || ((skip & SK_HI32) && Nd == 32)) rc = LS_OK;
             else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts, perm);
             if (rc != LS_OK) return rc;
         }
