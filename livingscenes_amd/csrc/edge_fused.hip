@@ -322,6 +322,89 @@ __device__ __forceinline__ void ft_gemm_phase(const FtJob<KS> (&jobs)[NJ], const
     }
 }
 
+// Round 4, late: the same phase with THREE M-tiles per unit of work and nothing resident.  Why: the form above keeps a W tile in registers (128 VGPRs at
+// K = 256) -- 242 - 254 VGPRs per wave, i.e. the two workgroups of a CU own its whole register file while their waves sit through ~13 sequential L2
+// round trips per q / k phase pair, and LS_SKIP=hi32 shows that these layers cost 0.165 ms of the 1.21 ms step in steady state: nothing can be
+// resident beside them.  Here a unit = (job, head, three consecutive M-tiles = the 96 feature rows of 32 points): three independent accumulators,
+// and per batch of two k-steps 12 A fragments + 4 W fragments (64 VGPRs) are requested, awaited and consumed by 18 MFMAs.  Same products in the same
+// order per accumulator (ascending k: l_a h_w, h_a h_w, h_a l_w) => bit-identical slabs; the W tile is streamed once per unit, as before once per
+// (job, head); ~120 VGPRs.  Every job's M-tile count is a multiple of three by construction (96 or 384 rows).
+// (Order: the operand images are read-only no-alias memory and the loop stores nothing, so only data dependencies keep hipcc from hoisting all sixteen
+//  batches' loads to the top -- the batch's lane offset passes through a volatile asm, and so do the accumulators after its MFMAs: edge.hip, pool kernel.)
+template <int KS, int HG, int NJ>
+__device__ __forceinline__ void ft_gemm_phase_g3(const FtJob<KS> (&jobs)[NJ], const uint4* __restrict__ wplanes, const int* __restrict__ wexp, int head0,
+                                                 int wave, int lane) {
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) total += (jobs[j].MT / 3) * HG;
+    for (int t = wave; t < total; t += 4) {      // (wave-uniform)
+        int j = 0, off = t;
+#pragma unroll
+        for (int q = 0; q < NJ - 1; ++q)
+            if (j == q && off >= (jobs[q].MT / 3) * HG) { off -= (jobs[q].MT / 3) * HG; j = q + 1; }
+        FtJob<KS> jb = jobs[0];
+#pragma unroll
+        for (int q = 1; q < NJ; ++q)
+            if (j == q) jb = jobs[q];
+        const int ng = jb.MT / 3, hl = off / ng, g = off - hl * ng, T = (head0 + hl) * 5 + jb.p;
+        const char* ab = reinterpret_cast<const char*>(jb.a_planes + ((size_t)(jb.mt0 + 3 * g) * KS * 2) * 64);
+        const char* wb = reinterpret_cast<const char*>(wplanes + ((size_t)T * KS * 2) * 64);
+        const int we = wexp[T * 32 + (lane & 31)];
+        ff16_t acc[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += 2) {
+            asm volatile("" : "+v"(voff));
+            fh8_t ah[3][2], al[3][2], bh[2], bl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bh[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2) * 1024 + voff));
+                bl[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2 + 1) * 1024 + voff));
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    ah[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2) * 1024 + voff));
+                    al[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2 + 1) * 1024 + voff));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (all sixteen requests first: the scheduler would sink each load to its MFMA)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m][u], bh[u], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m][u], bh[u], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m][u], bl[u], acc[m], 0, 0, 0);
+                }
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])::"memory");
+        }
+        // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int mt = 3 * g + m;
+            const int row0 = 32 * mt + 4 * (lane >> 5);
+            float* sp = jb.slab + (size_t)row0 * jb.sld + hl * 32 + (lane & 31);
+            const int* ae = jb.a_exp + (jb.mt0 + mt) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                sp[dr * jb.sld] = __builtin_ldexpf(acc[m][r], ae[dr] + we);
+            }
+        }
+    }
+}
+#ifndef LS_FT_G3
+#define LS_FT_G3 1
+#endif
+#if LS_FT_G3
+#define LS_FT_PHASE ft_gemm_phase_g3
+#else
+#define LS_FT_PHASE ft_gemm_phase
+#endif
+
 // thread -> (point, head-local, quad lane, neighbour range) of the attention phases: 256 threads = 32 points x HG heads x 4 lanes x (2 / HG) neighbour halves
 template <int HG>
 struct FtMap {
@@ -356,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void edge_ft_qk_kernel(const uint4* __restr
     // ---- q = VecLNA_Q(dst_f[n]) of the workgroup's heads (vec_dgcnn_atten.py:207,210)
     {
         const FtJob<KS> jq[1] = {{a_q, ae_q, b * MTQ, MTQ, 4, slab_q, SLD}};
-        ft_gemm_phase<KS, HG, 1>(jq, wplanes, wexp, head0, wave, lane);
+        LS_FT_PHASE<KS, HG, 1>(jq, wplanes, wexp, head0, wave, lane);
     }
     __syncthreads();
     const int c4 = mp.hl * 32 + mp.ql * 4;
@@ -379,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void edge_ft_qk_kernel(const uint4* __restr
     // ---- k = VecLNA_K(E[n, k]) = act(PK_lin[nbr] + QK_lin[n], PK_dir[nbr] + QK_dir[n])  (:206,209)
     {
         const FtJob<KS> jk[2] = {{a_p, ae_p, b * MTP, MTP, 1, slab_p, SLD}, {a_q, ae_q, b * MTQ, MTQ, 3, slab_q, SLD}};
-        ft_gemm_phase<KS, HG, 2>(jk, wplanes, wexp, head0, wave, lane);
+        LS_FT_PHASE<KS, HG, 2>(jk, wplanes, wexp, head0, wave, lane);
     }
     __syncthreads();
     {
@@ -466,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void edge_ft_v_kernel(const uint4* __restri
     // ---- v tables of the workgroup's heads
     {
         const FtJob<KS> jv[2] = {{a_p, ae_p, b * MTP, MTP, 0, slab_p, SLD}, {a_q, ae_q, b * MTQ, MTQ, 2, slab_q, SLD}};
-        ft_gemm_phase<KS, HG, 2>(jv, wplanes, wexp, head0, wave, lane);
+        LS_FT_PHASE<KS, HG, 2>(jv, wplanes, wexp, head0, wave, lane);
     }
     __syncthreads();
     // ---- soft-max over the 16 neighbours of (point, head) (:211-215); every lane of the (point, head) group computes it for itself
