@@ -24,6 +24,8 @@
 // to fp32 round-off, not bit for bit).  The attention arithmetic uses the helpers of edge.hip (vn_act, dot43, fma43: every multiply-add spelled
 // as an fma); what differs from edge_attn_v4_kernel is the ORDER in which the squared norms are summed over the channels (per head by a DPP quad
 // sum, then over the heads ascending, instead of one 64-lane tree).
+// [The numbers of this paragraph are those of the FIRST form of the GEMM phases (ft_gemm_phase: one 32 x 32 item at a time, resident W tile); the
+//  phases now run as ft_gemm_phase_g3 -- see there: layers 5 / 6 92 / 115 -> 80 / 100 us, 242 - 254 -> 148 - 174 VGPRs, bench 52.7k -> 54.3k.]
 // Measured (MI355X, B = 64, one step in flight, us per launch): layer 5 image 11 + q/k 37 + norms 6 + v 42 = 96 (table path 83 + 37 = 120);
 // layer 6 image 5 + q/k 59 + norms 6 + v 47 = 117 (96 + 54 = 150); whole bench 48.1k -> 50.0k object-instances/s.  What bounds the two big
 // kernels (timing variants, 12 steps in flight, us: whole | attention loops only | GEMM phases only): layer 6 q/k 56 | 18 | 45, v 50 | 18 | 31;
@@ -331,6 +333,9 @@ __device__ __forceinline__ void ft_gemm_phase(const FtJob<KS> (&jobs)[NJ], const
 // (job, head); ~120 VGPRs.  Every job's M-tile count is a multiple of three by construction (96 or 384 rows).
 // (Order: the operand images are read-only no-alias memory and the loop stores nothing, so only data dependencies keep hipcc from hoisting all sixteen
 //  batches' loads to the top -- the batch's lane offset passes through a volatile asm, and so do the accumulators after its MFMAs: edge.hip, pool kernel.)
+#ifndef LS_FT_KB
+#define LS_FT_KB 2
+#endif
 template <int KS, int HG, int NJ>
 __device__ __forceinline__ void ft_gemm_phase_g3(const FtJob<KS> (&jobs)[NJ], const uint4* __restrict__ wplanes, const int* __restrict__ wexp, int head0,
                                                  int wave, int lane) {
@@ -356,30 +361,41 @@ __device__ __forceinline__ void ft_gemm_phase_g3(const FtJob<KS> (&jobs)[NJ], co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
         unsigned voff = (unsigned)lane * 16u;
-#pragma unroll
-        for (int k0 = 0; k0 < KS; k0 += 2) {
+        constexpr int KB = LS_FT_KB;   // k-steps per batch
+        struct Stage { fh8_t ah[3][KB], al[3][KB], bh[KB], bl[KB]; };
+        auto load_stage = [&](Stage& sg, int k0) {
             asm volatile("" : "+v"(voff));
-            fh8_t ah[3][2], al[3][2], bh[2], bl[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                bh[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2) * 1024 + voff));
-                bl[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2 + 1) * 1024 + voff));
+            for (int u = 0; u < KB; ++u) {
+                sg.bh[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2) * 1024 + voff));
+                sg.bl[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2 + 1) * 1024 + voff));
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    ah[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2) * 1024 + voff));
-                    al[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2 + 1) * 1024 + voff));
+                    sg.ah[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2) * 1024 + voff));
+                    sg.al[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2 + 1) * 1024 + voff));
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);   // (all sixteen requests first: the scheduler would sink each load to its MFMA)
+        };
+        auto run_stage = [&](const Stage& sg) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < KB; ++u)
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m][u], bh[u], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m][u], bh[u], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m][u], bl[u], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.al[m][u], sg.bh[u], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.ah[m][u], sg.bh[u], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.ah[m][u], sg.bl[u], acc[m], 0, 0, 0);
                 }
             asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])::"memory");
+        };
+        // (Two register stages -- batch b + 1 requested before batch b's MFMAs -- were built and measured: layers 5 / 6 79.3 / 103.4 us against 80.7 / 102.9 us
+        //  alone, bench 53.96k against 54.37k: 64 more VGPRs buy no overlap that an L2 round trip of ~2 us against 576 matrix-pipe cycles could use.
+        //  Batches of one k-step (137 - 165 VGPRs): 88 / 105 us, 53.5k; of four (212 - 238): 82 / 112 us, 53.4k; two it is: 81 / 102 us, 54.1k.)
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += KB) {
+            Stage sg;
+            load_stage(sg, k0);
+            __builtin_amdgcn_sched_barrier(0);   // (all requests of the batch first: the scheduler would sink each load to its MFMA)
+            run_stage(sg);
         }
         // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
