@@ -195,136 +195,14 @@ __device__ __forceinline__ void ft_fma43(FT43& acc, float w, const FT43& y) {
 
 // One "job" of a phase: slab[rows of the instance][HG heads x (lin 16 | dir 16)] = A rows . W tile^T for weight pair `p` of the workgroup's heads.
 //   A: the instance's M-tiles mt0 .. mt0 + MT of an A-plane image; W: tile (head0 + hl) * 5 + p.
-// The flattened (head-local, M-tile) list of every job of a phase is cut into four contiguous pieces, one per wave; a wave keeps the W
-// fragments of its current tile in registers (KS x 8 VGPRs) and streams the A fragments (2 KB per k-step, coalesced, L2-resident).
 template <int KS>
 struct FtJob { const uint4* a_planes; const int* a_exp; int mt0; int MT; int p; float* slab; int sld; };
 
-template <int KS, int HG, int NJ>
-__device__ __forceinline__ void ft_gemm_phase(const FtJob<KS> (&jobs)[NJ], const uint4* __restrict__ wplanes, const int* __restrict__ wexp, int head0,
-                                              int wave, int lane) {
-    int total = 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) total += jobs[j].MT * HG;
-    const int per = (total + 3) / 4;
-    const int lo = wave * per, hi = min(total, lo + per);
-    fh8_t bh[KS], bl[KS];
-    int cur_tile = -1;
-    int we = 0;
-    // (job, head-local, M-tile) of flat item t: jobs in order, inside a job head-major
-    auto decode = [&](int t, FtJob<KS>& jb, int& hl, int& mt) {
-        int j = 0, off = t;
-#pragma unroll
-        for (int q = 0; q < NJ - 1; ++q)
-            if (j == q && off >= jobs[q].MT * HG) { off -= jobs[q].MT * HG; j = q + 1; }
-        jb = jobs[0];
-#pragma unroll
-        for (int q = 1; q < NJ; ++q)
-            if (j == q) jb = jobs[q];
-        hl = off / jb.MT;
-        mt = off - hl * jb.MT;
-    };
-    auto a_ptr = [&](int t) {
-        FtJob<KS> jb;
-        int hl, mt;
-        decode(t, jb, hl, mt);
-        return jb.a_planes + ((size_t)(jb.mt0 + mt) * KS * 2) * 64 + lane;
-    };
-    auto load_w = [&](int T) {   // wave-uniform
-        if (T == cur_tile) return;
-        cur_tile = T;
-        const uint4* wp = wplanes + ((size_t)T * KS * 2) * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bh[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2) * 64]);
-            bl[ks] = __builtin_bit_cast(fh8_t, wp[(size_t)(ks * 2 + 1) * 64]);
-        }
-        we = wexp[T * 32 + (lane & 31)];
-    };
-    auto store_tile = [&](const FtJob<KS>& jb, int hl, int mt, const ff16_t& acc) {
-        // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-        const int row0 = 32 * mt + 4 * (lane >> 5);
-        float* sp = jb.slab + (size_t)row0 * jb.sld + hl * 32 + (lane & 31);
-        const int* ae = jb.a_exp + (jb.mt0 + mt) * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            sp[dr * jb.sld] = __builtin_ldexpf(acc[r], ae[dr] + we);
-        }
-    };
-    // A k-step is 96 matrix-pipe cycles, an L2 round trip ~1 500: the A fragments must be in flight LONG before their MFMAs.  Written as load,
-    // load, three MFMAs per k-step the compiler put an s_waitcnt vmcnt(0) in front of every MFMA group (105 us per launch at layer 6).
-    if constexpr (KS <= 8) {
-        // whole tiles (KS x 2 loads = 64 VGPRs at KS = 8), double-buffered: tile t + 1 is requested before tile t's MFMAs start
-        fh8_t a0h[KS], a0l[KS], a1h[KS], a1l[KS];
-        auto load_a = [&](int t, fh8_t (&h)[KS], fh8_t (&l)[KS]) {
-            const uint4* ap = a_ptr(t);
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                h[u] = __builtin_bit_cast(fh8_t, ap[(size_t)(u * 2) * 64]);
-                l[u] = __builtin_bit_cast(fh8_t, ap[(size_t)(u * 2 + 1) * 64]);
-            }
-        };
-        auto tile = [&](int t, const fh8_t (&h)[KS], const fh8_t (&l)[KS]) {
-            FtJob<KS> jb;
-            int hl, mt;
-            decode(t, jb, hl, mt);
-            load_w((head0 + hl) * 5 + jb.p);
-            ff16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(l[u], bh[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h[u], bh[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h[u], bl[u], acc, 0, 0, 0);
-            }
-            store_tile(jb, hl, mt, acc);
-        };
-        if (lo < hi) load_a(lo, a0h, a0l);
-        for (int t = lo; t < hi; t += 2) {
-            if (t + 1 < hi) load_a(t + 1, a1h, a1l);
-            __builtin_amdgcn_sched_barrier(0);   // (requests above, matrix work below: the scheduler must not sink a load to its first use)
-            tile(t, a0h, a0l);
-            if (t + 2 < hi) load_a(t + 2, a0h, a0l);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < hi) tile(t + 1, a1h, a1l);
-        }
-    } else {
-        // KS = 16: the W fragments already take 128 VGPRs, so the A fragments come in batches of 8 k-steps (64 VGPRs), single-buffered; the other
-        // workgroup on the CU covers the wait
-        constexpr int AB = 8;
-        for (int t = lo; t < hi; ++t) {
-            FtJob<KS> jb;
-            int hl, mt;
-            decode(t, jb, hl, mt);
-            load_w((head0 + hl) * 5 + jb.p);
-            const uint4* ap = jb.a_planes + ((size_t)(jb.mt0 + mt) * KS * 2) * 64 + lane;
-            ff16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int k0 = 0; k0 < KS; k0 += AB) {
-                fh8_t ah[AB], al[AB];
-#pragma unroll
-                for (int u = 0; u < AB; ++u) {
-                    ah[u] = __builtin_bit_cast(fh8_t, ap[(size_t)((k0 + u) * 2) * 64]);
-                    al[u] = __builtin_bit_cast(fh8_t, ap[(size_t)((k0 + u) * 2 + 1) * 64]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < AB; ++u) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u], bh[k0 + u], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bh[k0 + u], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bl[k0 + u], acc, 0, 0, 0);
-                }
-            }
-            store_tile(jb, hl, mt, acc);
-        }
-    }
-}
-
-// Round 4, late: the same phase with THREE M-tiles per unit of work and nothing resident.  Why: the form above keeps a W tile in registers (128 VGPRs at
+// (First form, until late round 4 -- kept as a note, the code is gone: the flattened (head-local, M-tile) list of a phase cut into four contiguous pieces,
+//  one 32 x 32 item at a time, the item's W tile resident in registers (KS x 8 VGPRs), its A fragments in batches of eight k-steps, double-buffered
+//  whole tiles at K = 128.  Lessons that still hold: `load, load, 3 MFMA` per k-step makes hipcc wait vmcnt(0) before every MFMA group -- request a
+//  batch, fence, then consume it; a run-time-trip-count loop of dependent global loads serialises.)
+// The GEMM phase: THREE M-tiles per unit of work and nothing resident.  Why: the first form kept a W tile in registers (128 VGPRs at
 // K = 256) -- 242 - 254 VGPRs per wave, i.e. the two workgroups of a CU own its whole register file while their waves sit through ~13 sequential L2
 // round trips per q / k phase pair, and LS_SKIP=hi32 shows that these layers cost 0.165 ms of the 1.21 ms step in steady state: nothing can be
 // resident beside them.  Here a unit = (job, head, three consecutive M-tiles = the 96 feature rows of 32 points): three independent accumulators,
@@ -412,14 +290,7 @@ __device__ __forceinline__ void ft_gemm_phase_g3(const FtJob<KS> (&jobs)[NJ], co
         }
     }
 }
-#ifndef LS_FT_G3
-#define LS_FT_G3 1
-#endif
-#if LS_FT_G3
 #define LS_FT_PHASE ft_gemm_phase_g3
-#else
-#define LS_FT_PHASE ft_gemm_phase
-#endif
 
 // thread -> (point, head-local, quad lane, neighbour range) of the attention phases: 256 threads = 32 points x HG heads x 4 lanes x (2 / HG) neighbour halves
 template <int HG>
