@@ -109,6 +109,13 @@ def build(force=False, verbose=False):
     if (not force) and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = {k: list(v) for k, v in EXTRA_FLAGS.items()}
+    if any("-amdgpu-mfma-vgpr-form" in f for v in extra.values() for f in v):
+        # an LLVM-internal option (a pure instruction-count optimisation, the kernels are correct in either register form): dropped when this hipcc lacks it
+        probe = subprocess.run([hipcc, "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-x", "hip", "-c", "-o", os.devnull, "-"],
+                               input=b"__global__ void ls_probe() {}\n", stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if probe.returncode != 0:
+            extra = {k: [f for f in v if f != "-mllvm" and "-amdgpu-mfma-vgpr-form" not in f] for k, v in extra.items()}
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdr_t = max(hdr_t, os.path.getmtime(os.path.join(HERE, "..", "include", "livingscenes_hip.h")))
     procs, objs = [], []
@@ -118,7 +125,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
             continue
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + extra.get(s, []) + ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
