@@ -53,6 +53,11 @@ __device__ __forceinline__ u64 bperm64(int srclane, u64 v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(srclane << 2, (int)(unsigned)(v >> 32));
     return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u64 dpp_quad_bcast3(u64 v) {   // every lane of a quad receives the value of the quad's lane 3 (quad_perm [3,3,3,3])
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0xFF, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0xFF, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+}
 __device__ __forceinline__ u64 dpp_row_shr1(u64 v) {  // lane e of a 16-lane row receives lane e-1's value (lane 0: 0)
     const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x111, 0xF, 0xF, false);
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x111, 0xF, 0xF, false);
@@ -264,6 +269,13 @@ __device__ __forceinline__ unsigned kth_smallest_upper_bound(unsigned v, int K) 
     }
     return min(ans | 0x7FFFu, 0x7F800000u);
 }
+
+// the first ten exchanges of the 64-lane network: every aligned group of 16 lanes sorted ascending (DPP / ds_swizzle only)
+#define LS_SORT16(CX, v, lane)                                                                                         \
+    CX<1>(v, lane);                                                                                                    \
+    CX<3>(v, lane); CX<1>(v, lane);                                                                                    \
+    CX<7>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                                                    \
+    CX<15>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);
 
 #define LS_SORT64(CX, v, lane)                                                                                         \
     CX<1>(v, lane);                                                                                                    \

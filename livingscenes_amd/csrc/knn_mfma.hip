@@ -200,9 +200,25 @@ __global__ __launch_bounds__(256, CC == 32 ? 6 : 4) void knn_seed_kernel(const f
 #pragma unroll
     for (int u = 0; u < 4; ++u)
         ks[u] = make_key(quad_pair_distance<CC, FMA>(qv, qrow, sbase + (size_t)max(sidx[u], 0) * RF, lane), sidx[u], (sidx[u] >= 0) & qlast);
-    key_cx(ks[0], ks[1]); key_cx(ks[2], ks[3]); key_cx(ks[0], ks[2]); key_cx(ks[1], ks[3]); key_cx(ks[1], ks[2]);
-    u64 lk = ~0ull, rkey = ~0ull;
-    merge_keys<true>(ks[0], ks[1], ks[2], ks[3], lk, rkey, 16, lane);   // all distinct valid hints, sorted (K applies later)
+    // The row's 16 keys -- key (step u, quad g) sits in lane 4 g + 3 -- as ONE key per lane (lane 4 g + u takes step u's), sorted by the 16-lane
+    // network; repeated hints (equal keys: same index, same canonical distance) are adjacent afterwards, all but the first become "none" and the
+    // row is sorted once more (rare: wave-uniform branch).  Until round 4 the list was built by merge_keys' insertion loop: one ballot round
+    // of ~40 instructions per key that entered, ~7 rounds per wave = a quarter of this kernel's instructions; the result is the same list.
+    u64 lk = ~0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const u64 bq = dpp_quad_bcast3(ks[u]);
+        lk = (lane & 3) == u ? bq : lk;
+    }
+    LS_SORT16(cx64, lk, lane)
+    {
+        const u64 prev = dpp_row_shr1(lk);
+        const bool dup = (lane & 15) > 0 && prev == lk && lk != ~0ull;
+        if (__any(dup)) {
+            lk = dup ? ~0ull : lk;
+            LS_SORT16(cx64, lk, lane)
+        }
+    }
     if (live) seedkeys[((size_t)b * Nd + q) * 16 + (lane & 15)] = lk;
 }
 
