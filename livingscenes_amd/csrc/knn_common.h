@@ -277,6 +277,11 @@ __device__ __forceinline__ unsigned kth_smallest_upper_bound(unsigned v, int K) 
     CX<7>(v, lane); CX<2>(v, lane); CX<1>(v, lane);                                                                    \
     CX<15>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);
 
+// the first fifteen: every aligned group of 32 lanes sorted ascending
+#define LS_SORT32(CX, v, lane)                                                                                         \
+    LS_SORT16(CX, v, lane)                                                                                             \
+    CX<31>(v, lane); CX<8>(v, lane); CX<4>(v, lane); CX<2>(v, lane); CX<1>(v, lane);
+
 #define LS_SORT64(CX, v, lane)                                                                                         \
     CX<1>(v, lane);                                                                                                    \
     CX<3>(v, lane); CX<1>(v, lane);                                                                                    \

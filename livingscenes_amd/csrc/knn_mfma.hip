@@ -1162,7 +1162,8 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
         const int src = ((lane & 15) << 2) + 3;
         const u64 n0 = bperm64(src, ks[0]), n1 = bperm64(src, ks[1]), n2 = KO_US > 2 ? bperm64(src, ks[2]) : ~0ull;
         u64 k = lane < 16 ? best : (lane < 32 ? n0 : (lane < 48 ? n1 : n2));
-        LS_SORT64(cx64, k, lane)
+        if constexpr (KO_US == 1) { LS_SORT32(cx64, k, lane) }   // 16 + 16 keys: the 32-lane network (15 of the 21 exchanges) does it
+        else { LS_SORT64(cx64, k, lane) }
         best = k;
     }
     if (lane < K) {

@@ -91,7 +91,15 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_kernel(const float* __restrict
                 n += __builtin_popcountll(bal);
             }
             __builtin_amdgcn_wave_barrier();
-            for (int pos = 0; pos < n; pos += 48) {
+            int pos = 0;
+            if (c0 == 0) {   // nothing carried yet: the first 64 keys start at lane 0, and the usual ~18 of them need only the 32-lane network
+                u64 k = lane < n ? ls[lane] : ~0ull;
+                if (n <= 32) { LS_SORT32(cx64, k, lane) }   // (wave-uniform)
+                else { LS_SORT64(cx64, k, lane) }
+                best = k;
+                pos = 64;
+            }
+            for (; pos < n; pos += 48) {
                 u64 k = best;
                 if (lane >= 16) {
                     const int i = pos + lane - 16;
