@@ -372,6 +372,10 @@ __global__ __launch_bounds__(256, CC == 32 ? 4 : 2) void knn_sweep_kernel(const 
 
 // ---- 3. finish.  Same wave layout as the seed kernel; the seeded list is reloaded, survivors get canonical keys in rounds of
 // 16 per query (four quad-steps), a query flagged as overflowed scans every candidate the same way.
+// (Round 4, built and not kept: the four rows' survivors POOLED into one list of (row, survivor) pairs for the wave's 16 quads -- ceil(sum / 16)
+//  steps instead of max_r ceil(cnt_r / 4): 13.2 M -> 10.8 M VALU wave-instructions per launch, but every pair then gathers its query share too
+//  and the keys pass through an LDS table before they are merged: 36.5 -> 38.5 us alone (44 us with two steps unrolled) -- the kernel waits on
+//  its row gathers, not on issue slots.)
 template <int CC, bool FMA>
 __global__ __launch_bounds__(256, 4) void knn_finish_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                             const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int K,
