@@ -815,6 +815,8 @@ __global__ __launch_bounds__(256) void knn_sweep_f16_kernel(const unsigned short
     // Where the layer-1 launch's 42 us go (timing variants, 12 steps in flight): without the survivor loop 35, without filter arithmetic and loop 28,
     // without the MFMAs 32 -- i.e. MFMA ~10, filter ~7, survivor bookkeeping ~7, and ~18 that are the fragment stream (403 MB through the L1 path
     // = 11.7 us at 64 B/clk/CU), the per-wave set-up and the flush: no single lever is left in this kernel.
+    // (Late round 4: forced to four waves per SIMD -- __launch_bounds__(256, 4): 136 -> 128 VGPRs with ten spilled, two scratch accesses per tile --
+    //  the layer-1 launch went from 43 to 64 us; three waves it stays.)
     struct TileIn { f16x8k bf[KK]; float Bc, ic; };
     auto load_tile = [&](int t, TileIn& ti) {
         const int tc = min(t, t1 - 1);
