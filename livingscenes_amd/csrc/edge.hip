@@ -738,7 +738,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     {
         // (DP = 3 / 4 -- 195 / 219 VGPRs, still two workgroups per CU -- measured in round 4: layers 2 / 3 / 4 at 120 / 114 / 81 and 120 / 113 / 82 us
         //  against 110 / 111 / 84 us: a deeper prefetch does not deliver the rows faster, the vector-memory path is at its throughput.  Nor is it L2
-        //  channel camping on the 1 KB row stride: table rows padded by 128 / 256 bytes changed nothing, 105 / 108 / 81 -> 106 / 108 / 82 us.)
+        //  channel camping on the 1 KB row stride: table rows padded by 128 / 256 bytes changed nothing, 105 / 108 / 81 -> 106 / 108 / 82 us.  Nor does
+        //  locality help: every point's neighbours taken in ascending index order (a 63-comparator sort in registers), with and without the Morton
+        //  processing order: layers 2 / 3 / 4 119 / 99 / 80 and 109 / 97 / 79 us against 103 / 102 / 79 us.)
         constexpr int DP = 2;
         F43 py[DP], pd[DP];
 #pragma unroll
