@@ -56,6 +56,10 @@ typedef enum {
 
 #define LS_MAX_LAYERS 8
 
+/* version of this C ABI: bumped whenever a signature or struct layout changes incompatibly (101: double-precision Adam hyper-parameters in
+ * ls_adam_group / ls_adam_step_f32 / ls_se3_adam_step_f32, LS_OPT_EDGE_STAGED).  ls_version() returns the value the LIBRARY was built with; a
+ * binding compares it with the header it was written against and refuses a mismatch (livingscenes_amd/_lib.py: load). */
+#define LS_ABI_VERSION 101
 int ls_version(void);
 const char* ls_last_error(void);
 /* number of HIP devices visible, or a negative ls_status */
@@ -238,6 +242,10 @@ void ls_model_destroy(ls_model_t* m);
 #define LS_OPT_ENCODE_GRAPH 3     /* [0, or LS_ENCODE_GRAPH in the environment] ls_encode replays a captured hipGraph of its ~170 launches (one per
                                      (workspace, B, N, flags, stream); needs a non-NULL stream; profiled / traced calls always enqueue directly).
                                      Off by default: on ROCm 7.2 the replay measured slower than direct enqueue (22.2k vs 29.6k obj/s, one step in flight) */
+#define LS_OPT_EDGE_STAGED 4      /* [0, or LS_EDGE_STAGED in the environment] attention layers 2 - 4 (vec_dgcnn_atten.py:205-219) with LDS-staged neighbour tiles
+                                     (edge_staged.hip): 0 = never (row gathers through L1: edge_attn_fq_kernel), 1 = when one workgroup per CU fills the chip
+                                     (B * Nd / 128 >= 128), 2 = whenever the layer shape fits.  The two kernels agree to ~1e-6 of the tensor maximum.  Off by
+                                     default: measured at B = 64 (round 5) 132 / 104 / 105 us against 96 / 107 / 82 us at layers 2 / 3 / 4 */
 int ls_model_set_option(ls_model_t* m, int option, int value);
 /* the handle's CURRENT value of an option (what ls_model_create read from the environment, or the last ls_model_set_option): the only
  * way a caller can change an option temporarily and put back exactly what was there */

@@ -16,7 +16,8 @@ FLAG_CONTRACT_FMA = 1
 FLAG_KNN_MFMA_FILTER = 2
 FLAG_KNN_VALU_ONLY = 4
 FLAG_KABSCH_RAW_WEIGHTS = 8
-OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2, OPT_ENCODE_GRAPH = 1, 2, 3
+OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2, OPT_ENCODE_GRAPH, OPT_EDGE_STAGED = 1, 2, 3, 4
+ABI_VERSION = 101   # == LS_ABI_VERSION in include/livingscenes_hip.h: a library of another version is refused (argument layouts differ)
 KABSCH_OK, KABSCH_RANK1, KABSCH_RANK0, KABSCH_NONFINITE = 0, 1, 2, 3
 
 
@@ -166,6 +167,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        got = int(lib.ls_version())
+        if got != ABI_VERSION:
+            raise LsError(f"{LIB_PATH} reports C-ABI version {got}, this binding was written for {ABI_VERSION}: rebuild the library "
+                          "(`python -m livingscenes_amd.build --force`) -- a stale library would reinterpret arguments silently")
         _lib = lib
     return _lib
 

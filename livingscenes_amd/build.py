@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblivingscenes_hip.so")
-SOURCES = ["model.hip", "knn.hip", "knn_mfma.hip", "knn_xyz.hip", "fps.hip", "gemm.hip", "edge.hip", "edge_fused.hip", "pointwise.hip", "sdf.hip", "match.hip", "icp.hip", "mise.hip", "mcubes.hip", "sinkhorn.hip", "optim.hip"]
+SOURCES = ["model.hip", "knn.hip", "knn_mfma.hip", "knn_xyz.hip", "fps.hip", "gemm.hip", "edge.hip", "edge_fused.hip", "edge_staged.hip", "pointwise.hip", "sdf.hip", "match.hip", "icp.hip", "mise.hip", "mcubes.hip", "sinkhorn.hip", "optim.hip"]
 # -fno-slp-vectorize: no COMPILER-FORMED packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Measured on MI355X (round 2,
 # scripts/diag/edge_determinism.py): the attention edge kernel built WITH those instructions was not reproducible while its waves
 # shared CUs with the bf16-MFMA GEMM of other streams -- the last 16 lanes of a wave occasionally consumed a stale operand (1e-6..1e-5
@@ -31,7 +31,8 @@ EXTRA_FLAGS = {"pointwise.hip": ["-fno-vectorize"], "knn_mfma.hip": ["-mllvm", "
 # allowed substrings -- a future hipcc, a dropped flag or an innocent float2 cannot silently bring the defect back.  Allowed: the
 # kernels that spell packed math on purpose (explicit 2-vectors in the f16 split of the fused attention kernel's staging phase and of
 # the weight pre-split), covered by the bit-identity tests with 12 handles in flight (tests/test_hip_fullbatch.py).
-PACKED_FP32_GUARD = {"edge.hip": ["edge_attn_fq_kernel", "edge_presplit_wq_kernel"], "edge_fused.hip": ["edge_ft_presplit_w_kernel", "edge_ft_prep_a_kernel"], "pointwise.hip": []}
+PACKED_FP32_GUARD = {"edge.hip": ["edge_attn_fq_kernel", "edge_presplit_wq_kernel"], "edge_fused.hip": ["edge_ft_presplit_w_kernel", "edge_ft_prep_a_kernel"],
+                     "edge_staged.hip": ["edge_st_presplit_q_kernel", "edge_attn_staged_kernel"], "pointwise.hip": []}
 
 
 def llvm_bin():

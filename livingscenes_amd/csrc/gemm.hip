@@ -193,6 +193,27 @@ __device__ __forceinline__ void store_half_tile(const float* stg, float* __restr
     }
 }
 
+// store_half_tile for the SLICE-MAJOR layout (GemmAux::slice_cols / slice_rows; edge_staged.hip): the half tile's 64 columns are 64 / sc slices, and the 32
+// rows x sc columns of one slice are CONTIGUOUS in memory (32 * sc floats: 1 KB at sc = 8) -- the lanes walk the half tile slice by slice, so every
+// store instruction writes whole lines.  gm0 % 32 == 0 and slice_rows % 32 == 0: the 32 rows belong to one instance.
+__device__ __forceinline__ void store_half_tile_sliced(const float* stg, float* __restrict__ out, int M, int N, int gm0, int gn0, int lane, int sc, int srows) {
+    const int bi = gm0 / srows, r0 = gm0 - bi * srows;
+    float* ob = out + (size_t)bi * srows * N + (size_t)r0 * sc;
+    const size_t sstride = (size_t)srows * sc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx = u * 64 + lane;           // float4 index inside the half tile, slice-major: [slice][row][float4 of the row's sc columns]
+        int s_, rr, q;
+        if (sc == 8) { s_ = idx >> 6; rr = (idx >> 1) & 31; q = idx & 1; }
+        else { s_ = idx >> 5; rr = idx & 31; q = 0; }
+        const int gn = gn0 + s_ * sc + q * 4;
+        if (gm0 + rr < M && gn < N) {
+            const float4 v = *reinterpret_cast<const float4*>(&stg[rr * 68 + s_ * sc + q * 4]);
+            *reinterpret_cast<float4*>(ob + (size_t)(gn / sc) * sstride + (size_t)rr * sc + q * 4) = v;
+        }
+    }
+}
+
 // Optional row gather (down-sampled encoder layers): output row m = (b*gNd + n)*3 + x reads A row
 // (b*gNs + a_rows[b*gNd + n])*3 + x, i.e. the GEMM runs only on the FPS-selected points of each instance.
 // PIECES = 2 (opt-in, LS_SDF_BF16X2): a = a1 + a2 only, three MFMAs per 16 k (a1b1 + a1b2 + a2b1); products carry a 2^-16
@@ -1543,7 +1564,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
-            store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, nullptr);
+            if (aux.slice_cols) store_half_tile_sliced(stg, out, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, aux.slice_cols, aux.slice_rows);
+            else store_half_tile(stg, out, ldc, M, N, m0 + wm * 64 + i * 32, n0 + wn * 64, lane, full_tile, vec_ok, nullptr);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1890,7 +1912,12 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     // CU): 480 tiles 88 -> 73 us, 768 tiles 355 -> 280 us, 3072 tiles 1186 -> 1002 us; ties at 384 tiles, loses below one round
     const long long wtiles = (long long)cdiv(M, 256) * cdiv(N, 256);
     const bool wide_on = wide_mode >= 0 ? wide_mode != 0 : (wtiles >= 1024 || (wtiles >= 256 && wtiles * 100 >= 85 * 256 * cdiv(wtiles, 256)));
-    if (split && pieces == 22 && persist && !mask && (K == 32 || K == 64) && tm >= 16 && !h2_unpipelined && !aux.out_rowmax) {
+    const bool sliced = aux.slice_cols != 0;
+    if (sliced)
+        LS_REQUIRE(split && pieces == 22 && !mask && !a_rows && (K == 32 || K == 64) && nsplit == 1 && !aux.out_rowmax && !bias && (aux.slice_cols == 4 || aux.slice_cols == 8) &&
+                   aux.slice_rows % 32 == 0 && M % aux.slice_rows == 0 && N % aux.slice_cols == 0 && ((uintptr_t)out & 15) == 0,
+                   "gemm: slice-major output needs the K = 32 / 64 f16-split kernel (M=%d N=%d K=%d slice %d x %d)", M, N, K, aux.slice_rows, aux.slice_cols);
+    if (split && pieces == 22 && (sliced || (persist && tm >= 16 && !h2_unpipelined)) && !mask && (K == 32 || K == 64) && !aux.out_rowmax) {
         static const int sk_wgs32 = getenv("LS_GEMM_PERSIST_WGS32") ? atoi(getenv("LS_GEMM_PERSIST_WGS32")) : 512;   // A/B
         static const int sk_wgs64 = getenv("LS_GEMM_PERSIST_WGS64") ? atoi(getenv("LS_GEMM_PERSIST_WGS64")) : 512;
         int per_n = cdiv(K == 32 ? sk_wgs32 : sk_wgs64, tn);   // resident workgroups per CU x 256, spread evenly over the N-tiles

@@ -116,6 +116,10 @@ struct GemmAux {
     const void* w_planes = nullptr;    // pre-split W (gemm_presplit_w_launch): row n = K / 32 lines [hi: 32 f16 | lo: 32 f16] of s_n W[n, :], s_n from w_rowmax (required)
     float* out_rowmax = nullptr;       // [M][2 * cdiv(N, 128)]: max|out[row, 64-column block]| written by the epilogue (un-split launches only)
     int noscale = 0;                   // LS_GEMM_RANGE=0: the round-2 arithmetic (no row scaling; |a| < 65504 required), A/B timing
+    // SLICE-MAJOR output (edge_staged.hip): the M rows are instances of slice_rows rows; element (m, n) goes to
+    // out[(m / slice_rows) * slice_rows * N + (n / slice_cols) * slice_rows * slice_cols + (m % slice_rows) * slice_cols + n % slice_cols] -- per instance
+    // N / slice_cols contiguous slices of [slice_rows][slice_cols] floats.  slice_cols = 4 | 8, slice_rows % 32 == 0; K = 32 / 64 GEMMs only (gemm_h2_smallk_kernel)
+    int slice_cols = 0, slice_rows = 0;
 };
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -53,6 +53,15 @@ int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, 
                         float* out, float* rowmax, hipStream_t st);
 int edge_ft_rowmax_parts(int Co, int Cin);
 int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipStream_t st);
+// edge_staged.hip: attention layers 2 - 4 with LDS-staged neighbour tiles (slice-major table)
+int edge_st_variant(int Co, int Cin);
+int edge_st_cs(int variant);
+int edge_st_pts(int variant);
+size_t edge_st_q_bytes(int Co, int Cin);
+bool edge_st_fits(int Co, int Cin, int Ns, int Nd);
+int edge_st_prepare_launch(const float* W, int Co, int Cin, float* Wp, void* qplanes, hipStream_t st);
+int edge_attn_staged_launch(const float* T, const float* cur, int Cin, const void* qplanes, const int32_t* knn, const int32_t* dst_rows, int B, int Nd, int Ns,
+                            int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax);
 int gemm_dispatch_gather(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, const int32_t*, int, int, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
@@ -105,6 +114,10 @@ struct ls_model {
     void* wt_planes[LS_MAX_LAYERS] = {};   // attention layers whose input has 128 / 256 channels (released layers 5, 6): ALL table weights as per-head f16
                                            // MFMA fragment tiles (edge_fused.hip); used when the call's point counts fit the fused kernels
     void* wq_planes[LS_MAX_LAYERS] = {};   // attention layers 2 - 4: destination-side weights as f16 MFMA fragments (edge.hip, edge_attn_fq_kernel)
+    float* wst_w[LS_MAX_LAYERS] = {};      // attention layers 2 - 4, LDS-staged path (edge_staged.hip): neighbour-side weight rows in slice order ...
+    void* wst_q[LS_MAX_LAYERS] = {};       // ... and the destination-side weights as per-Q-block f16 MFMA fragments
+    int edge_staged = 0;                   // LS_OPT_EDGE_STAGED: 0 = never (default: measured slower than the gather kernel), 1 = when the grid fills the chip
+                                           // (B * Nd / PTS >= 128 workgroups), 2 = whenever the shape fits
     float* dec_wt = nullptr;            // transposed decoder weights [kin_l][out_l], built by the first backward call
     size_t dec_wt_off[12] = {};
     // max|row| of every weight matrix a GEMM reads (gemm.hip, GemmAux::w_rowmax): saves the kernels their pre-pass over W
@@ -333,7 +346,7 @@ static size_t edge_table_floats(const ls_model_desc& d, int i, int B, int Ns, in
     return rows ? (size_t)B * 3 * ((size_t)Ns * pc + (size_t)Nd * (nc - pc)) : (size_t)B * Ns * 3 * nc;
 }
 struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; const float* cur = nullptr; const void* Wq = nullptr; int Cin = 0;
-                    const void* Wt = nullptr; };   // Wt != null: no table at all (edge_fused.hip); the table area holds that path's scratch   // cur != null: destination side fused into the edge kernel
+                    const void* Wt = nullptr; const void* Ws = nullptr; };   // Ws != null: slice-major table + staged kernel (edge_staged.hip), Ws = its Q planes   // Wt != null: no table at all (edge_fused.hip); the table area holds that path's scratch   // cur != null: destination side fused into the edge kernel
 
 // where the table(s) of layer i live in T and how the edge kernel reads them (no launch)
 static bool edge_fused(const ls_model* m, int i) {
@@ -357,10 +370,20 @@ static bool edge_fused_t(const ls_model* m, int i, int B, int Ns, int Nd, bool h
     return edge_ft_supported(Co, Cin, Ns, Nd, d.atten_head_c, has_rows) &&
            edge_ft_scratch_bytes(B, Ns, Nd, Cin, Co, has_rows) <= edge_table_floats(d, i, B, Ns, Nd, has_rows) * sizeof(float);
 }
+// LDS-staged path of attention layers 2 - 4 (edge_staged.hip): one 1024-thread workgroup per CU streams its instance's table through the LDS, so
+// it pays once B * Nd / PTS workgroups fill the chip; below that the gather kernel (edge_attn_fq_kernel) has the shorter critical path
+static bool edge_staged(const ls_model* m, int i, int B, int Ns, int Nd) {
+    const ls_model_desc& d = m->d;
+    if (!m->edge_staged || !m->wst_q[i] || !edge_fused(m, i) || i < d.atten_start_layer || d.atten_head_c != 16) return false;
+    const int Cin = layer_cin(d, i), Co = d.feat_dim[i];
+    if (!edge_st_fits(Co, Cin, Ns, Nd)) return false;
+    return m->edge_staged >= 2 || (long long)B * (Nd / edge_st_pts(edge_st_variant(Co, Cin))) >= 128;
+}
 static EdgeTables edge_tables_layout(const ls_model* m, int i, const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, float* T) {
     const ls_model_desc& d = m->d;
     const int Cin = layer_cin(d, i), nc = layer_ncols(d, i), pc = layer_pcols(d, i);
     if (edge_fused_t(m, i, B, Ns, Nd, dst_rows != nullptr)) { EdgeTables e{nullptr, 0, 0, 0, 0, cur, nullptr, Cin}; e.Wt = m->wt_planes[i]; return e; }
+    if (edge_staged(m, i, B, Ns, Nd)) { EdgeTables e{nullptr, pc, 0, 0, 0, cur, nullptr, Cin}; e.Ws = m->wst_q[i]; return e; }
     // (the fused kernel gathers table rows by 32-bit byte offsets: a batch whose neighbour-side table reaches 4 GB takes the table path)
     if (edge_fused(m, i) && edge_attn_fq_fits(B, Ns, pc)) return EdgeTables{nullptr, pc, 0, 0, 0, cur, m->wq_planes[i], Cin};
     if (dst_rows) return EdgeTables{T + (size_t)B * Ns * 3 * pc, pc, nc - pc, Nd, 0};
@@ -380,6 +403,12 @@ static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_
     // attention layers 2 - 4 (fused): only the neighbour-side table; the destination side is computed inside the edge kernel (edge.hip)
     GemmAux ax = aux_w(m, W, nc, Cin);
     ax.a_rowmax = a_rowmax; ax.a_parts = a_parts;
+    if (et.Ws) {   // slice-major neighbour-side table from the slice-ordered weight rows (edge_staged.hip)
+        GemmAux as = aux_w(m, m->wst_w[i], pc, Cin);
+        as.a_rowmax = a_rowmax; as.a_parts = a_parts;
+        as.slice_cols = 2 * edge_st_cs(edge_st_variant(d.feat_dim[i], Cin)); as.slice_rows = Ns * 3;
+        return gemm_dispatch(cur, Cin, m->wst_w[i], Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs, as);
+    }
     if (et.cur) return gemm_dispatch(cur, Cin, W, Cin, nullptr, T, pc, B * Ns * 3, pc, Cin, 0, gs, ax);
     if (dst_rows) {
         // down-sampled layer: P table on all source points, Q table only on the FPS-selected destination points
@@ -407,6 +436,10 @@ static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, 
             if (rm_written) *rm_written = rm_out != nullptr;
             if (rm_parts) *rm_parts = edge_ft_rowmax_parts(Co, et.Cin);
             return edge_ft_attn_launch(et.Wt, knn, dst_rows != nullptr, B, Ns, Nd, et.Cin, Co, d.neg_slope, const_cast<float*>(T), out, rm_out, st);
+        }
+        if (et.Ws) {
+            if (rm_written) *rm_written = rm_out != nullptr;
+            return edge_attn_staged_launch(T, et.cur, et.Cin, et.Ws, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
         }
         if (et.cur) {
             if (rm_written) *rm_written = rm_out != nullptr;
@@ -489,7 +522,7 @@ static int encoder_tail(ls_model* m, const float* cur, int B, int NP, float* Tc,
 
 extern "C" {
 
-int ls_version(void) { return 100; }
+int ls_version(void) { return LS_ABI_VERSION; }
 const char* ls_last_error(void) { return g_err; }
 
 int ls_device_count(void) {
@@ -668,10 +701,21 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
         const int rc = edge_presplit_wq_launch(m->blob + desc->off_edge[i] + (size_t)layer_pcols(*desc, i) * Cin, Co, Cin, m->wq_planes[i], nullptr);
         if (rc != LS_OK || hipDeviceSynchronize() != hipSuccess) { ls_model_destroy(m); return LS_ERR_HIP; }
     }
+    if (const char* ev = getenv("LS_EDGE_STAGED")) m->edge_staged = atoi(ev);
+    for (int i = desc->atten_start_layer; i < desc->num_layers && i >= 1; ++i) {   // LDS-staged attention (edge_staged.hip): slice-ordered P rows + Q-block planes
+        const int Co = desc->feat_dim[i], Cin = layer_cin(*desc, i);
+        if (desc->atten_head_c != 16 || !edge_st_variant(Co, Cin) || !m->wq_planes[i]) continue;
+        e = hipMalloc((void**)&m->wst_w[i], (size_t)4 * Co * Cin * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&m->wst_q[i], edge_st_q_bytes(Co, Cin));
+        if (e != hipSuccess) { set_error("model_create: %s", hipGetErrorString(e)); ls_model_destroy(m); return LS_ERR_HIP; }
+        const int rc = edge_st_prepare_launch(m->blob + desc->off_edge[i], Co, Cin, m->wst_w[i], m->wst_q[i], nullptr);
+        if (rc != LS_OK || hipDeviceSynchronize() != hipSuccess) { ls_model_destroy(m); return LS_ERR_HIP; }
+    }
     {   // row maxima of every matrix the GEMMs read (GemmAux::w_rowmax)
         std::vector<WSpec> specs;
         const ls_model_desc& d = *desc;
         for (int i = 1; i < d.num_layers; ++i) specs.push_back({m->blob + d.off_edge[i], (size_t)layer_ncols(d, i), layer_cin(d, i)});
+        for (int i = 1; i < d.num_layers; ++i) if (m->wst_w[i]) specs.push_back({m->wst_w[i], (size_t)layer_pcols(d, i), layer_cin(d, i)});
         for (int i = d.res_global_start_layer; i < d.num_layers; ++i)
             if (i >= 0) specs.push_back({m->blob + d.off_glob[i], (size_t)4 * d.feat_dim[i], d.feat_dim[i]});
         if (d.num_layers >= 1) specs.push_back({m->blob + d.off_convc, align_up((size_t)d.c_dim + 1, 4), d.feat_dim[d.num_layers - 1]});
@@ -702,6 +746,8 @@ void ls_model_destroy(ls_model_t* m) {
     for (int i = 0; i < LS_MAX_LAYERS; ++i) {
         if (m->wq_planes[i]) (void)hipFree(m->wq_planes[i]);
         if (m->wt_planes[i]) (void)hipFree(m->wt_planes[i]);
+        if (m->wst_w[i]) (void)hipFree(m->wst_w[i]);
+        if (m->wst_q[i]) (void)hipFree(m->wst_q[i]);
     }
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->side2) (void)hipStreamDestroy(m->side2);
@@ -725,6 +771,7 @@ int ls_model_set_option(ls_model_t* m, int option, int value) {
         case LS_OPT_SDF_TRAIN_SPLITK: m->train_splitk = value != 0; return LS_OK;
         case LS_OPT_SDF_BF16X2: m->sdf_bf16x2 = value != 0; return LS_OK;
         case LS_OPT_ENCODE_GRAPH: m->use_graph = value != 0; return LS_OK;
+        case LS_OPT_EDGE_STAGED: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_EDGE_STAGED takes 0, 1 or 2"); m->edge_staged = value; return LS_OK;
         default: set_error("model_set_option: unknown option %d", option); return LS_ERR_INVALID;
     }
 }
@@ -735,6 +782,7 @@ int ls_model_get_option(const ls_model_t* m, int option, int* value) {
         case LS_OPT_SDF_TRAIN_SPLITK: *value = m->train_splitk ? 1 : 0; return LS_OK;
         case LS_OPT_SDF_BF16X2: *value = m->sdf_bf16x2 ? 1 : 0; return LS_OK;
         case LS_OPT_ENCODE_GRAPH: *value = m->use_graph ? 1 : 0; return LS_OK;
+        case LS_OPT_EDGE_STAGED: *value = m->edge_staged; return LS_OK;
         default: set_error("model_get_option: unknown option %d", option); return LS_ERR_INVALID;
     }
 }
