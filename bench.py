@@ -237,7 +237,7 @@ def fps_entry(level, avg_s, cfg, B, N):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (one process each); default: the launcher's WORLD_SIZE, 1 without a launcher")
     ap.add_argument("--steps", type=int, default=480,
                     help="timed steps (a step is ~2.5 ms: a 24-step region was short enough for one host hiccup to cost 25 %%)")
     ap.add_argument("--warmup", type=int, default=48)
@@ -266,6 +266,7 @@ def main():
     # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (does not return); started by a launcher it
     # insists on WORLD_SIZE == N -- a `--gpus 8` command can never silently measure one GPU.
     world, rank, local_rank = launch.ensure_ranks(args.gpus, __file__, sys.argv[1:])
+    args.gpus = world
     if world > 1:   # one line per rank on stderr, before anything can fail: the launcher's log shows how many ranks really started
         print(f"bench.py: rank {rank} of {world} started (local_rank {local_rank}, pid {os.getpid()})", file=sys.stderr, flush=True)
     global torch
@@ -278,6 +279,7 @@ def main():
     # LS_BENCH_BACKEND=gloo: dry run of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices; the
     # collectives go through the host) -- a logic check only, never a measurement
     backend = os.environ.get("LS_BENCH_BACKEND", "nccl")
+    launcher_local = local_rank          # (the shared-device dry run folds local_rank onto the devices that exist; the CPU binding keeps the launcher's)
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     elif local_rank >= torch.cuda.device_count():
@@ -285,6 +287,18 @@ def main():
                          f"(RCCL wants one GPU per rank; LS_BENCH_BACKEND=gloo is the shared-device dry run)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one rank per GPU: each rank on the cores next to ITS GPU, disjoint from the other ranks' (livingscenes_amd/launch.py: bind_rank); only a rank
+    # that runs the CPU leg (world == 1) keeps a thread pool
+    n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    try:
+        props = [torch.cuda.get_device_properties(r % torch.cuda.device_count()) for r in range(n_local)]
+        pci = ["%04x:%02x:%02x.0" % (p_.pci_domain_id, p_.pci_bus_id, p_.pci_device_id) for p_ in props]
+    except Exception:
+        pci = None
+    my_cpus = launch.bind_rank(launcher_local if n_local > 1 else 0, n_local, pci)
+    if world > 1:
+        torch.set_num_threads(1)
+        print(f"bench.py: rank {rank} bound to CPUs {launch.format_cpulist(my_cpus)} (device {local_rank})", file=sys.stderr, flush=True)
     import torch.distributed as dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -379,7 +393,9 @@ def main():
     step_stats = {"inter_completion_ms_min": round(gaps[0], 4), "inter_completion_ms_median": round(gaps[len(gaps) // 2], 4),
                   "inter_completion_ms_p90": round(gaps[int(0.9 * (len(gaps) - 1))], 4), "inter_completion_ms_max": round(gaps[-1], 4),
                   "last_step_done_ms": round(done_ms[-1], 3)}
-    my = torch.tensor([dt, dt_host, float(torch.cuda.current_device()), float(B * args.steps)], device=dev, dtype=torch.float64)
+    # (+ the rank's CPU set as up to four 64-bit masks -> 256 hardware threads, so that a host-bound or doubly-booked rank shows in the line)
+    cpu_masks = [float(sum(1 << (c - 52 * k) for c in my_cpus if 52 * k <= c < 52 * (k + 1))) for k in range(8)]
+    my = torch.tensor([dt, dt_host, float(torch.cuda.current_device()), float(B * args.steps)] + cpu_masks, device=dev, dtype=torch.float64)
     dt_t = my[:1].clone()
     per_rank = None
     if multi:
@@ -387,8 +403,10 @@ def main():
         mine = my if backend == "nccl" else my.cpu()     # gloo gathers through host memory only
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
+        def cpus_of(v):
+            return launch.format_cpulist([52 * k + b for k in range(8) for b in range(52) if (int(v[4 + k]) >> b) & 1])
         per_rank = [{"rank": r, "device": int(v[2]), "objects": int(v[3]), "ms_per_step": round(float(v[0]) / args.steps * 1e3, 4),
-                     "host_enqueue_ms_per_step": round(float(v[1]) / args.steps * 1e3, 4)} for r, v in enumerate(allr)]
+                     "host_enqueue_ms_per_step": round(float(v[1]) / args.steps * 1e3, 4), "cpus": cpus_of(v)} for r, v in enumerate(allr)]
     dt = float(dt_t.item())
 
     # secondary figure (never `value`): the same K steps with LS_FLAG_CONTRACT_FMA, i.e. dist = fmaf(diff, diff, dist) as nvcc
@@ -602,7 +620,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1]+[2]: batch={B} instances x N={N} pts per GPU = {n_obj}-object scene + rescan; "
                                    f"VN-DGCNN encode, {n_obj}x{n_obj} sequential matching, {n_obj} Kabsch poses",
                        "instances_per_step_per_gpu": B, "points": N, "parallelism": f"instance-sharded x{world}",
-                       "steps_in_flight": nfl, "host_enqueue_ms_per_step": round(dt_host / args.steps * 1e3, 3), "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "steps_in_flight": nfl, "host_enqueue_ms_per_step": round(max([p_["host_enqueue_ms_per_step"] for p_ in per_rank] if per_rank else [dt_host / args.steps * 1e3]), 3),
+                       "host_enqueue_basis": "max over ranks" if per_rank else "this rank", "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "knn_arithmetic": "canonical (separately rounded mul/add)"},
             "check": {"oracle_relerr": oracle_check, "rotations_proper": det_ok, "matches_identity": f"{n_correct}/{n_obj}",
                       "handles_bit_identical": f"{handles_identical} ({len(ran)} handles, last step of each)",

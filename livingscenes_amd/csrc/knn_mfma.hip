@@ -1146,7 +1146,8 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
         if (keep) sp[pos] = (unsigned short)j;
         cnt += __popcll(m);
     }
-    if (lane == 0) surv_cnt[qg] = cnt;    // how many candidates get a canonical distance: the exact-phase statistic (knn_sweep_stats_launch)
+    if (lane == 0) surv_cnt[qg] = -cnt - 1;   // how many candidates get a canonical distance: the exact-phase statistic (knn_sweep_stats_launch).  Stored as
+                                              // -(count + 1): a RAW count of up to KO_MAXNS, not a sweep-path list length (whose values above KS_CAP mean "scanned all Ns")
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the list is wave-private, LDS ops of a wave complete in order
     __builtin_amdgcn_wave_barrier();
     // 4. canonical keys of the survivors, 16 KO_US per step, sorted with the list so far by the 64-lane network
@@ -1197,6 +1198,16 @@ size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C) {
            + ((size_t)B * Ns + (size_t)B * dst_n) * sizeof(float) + 256;                               // inverse row scales of the f16 images
 }
 
+// byte offset of the per-query survivor counters inside a sweep-path scratch area: row norms | inverse row scales | seed keys | COUNTERS | ...
+// (ONE definition for knn_sweep_launch_t, which lays the area out, and knn_sweep_stats_launch, which reads the counters back)
+static size_t knn_sweep_surv_cnt_offset(int B, int Ns, int dst_n, size_t nq) {
+    size_t off = (size_t)B * Ns * sizeof(float) + (size_t)B * dst_n * sizeof(float);     // row norms
+    off = (off + 255) & ~(size_t)255;
+    off += (size_t)B * Ns * sizeof(float) + (size_t)B * dst_n * sizeof(float);            // inverse row scales
+    off = (off + 255) & ~(size_t)255;
+    return off + nq * 16 * sizeof(u64);                                                   // seed keys
+}
+
 template <int CC>
 static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t* dst_rows, int B, int Nd, int dst_n, int Ns, int K, bool fma,
                               int32_t* idx_out, float* dist_out, const int32_t* seed_idx, int seed_n, int seed_by_row, void* scratch,
@@ -1220,6 +1231,7 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
     off = (off + 255) & ~(size_t)255;
     u64* seedkeys = (u64*)(sc + off);
     off += nq * 16 * sizeof(u64);
+    if (off != knn_sweep_surv_cnt_offset(B, Ns, dst_n, nq)) { set_error("knn sweep: scratch layout and knn_sweep_surv_cnt_offset disagree"); return LS_ERR_INVALID; }
     int32_t* surv_cnt = (int32_t*)(sc + off);
     off += nq * sizeof(int32_t);
     unsigned short* surv = (unsigned short*)(sc + off);
@@ -1386,7 +1398,7 @@ __global__ __launch_bounds__(256) void knn_stats_kernel(const int32_t* __restric
     unsigned long long s = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long long)gridDim.x * 256) {
         const int c = surv_cnt[i];
-        s += (unsigned long long)(c > KS_CAP ? Ns : c);
+        s += (unsigned long long)(c < 0 ? -(c + 1) : (c > KS_CAP ? Ns : c));      // negative: the one-sweep path's raw count (knn_finish_select_kernel)
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&out[0], s);
@@ -1394,11 +1406,7 @@ __global__ __launch_bounds__(256) void knn_stats_kernel(const int32_t* __restric
 }
 int knn_sweep_stats_launch(const void* scratch, int B, int Nd, int dst_n, int Ns, unsigned long long* out, hipStream_t st) {
     const size_t nq = (size_t)B * Nd;
-    size_t off = (size_t)B * Ns * sizeof(float) + (size_t)B * dst_n * sizeof(float);     // row norms            (layout of knn_sweep_launch_t)
-    off = (off + 255) & ~(size_t)255;
-    off += (size_t)B * Ns * sizeof(float) + (size_t)B * dst_n * sizeof(float);            // inverse row scales
-    off = (off + 255) & ~(size_t)255;
-    off += nq * 16 * sizeof(u64);                                                         // seed keys
+    const size_t off = knn_sweep_surv_cnt_offset(B, Ns, dst_n, nq);
     hipLaunchKernelGGL(knn_stats_kernel, dim3((unsigned)std::min<size_t>(cdiv((long long)nq, 256), 256)), dim3(256), 0, st,
                        (const int32_t*)((const char*)scratch + off), (long long)nq, Ns, out);
     LS_LAUNCH_CHECK();

@@ -240,7 +240,14 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
         }
         maxTG = std::max(maxTG, (size_t)p.Nd[i] * 3 * 2 * p.Co[i]);
         maxC = std::max(maxC, (size_t)p.Co[i]);
-        if (i >= d.res_global_start_layer) maxRm = std::max(maxRm, (size_t)p.Nd[i]);
+        // row maxima of a layer's message / output: one part per 32 channels + 1, or -- where the table-free path of the 32-point layers may run
+        // (edge_fused.hip) -- one per head group; sized per LAYER (round 4 sized Nd and the parts by separate maxima, which only held because
+        // the released schedule has wide early layers: ADVICE r4)
+        if (i >= d.res_global_start_layer) {
+            size_t parts = (size_t)p.Co[i] / 32 + 1;
+            if (i > 0 && attn && (p.Cin[i] == 128 || p.Cin[i] == 256)) parts = std::max(parts, (size_t)edge_ft_rowmax_parts(p.Co[i], p.Cin[i]));
+            maxRm = std::max(maxRm, (size_t)p.Nd[i] * parts);
+        }
         // split-K slabs of the under-filled GEMMs (residual global conv: per-point part and per-instance mean part)
         maxGws = std::max(maxGws, std::max(gemm_scratch_floats(B * p.Nd[i] * 3, 2 * p.Co[i], p.Co[i]), gemm_scratch_floats(B * 3, 4 * p.Co[i], p.Co[i])));
         maxKnn = std::max(maxKnn, (size_t)p.Nd[i] * 16);
@@ -277,9 +284,9 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     maxGws = std::max(maxGws, gemm_scratch_floats(B * p.NP * 3, p.Cdp, p.Co[p.L - 1]));
     p.o_gws = take(maxGws * 4 + 256);
     // row maxima of the messages / layer outputs, chained into the GEMMs that read them (gemm.hip, GemmAux)
-    p.o_rm_msg = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);   // (the table-free 32-point layers emit one maximum per head group: <= C / 32 parts)
-    p.o_rm_out[0] = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);
-    p.o_rm_out[1] = take((size_t)B * maxRm * 3 * (maxC / 32 + 1) * 4);
+    p.o_rm_msg = take((size_t)B * maxRm * 3 * 4);      // maxRm = max over the layers of Nd x parts (above)
+    p.o_rm_out[0] = take((size_t)B * maxRm * 3 * 4);
+    p.o_rm_out[1] = take((size_t)B * maxRm * 3 * 4);
     // staging of the captured-graph path: the graph reads x from / writes the codes to FIXED addresses inside the workspace
     p.o_xin = take((size_t)B * 3 * N * 4);
     p.o_out = take((size_t)B * (4 * (size_t)d.c_dim + 4) * 4);

@@ -28,6 +28,39 @@ def shard_range(n_items, rank=None, world_size=None):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def balanced_assignment(costs, world_size=None):
+    """Cost-balanced partition of items with (integer) costs over the ranks: -> list of index lists, one per rank, each ascending.
+    Equal costs keep the contiguous block partition of shard_range (nothing to balance: identical to the unbalanced path).  Otherwise longest-
+    processing-time-first: items by decreasing cost (ties: by index) onto the currently lightest rank (ties: lowest rank) -- a deterministic
+    function of `costs`, so every rank computes the same assignment without talking; max load <= 4/3 of the optimum, and within a few per cent of
+    the mean once a rank holds several items.  Motivation (SURVEY 8e, configs[3]): a 3RScan instance has 1 k - 60 k raw points and the ragged FPS
+    costs ~P per cloud, so equal instance COUNTS leave ranks with very unequal work."""
+    if world_size is None:
+        world_size = world()[1]
+    n = len(costs)
+    costs = [int(c) for c in costs]
+    if n == 0 or min(costs) == max(costs):
+        return [list(range(*shard_range(n, r, world_size))) for r in range(world_size)]
+    load = [0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in sorted(range(n), key=lambda i: (-costs[i], i)):
+        r = min(range(world_size), key=lambda r: (load[r], r))
+        load[r] += costs[i]
+        out[r].append(i)
+    return [sorted(o) for o in out]
+
+
+def assignment_restore(assign, device=None):
+    """Index tensor that puts rows concatenated in rank order (rank 0's items, rank 1's, ...) back into the original item order."""
+    flat = [i for a in assign for i in a]
+    inv = torch.empty(len(flat), dtype=torch.long)
+    inv[torch.tensor(flat, dtype=torch.long)] = torch.arange(len(flat))
+    return inv.to(device) if device is not None else inv
+
+
+ENCODE_COST_POINTS = 1024   # what one instance costs beyond its FPS pass, in points: the encoder works on 1024 sampled points whatever the cloud's size
+
+
 def broadcast_weights(module, src=0):
     """Broadcast every parameter of `module` from rank `src` as ONE flat fp32 buffer (one collective, not 78)."""
     if not (dist.is_available() and dist.is_initialized()):
@@ -143,25 +176,34 @@ def sharded_encode(model, x_all):
     return all_gather_codes(emb, counts)
 
 
-def sharded_encode_fps(model, clouds):
+def sharded_encode_fps(model, clouds, balance=True):
     """Shape_Prior.encode_fps over a LIST of raw clouds [Ni,3] (the flat (scene, instance) list of SURVEY 8e): every rank samples and
-    encodes its block (one ragged FPS launch + one encoder batch per rank), the codes are all-gathered.  Same list on every rank."""
+    encodes its share (one ragged FPS launch + one encoder batch per rank), the codes are all-gathered and returned in list order.  Same
+    list on every rank.  balance=True: the share is cost-balanced (balanced_assignment on P_i + ENCODE_COST_POINTS: the ragged FPS costs ~P per
+    cloud) instead of equal counts; equal-size clouds keep the block partition."""
     rank, ws = world()
     n = len(clouds)
-    lo, hi = shard_range(n, rank, ws)
     dev = clouds[0].device
-    if hi > lo:
-        mine = clouds[lo:hi]
+    if balance:
+        assign = balanced_assignment([c.shape[0] + ENCODE_COST_POINTS for c in clouds], ws)
+    else:
+        assign = [list(range(*shard_range(n, r, ws))) for r in range(ws)]
+    mine = [clouds[i] for i in assign[rank]]
+    if mine:
         mx = max(c.shape[0] for c in mine)
-        buf = torch.zeros(hi - lo, 3, mx, device=dev)
-        mask = torch.zeros(hi - lo, 1, mx, dtype=torch.bool, device=dev)
+        buf = torch.zeros(len(mine), 3, mx, device=dev)
+        mask = torch.zeros(len(mine), 1, mx, dtype=torch.bool, device=dev)
         for i, c in enumerate(mine):
             buf[i, :, : c.shape[0]] = c.T
             mask[i, :, : c.shape[0]] = True
         emb = model.encode_fps(buf, mask)
     else:
         emb = empty_codes(model.encoder.c_dim, dev)
-    return all_gather_codes(emb, shard_counts(n, ws))
+    allc = all_gather_codes(emb, [len(a) for a in assign])
+    if all(a == list(range(*shard_range(n, r, ws))) for r, a in enumerate(assign)):
+        return allc
+    inv = assignment_restore(assign, allc["z_inv"].device)
+    return {k: v[inv] for k, v in allc.items()}
 
 
 def sharded_pairs(n_pairs, register_block):

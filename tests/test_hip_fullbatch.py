@@ -201,6 +201,14 @@ def test_bench_gpus_2_runs_two_ranks():
     assert abs(line["value"] - 2 * 64 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
     assert line["ms_per_step"] >= max(r["ms_per_step"] for r in line["per_rank"]) - 1e-3      # MAX over ranks, never the mean
     assert line["check"]["handles_bit_identical"].startswith("True") and line["check"]["rotations_proper"]
+    # each rank pinned to its own cores (livingscenes_amd/launch.py: bind_rank), and the line shows a host-bound rank: max-over-ranks enqueue time
+    from livingscenes_amd import launch
+    cpu_sets = [set(launch.parse_cpulist(r["cpus"])) for r in line["per_rank"]]
+    assert all(cpu_sets), line["per_rank"]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert not (cpu_sets[0] & cpu_sets[1]), line["per_rank"]
+    assert line["config"]["host_enqueue_basis"] == "max over ranks"
+    assert abs(line["config"]["host_enqueue_ms_per_step"] - max(r["host_enqueue_ms_per_step"] for r in line["per_rank"])) < 2e-3
     # one rank, RCCL initialised (the "nccl" backend with a single rank: the only RCCL leg a one-GPU box can run)
     env1 = dict(env, LS_BENCH_FORCE_DIST="1")
     env1.pop("LS_BENCH_BACKEND")

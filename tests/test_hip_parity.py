@@ -467,6 +467,24 @@ def test_encoder_forward_vs_oracle(which, B, N):
     assert relerr(hs, scale) < TOL and relerr(ht, center.squeeze(1)) < TOL
 
 
+def test_encoder_b3_equals_the_reference_per_instance(golden):
+    """The B = 3 decision pinned by the REFERENCE (tests/golden/encoder_b3.npz, make_golden_b3.py): ls_encode on a batch of exactly three instances
+    equals the reference's VecDGCNN_att.forward run on the three instances one at a time (vec_dgcnn_atten.py:157 crosses over the batch axis at
+    B = 3; the build never does): FPS and layer-0 k-NN identical, codes within TOL."""
+    g = golden("encoder_b3")
+    cfg = synth.small_encoder_cfg()
+    m = _hip_model(cfg, synth.make_encoder_weights(cfg, 7))
+    hz, hi, hs, ht, knn_l, fps_l = m.encode(torch.from_numpy(g["x"]).to(_dev()), pre_normalised=True, trace=True)
+    for b in range(3):
+        assert np.array_equal(knn_l[0][b:b + 1].cpu().numpy(), g[f"single{b}_knn_idx_0"])
+        assert np.array_equal(fps_l[0][b:b + 1].cpu().numpy(), g[f"single{b}_fps_idx_0"])
+        for i in range(1, cfg["num_layers"]):
+            assert (knn_l[i][b:b + 1].cpu().numpy() == g[f"single{b}_knn_idx_{i}"]).mean() > 0.995
+    assert relerr(hz, g["single_z_so3"]) < TOL and relerr(hi, g["single_z_inv"]) < TOL
+    assert relerr(hs, g["single_scale"]) < TOL and relerr(ht, g["single_center"].reshape(3, 3)) < TOL
+    assert relerr(hz, g["batched_z_so3"]) > 0.1          # ... and not the reference's batched B = 3 result
+
+
 def test_shape_prior_encode_vs_golden(golden):
     """Shape_Prior.encode end to end against the fixture produced by the reference's own model_utils.Shape_Prior."""
     g = golden("shape_prior_full")

@@ -797,6 +797,79 @@ def test_sharded_encode_world_size_2_on_one_device(tmp_path):
         assert p.returncode == 0 and f"rank {r} ok" in out, err[-3000:]
 
 
+_SHARD_SKEW_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from livingscenes_amd import sharding, synth
+from livingscenes_amd.model_utils import Shape_Prior
+ws = int(sys.argv[3])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%d" %% int(sys.argv[1]), rank=int(sys.argv[2]), world_size=ws)
+rank = dist.get_rank()
+dev = torch.device("cuda:0")
+ecfg, dcfg = synth.small_encoder_cfg(), synth.small_decoder_cfg()
+sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 4), synth.make_decoder_weights(dcfg, 4), device=dev, n_pcl=128)
+# deliberately skewed raw clouds (configs[3]: 1 k - 60 k points per 3RScan instance), the big ones FIRST: the block partition would hand
+# rank 0 almost everything
+rng = np.random.default_rng(7)
+sizes = sorted(np.exp(rng.uniform(np.log(300.0), np.log(20000.0), 36)).astype(int).tolist(), reverse=True)
+g = torch.Generator().manual_seed(3)
+clouds = [torch.randn(n, 3, generator=g).to(dev) for n in sizes]
+seen = []
+enc = sp.encode_fps
+def spy(pc, mask):
+    seen.append(int(mask.sum()))
+    return enc(pc, mask)
+sp.encode_fps = spy
+codes = sharding.sharded_encode_fps(sp, clouds)
+sp.encode_fps = enc
+mine = torch.tensor([float(sum(seen))])
+tot = [torch.zeros(1) for _ in range(ws)]
+dist.all_gather(tot, mine)
+tot = [float(t) for t in tot]
+assert abs(sum(tot) - sum(sizes)) < 0.5, (tot, sum(sizes))
+mean = sum(tot) / ws
+assert max(tot) <= 1.1 * mean and min(tot) >= 0.9 * mean, ("per-rank point totals", tot)
+block = [sum(sizes[i] for i in range(*sharding.shard_range(len(sizes), r, ws))) for r in range(ws)]
+assert max(block) > 1.5 * mean                     # the partition this replaces was that bad on this list
+# list order restored, every code equal to the unsharded encode of the same cloud (a row's code does not depend on the batch it rides in)
+mx = max(sizes)
+buf = torch.zeros(len(sizes), 3, mx, device=dev)
+mask = torch.zeros(len(sizes), 1, mx, dtype=torch.bool, device=dev)
+for i, c in enumerate(clouds):
+    buf[i, :, : c.shape[0]] = c.T
+    mask[i, :, : c.shape[0]] = True
+whole = sp.encode_fps(buf, mask)
+for k in ("z_so3", "z_inv", "s", "t"):
+    assert torch.equal(codes[k], whole[k]), k
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_encode_fps_balances_skewed_clouds_world_size_3_on_one_device(tmp_path):
+    """SURVEY 8(e), configs[3]: three processes (gloo, all on cuda:0) share a list of 36 raw clouds of 300 - 20 000 points, largest first.
+    sharded_encode_fps hands them out by cost (sharding.balanced_assignment): every rank's point total within 10 % of the mean (the block
+    partition would give rank 0 more than 1.5x), the codes come back in list order and equal the unsharded encode bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "skew_worker.py"
+    script.write_text(_SHARD_SKEW_WORKER % os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(port), str(r), "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(3)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"rank {r} ok" in out, err[-3000:]
+
+
 _SHARD_E2E_WORKER = r"""
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)

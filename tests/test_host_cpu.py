@@ -177,6 +177,62 @@ def test_dropin_registers_reference_import_names():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_balanced_assignment_evens_out_skewed_costs():
+    """sharding.balanced_assignment (SURVEY 8e, configs[3]: 3RScan clouds of 1 k - 60 k raw points, FPS cost ~ P): a partition (every item once),
+    identical on every rank, equal costs -> the block partition, skewed costs -> per-rank totals within 10 %% of the mean once a rank holds several
+    items; the restore index undoes the rank-order concatenation."""
+    import numpy as np
+    import torch
+    from livingscenes_amd import sharding
+    for n, ws in ((0, 3), (5, 8), (64, 8), (7, 2)):
+        a = sharding.balanced_assignment([1024] * n, ws)
+        assert a == [list(range(*sharding.shard_range(n, r, ws))) for r in range(ws)]
+    rng = np.random.default_rng(0)
+    for ws in (2, 3, 8):
+        costs = np.exp(rng.uniform(np.log(1e3), np.log(6e4), 40 * ws)).astype(int).tolist()       # log-uniform 1 k .. 60 k
+        a = sharding.balanced_assignment(costs, ws)
+        assert sorted(i for part in a for i in part) == list(range(len(costs))) and all(part == sorted(part) for part in a)
+        assert a == sharding.balanced_assignment(list(costs), ws)
+        loads = [sum(costs[i] for i in part) for part in a]
+        assert max(loads) <= 1.1 * (sum(costs) / ws) and min(loads) >= 0.9 * (sum(costs) / ws), loads
+        block = [sum(costs[i] for i in range(*sharding.shard_range(len(costs), r, ws))) for r in range(ws)]
+        assert max(loads) <= max(block)
+        inv = sharding.assignment_restore(a)
+        flat = torch.tensor([i for part in a for i in part])
+        assert torch.equal(flat[inv], torch.arange(len(costs)))
+    # one dominant item: nothing can balance it, but nothing else rides with it
+    a = sharding.balanced_assignment([60000, 1000, 1000, 1000, 1000], 2)
+    assert a == [[0], [1, 2, 3, 4]]
+
+
+def test_launcher_world_and_rank_cpu_sets(monkeypatch):
+    """launch.py: WORLD_SIZE=1 alone is not a launcher; no --gpus adopts the launcher's world; an explicit mismatch is refused; the per-rank CPU
+    sets are disjoint, follow the GPU's NUMA node, keep SMT siblings together and fall back to an even split where the node is unknown."""
+    from livingscenes_amd import launch
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR"):
+        monkeypatch.delenv(k, raising=False)
+    assert launch.launcher_world() is None and launch.ensure_ranks(None, "x.py", []) == (1, 0, 0)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert launch.launcher_world() is None and launch.ensure_ranks(1, "x.py", []) == (1, 0, 0)
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("LOCAL_RANK", "3")
+    assert launch.ensure_ranks(None, "x.py", []) == (8, 3, 3) and launch.ensure_ranks(8, "x.py", []) == (8, 3, 3)
+    with pytest.raises(SystemExit):
+        launch.ensure_ranks(4, "x.py", [])
+    assert launch.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and launch.format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    core_of = {c: c % 128 for c in range(256)}
+    sets = [launch.rank_cpus(r, 8, nodes, range(256), node_cpus, core_of) for r in range(8)]
+    assert all(len(s) == 32 for s in sets) and len(set().union(*map(set, sets))) == 256
+    assert all(set(sets[r]) <= set(node_cpus[nodes[r]]) for r in range(8))
+    assert all({core_of[c] for c in s} == {c for c in s if c < 128} for s in sets)              # both hardware threads of a core with one rank
+    loose = [launch.rank_cpus(r, 3, [None, None, None], range(12), {}) for r in range(3)]
+    assert loose == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]]
+    mixed = [launch.rank_cpus(r, 3, [0, None, 0], range(8), {0: [0, 1, 2, 3]}) for r in range(3)]
+    assert mixed == [[0, 1], [4, 5, 6, 7], [2, 3]]
+    assert launch.bind_rank(0, 1) == sorted(__import__("os").sched_getaffinity(0))
+
+
 def test_shard_range_partitions():
     from livingscenes_amd import sharding
     for n in (0, 1, 7, 64, 65):
@@ -310,9 +366,10 @@ solver = _Solver()
 want = more_solver.solve_end2end_batch(solver, pairs)
 calls0, regs0 = _Model.calls, _Solver.regs
 got = more_solver.solve_end2end_batch(solver, pairs, sharded=True)
-n_inst = sum(p[0]["pc"].shape[0] + p[1]["pc"].shape[0] for p in pairs)
-lo, hi = sharding.shard_range(n_inst)
-assert _Model.calls - calls0 == hi - lo, "each rank encodes only its block of the flat instance list"
+sizes = [int(sc["pc_mask"][i].sum()) for p in pairs for sc in p for i in range(sc["pc"].shape[0])]      # the flat (scene, instance) list
+assign = sharding.balanced_assignment([n + sharding.ENCODE_COST_POINTS for n in sizes], ws)
+assert sorted(i for a in assign for i in a) == list(range(len(sizes)))
+assert _Model.calls - calls0 == len(assign[rank]), "each rank encodes only its (cost-balanced) share of the flat instance list"
 n_pairs = sum(int((w["matches"] >= 0).sum()) for w in want)
 plo, phi = sharding.shard_range(n_pairs)
 assert _Solver.regs - regs0 == phi - plo, "each rank registers only its block of the matched pairs"

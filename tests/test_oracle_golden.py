@@ -80,6 +80,26 @@ def test_encoder_small_trace(golden):
     close(z_inv, g["z_inv"], what="z_inv")
 
 
+def test_b3_fixture_pins_the_cross_product_axis(golden):
+    """tests/golden/encoder_b3.npz (make_golden_b3.py): the reference's get_graph_feature calls torch.cross without a dim
+    (vec_dgcnn_atten.py:157) -- over xyz for every batch size except B = 3, where the first axis of size 3 is the BATCH axis.  The oracle (and the
+    HIP path) always cross over xyz: at B = 3 they must equal the reference run on the three instances ONE AT A TIME, and the reference's own
+    batched B = 3 result is on record as different (it mixes the instances)."""
+    g = golden("encoder_b3")
+    cfg = synth.small_encoder_cfg()
+    w = synth.make_encoder_weights(cfg, seed=7)
+    tr = {}
+    center, scale, z_so3, z_inv = net.encoder_forward(w, cfg, T(g["x"]), trace=tr)
+    for b in range(3):
+        for i in range(cfg["num_layers"]):
+            assert np.array_equal(tr[f"knn_idx_{i}"][b:b + 1].numpy(), g[f"single{b}_knn_idx_{i}"]), f"instance {b} knn layer {i}"
+        assert np.array_equal(tr["fps_idx_2"][b:b + 1].numpy(), g[f"single{b}_fps_idx_0"])
+    for name, v in (("center", center), ("scale", scale), ("z_so3", z_so3), ("z_inv", z_inv)):
+        close(v, g["single_" + name], what="B=3 vs the reference per instance: " + name)
+        a, b = np.asarray(g["single_" + name], np.float64), np.asarray(g["batched_" + name], np.float64)
+        assert np.abs(a - b).max() / np.abs(a).max() > 0.1, f"the reference's batched B=3 {name} was expected to differ (torch.cross over the batch axis)"
+
+
 def test_shape_prior_full_and_decoder(golden):
     g = golden("shape_prior_full")
     ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
