@@ -1181,6 +1181,320 @@ __global__ __launch_bounds__(256, KO_WPS) void knn_finish_select_kernel(const fl
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FUSED build (round 5): image -> ONE kernel.  The seeded path above is five launches (image, seed, sweep, finish) that hand seed keys
+// (u64 [B Nd][16]), survivor lists (u16 [B Nd][256]) and counters to each other through HBM -- 150 MB moved per layer-1 call for 54 MB of
+// compulsory traffic, three launch boundaries, and 16 hint distances per query whose only use is a threshold.  The one-sweep path needs no
+// hints but stores a cosine per pair (128 MB at Ns = 1024).  Here a workgroup of eight waves owns 32 queries of one instance and does
+// everything on chip:
+//   1. sweep      wave w takes the candidate tiles w, w + 8, ...: S = q'.s' on the f16 matrix cores into REGISTERS (TPW x 16 per lane), then in
+//                 place  lo = d^ - eps nn  with  d^ = |q'|^2 + |s'|^2 - 2 S iq ic  (lo <= d_canonical <= hi = d^ + eps nn, the bound of the f16
+//                 sweep: eps_b above, + 2^-21 for the roundings of d^ / lo / hi themselves); every lane keeps the minimum of hi per query row;
+//   2. threshold  the minima of the 8 x 32 (wave, column class) groups of a row are folded into 64 LDS slots by atomic-min (disjoint candidate
+//                 groups stay disjoint); T = an upper bound of the K-th smallest slot (knn_common.h) -- at least K candidates have a canonical
+//                 distance <= T, so T bounds the K-th canonical distance from above;
+//   3. filter     a candidate survives iff !(lo > T) (a candidate of the true top K has d_canonical <= K-th <= T, hence lo <= T; NaN bounds
+//                 survive): appended to the query's LDS list (~18 of 1024);
+//   4. exact      the workgroup's survivors as ONE flat list of (query, candidate) pairs, 16 per wave step on the quad chains
+//                 (quad_pair_distance: the canonical fp32 chain), query rows out of LDS -- every step is full, whereas one wave per query leaves
+//                 its second step of 16 nearly empty;
+//   5. select     per query the K smallest (distance, index) keys by the 32- / 64-lane network, two queries per wave pass when both fit 32.
+// A query with more than KF_LCAP survivors (duplicates, non-finite rows) is finished by brute force over all candidates: slow, still exact.
+// The lists only ever hold canonical keys and a dropped candidate provably cannot enter them: bit-identical to the oracle by construction.
+// Hints are not used at all (they never influenced results).
+constexpr int KF_QT = 32;        // queries per workgroup (one 32-row MFMA operand)
+constexpr int KF_WAVES = 8;
+constexpr int KF_LCAP = 64;      // survivors per query that go through the flat exact phase (one 64-lane sorting pass)
+constexpr int KF_MAXNS = KF_WAVES * 4 * 32;   // at most four tiles per wave
+
+template <int CC>
+struct KfLds {
+    float qrows[KF_QT][3 * CC];          // the workgroup's query rows (fp32, x-major as in global memory)
+    float2 qn[KF_QT];                    // {|q'|^2, -2 iq} per query row (padding queries: {0, 0})
+    unsigned hm[KF_QT][64];              // group minima of hi (bit patterns of non-negative floats)
+    float T[KF_QT];
+    int cnt[KF_QT];
+    int base[KF_QT + 1];
+    unsigned short list[KF_QT][KF_LCAP];
+    unsigned plist[KF_QT * KF_LCAP];     // flat pair list: candidate | row << 16 | slot << 21
+    u64 keys[KF_QT][KF_LCAP];
+};
+
+// brute force of one query by one wave: every candidate's canonical key, 48 per pass, merged with the best 16 so far
+template <int CC, bool FMA>
+__device__ __noinline__ u64 kf_brute_row(const float* __restrict__ qrow, const float* __restrict__ sbase, int Ns, int lane) {
+    constexpr int RF = 3 * CC;
+    const int quad = lane >> 2;
+    const bool qlast = (lane & 3) == 3;
+    QuadRow<CC> qv;
+    qv.load(qrow, lane);
+    u64 best = ~0ull;
+    for (int base = 0; base < Ns; base += 48) {
+        u64 ks[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = base + u * 16 + quad;
+            const bool v = c < Ns;
+            ks[u] = make_key(quad_pair_distance<CC, FMA>(qv, qrow, sbase + (size_t)(v ? c : 0) * RF, lane), c, v & qlast);
+        }
+        const int src = ((lane & 15) << 2) + 3;
+        const u64 n0 = bperm64(src, ks[0]), n1 = bperm64(src, ks[1]), n2 = bperm64(src, ks[2]);
+        u64 k = lane < 16 ? best : (lane < 32 ? n0 : (lane < 48 ? n1 : n2));
+        LS_SORT64(cx64, k, lane)
+        best = k;
+    }
+    return best;     // lanes 0 .. 15: the 16 smallest keys, ascending
+}
+
+#ifndef LS_KF_WPE
+#define LS_KF_WPE 4      // waves per SIMD the kernel is compiled for (dev A/B: scripts/dev/build_variants.py)
+#endif
+template <int CC, bool FMA, int TPW>
+__global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE) void knn_fused_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf, const int32_t* __restrict__ dst_rows,
+                                                                  const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
+                                                                  const float* __restrict__ nrm_dst, const float* __restrict__ nrm_src,
+                                                                  const float* __restrict__ isc_dst, const float* __restrict__ isc_src, int Nd, int dst_n,
+                                                                  int dst_npad, int Ns, int ns_pad, int K, int qtiles, float eps,
+                                                                  int32_t* __restrict__ idx_out, float* __restrict__ dist_out, int32_t* __restrict__ surv_cnt) {
+    constexpr int D = 3 * CC, KK = D / 16, RF = 3 * CC;
+    __shared__ __attribute__((aligned(16))) KfLds<CC> L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);          // the query tiles of one instance share an XCD's L2 (its image and rows)
+    const int b = logical / qtiles, q0 = (logical - b * qtiles) * KF_QT;
+    const unsigned short* dqb = dq + (size_t)b * dst_npad * D;
+    const unsigned short* sqb = sq + (size_t)b * ns_pad * D;
+    const float* sbase = srcf + (size_t)b * Ns * RF;
+    const float* dbase = dstf + (size_t)b * dst_n * RF;
+    const int ntiles = ns_pad >> 5;
+
+    // ---- 0. the query rows (fp32) into LDS, their norms / scales, the LDS state
+    for (int i = tid; i < KF_QT * (RF / 4); i += 64 * KF_WAVES) {
+        const int qr = i / (RF / 4), c4 = i - qr * (RF / 4);
+        const int q = min(q0 + qr, Nd - 1);
+        const int r = dst_rows ? dst_rows[(size_t)b * Nd + q] : q;
+        *reinterpret_cast<float4*>(&L.qrows[qr][c4 * 4]) = *reinterpret_cast<const float4*>(dbase + (size_t)r * RF + c4 * 4);
+    }
+    if (tid < KF_QT) {
+        const int q = q0 + tid;
+        const int r = q < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + q] : q) : 0;
+        const float nq = nrm_dst[(size_t)b * dst_n + r], iq = isc_dst[(size_t)b * dst_n + r];
+        L.qn[tid] = q < Nd ? make_float2(nq, -2.0f * iq) : make_float2(0.f, 0.f);
+        L.cnt[tid] = 0;
+    }
+    for (int i = tid; i < KF_QT * 64; i += 64 * KF_WAVES) (&L.hm[0][0])[i] = 0x7F800000u;
+
+    // ---- 1. sweep: this wave's tiles, S in registers
+    f16x8k a[KK];
+    {
+        const int qi = q0 + l31;
+        const int r = qi < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + qi] : qi) : 0;
+        const unsigned short* ap = dqb + ((size_t)(r >> 5) * KK * 64 + lh * 32 + (r & 31)) * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(ap + (size_t)kk * 512));
+    }
+    f32x16 S[TPW];
+    float cns[TPW], cic[TPW];          // the tile's column: |s'|^2 and its inverse image scale (this lane's candidate)
+    {
+        f16x8k bf[2][KK];
+        auto load_b = [&](int t, f16x8k (&dstb)[KK]) {
+            const int tg = min(wave + KF_WAVES * t, ntiles - 1);
+            const unsigned short* bp = sqb + ((size_t)tg * KK * 64 + lane) * 8;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) dstb[kk] = __builtin_bit_cast(f16x8k, *reinterpret_cast<const uint4*>(bp + (size_t)kk * 512));
+        };
+        load_b(0, bf[0]);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            if (t + 1 < TPW) load_b(t + 1, bf[(t + 1) & 1]);
+            const int cg = min((wave + KF_WAVES * t) * 32 + l31, Ns - 1);
+            cns[t] = nrm_src[(size_t)b * Ns + cg];
+            cic[t] = isc_src[(size_t)b * Ns + cg];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[t][r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], bf[t & 1][kk], S[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();     // qn, hm, cnt are initialised
+    // bounds in place: S := lo; per row the minimum of hi over this lane's columns, folded straight into the row's LDS slot (step 2).  Rows outside,
+    // tiles inside: a row's {|q'|^2, -2 iq} is one broadcast LDS read, nothing but S stays live across rows.  (fminf ignores a NaN operand: a NaN
+    // bound never wins the minimum; its candidate survives the filter below.)  Padding columns (candidate >= Ns) and padding tiles contribute nothing.
+    bool colv[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) colv[t] = (wave + KF_WAVES * t) < ntiles && (wave + KF_WAVES * t) * 32 + l31 < Ns;
+    {
+        const int slot = (wave & 1) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float2 qn = L.qn[qr];
+            float hmin = INFINITY;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const float nn = qn.x + cns[t], w = qn.y * cic[t];
+                const float dh = __builtin_fmaf(S[t][r], w, nn), e = eps * nn;
+                hmin = colv[t] ? fminf(hmin, dh + e) : hmin;
+                float lo = dh - e;
+                asm volatile("" : "+v"(lo));      // (materialised HERE: left free, the optimiser sinks the subtraction into the filter and keeps dh AND nn alive instead -- two registers per pair)
+                S[t][r] = lo;
+            }
+            // ---- 2. threshold: (non-negative floats order like their bit patterns; +inf = "no candidate")
+            const float h = fmaxf(hmin, 0.0f);
+            if (h < INFINITY) atomicMin(&L.hm[qr][slot], __float_as_uint(h));
+#ifndef LS_KF_NOSB
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four rows' LDS reads in flight at a time: hoisted all sixteen, they cost 32 registers beside S)
+#endif
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < KF_QT / KF_WAVES; ++u) {
+        const int qr = wave * (KF_QT / KF_WAVES) + u;
+        const unsigned tb = kth_smallest_upper_bound(L.hm[qr][lane], K < 64 ? K : 64);
+        if (lane == 0) L.T[qr] = __uint_as_float(tb);
+    }
+    __syncthreads();
+    // ---- 3. filter
+    {
+        unsigned mask[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) mask[t] = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float Tr = L.T[(r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) mask[t] |= (S[t][r] > Tr) ? 0u : (1u << r);
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int cg = (wave + KF_WAVES * t) * 32 + l31;
+            unsigned m = colv[t] ? mask[t] : 0u;
+            while (m) {
+                const int r = __builtin_ctz(m);
+                m &= m - 1;
+                const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (q0 + qr < Nd) {
+                    const int pos = atomicAdd(&L.cnt[qr], 1);
+                    if (pos < KF_LCAP) L.list[qr][pos] = (unsigned short)cg;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 4. the flat pair list (queries that overflowed their list are left to the brute-force pass of step 5)
+    if (wave == 0) {
+        const int c = (lane < KF_QT && L.cnt[lane] <= KF_LCAP) ? L.cnt[lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < KF_QT; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            incl += lane >= o ? v : 0;
+        }
+        if (lane < KF_QT) L.base[lane] = incl - c;
+        if (lane == KF_QT - 1) L.base[KF_QT] = incl;
+        if (lane < KF_QT && q0 + lane < Nd && surv_cnt) surv_cnt[(size_t)b * Nd + q0 + lane] = -(L.cnt[lane] > KF_LCAP ? Ns : L.cnt[lane]) - 1;   // statistic (knn_stats_kernel)
+    }
+    __syncthreads();
+    for (int i = tid; i < KF_QT * KF_LCAP; i += 64 * KF_WAVES) {
+        const int qr = i / KF_LCAP, j = i - qr * KF_LCAP;
+        const int c = L.cnt[qr];
+        if (c <= KF_LCAP && j < c) L.plist[L.base[qr] + j] = (unsigned)L.list[qr][j] | ((unsigned)qr << 16) | ((unsigned)j << 21);
+    }
+    __syncthreads();
+    {
+        // Two pairs in flight per quad: the candidate row of step s + 1 is requested before the chain of step s runs (a step is ~2 us of L2
+        // gather latency in front of ~600 cycles of dependent adds; a workgroup has ~5 steps).
+        const int P = L.base[KF_QT];
+        const int Q = wave * 16 + (lane >> 2);
+        const bool qlast = (lane & 3) == 3;
+        struct Pair { unsigned ent; bool v; QuadRow<CC> c; };
+        auto fetch = [&](int p0, Pair& pr) {
+            const int p = p0 + Q;
+            pr.v = p < P;
+            pr.ent = L.plist[pr.v ? p : 0];
+            pr.c.load(sbase + (size_t)(pr.ent & 0xFFFFu) * RF, lane, 0);
+        };
+        auto finish = [&](const Pair& pr) {
+            const int cand = pr.ent & 0xFFFFu, qr = (pr.ent >> 16) & 31, slot = pr.ent >> 21;
+            const float* qrow = &L.qrows[qr][0];
+            QuadRow<CC> qv;
+            qv.load(qrow, lane);
+            float d;
+            if constexpr (CC == 32) {
+                d = quad_round<CC, FMA, true>(0.0f, qv, pr.c);
+            } else {
+                const float* crow = sbase + (size_t)cand * RF;
+                d = quad_round<CC, FMA, false>(0.0f, qv, pr.c);
+#pragma unroll
+                for (int r = 1; r < CC / 32; ++r) {
+                    QuadRow<CC> q, c;
+                    q.load(qrow, lane, r);
+                    c.load(crow, lane, r);
+                    d = (r == CC / 32 - 1) ? quad_round<CC, FMA, true>(d, q, c) : quad_round<CC, FMA, false>(d, q, c);
+                }
+            }
+            if (pr.v && qlast) L.keys[qr][slot] = make_key(d, cand, true);
+        };
+#ifdef LS_KF_NOPIPE      // dev A/B: one pair per quad at a time
+        for (int p0 = 0; p0 < P; p0 += 16 * KF_WAVES) { Pair pa; fetch(p0, pa); finish(pa); }
+        if (false) {
+#else
+        if (P > 0) {
+#endif
+            Pair pa, pb;
+            fetch(0, pa);
+            for (int p0 = 0; p0 < P; p0 += 2 * 16 * KF_WAVES) {
+                fetch(p0 + 16 * KF_WAVES, pb);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(pa);
+                if (p0 + 16 * KF_WAVES < P) {       // (uniform)
+                    fetch(p0 + 2 * 16 * KF_WAVES, pa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(pb);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 5. select: this wave's four queries, two per pass when both lists fit 32 lanes
+    auto emit = [&](int qr, u64 k, int e) {
+        const int q = q0 + qr;
+        if (q < Nd && e < K) {
+            const size_t o = ((size_t)b * Nd + q) * K + e;
+            const unsigned hi = (unsigned)(k >> 32), lw = (unsigned)k;
+            idx_out[o] = hi == 0xFFFFFFFFu ? -1 : (int)lw;
+            if (dist_out) dist_out[o] = hi == 0xFFFFFFFFu ? INFINITY : __uint_as_float(hi);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < KF_QT / KF_WAVES; u += 2) {
+        const int qa = wave * (KF_QT / KF_WAVES) + u, qb = qa + 1;
+        const int ca = L.cnt[qa], cb = L.cnt[qb];
+        if (ca <= 32 && cb <= 32) {
+            const int qr = lh ? qb : qa, c = lh ? cb : ca;
+            u64 k = l31 < c ? L.keys[qr][l31] : ~0ull;
+            LS_SORT32(cx64, k, lane)
+            emit(qr, k, l31);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qr = h ? qb : qa, c = h ? cb : ca;
+                u64 k;
+                if (c <= KF_LCAP) {
+                    k = lane < c ? L.keys[qr][lane] : ~0ull;
+                    LS_SORT64(cx64, k, lane)
+                } else {
+                    k = q0 + qr < Nd ? kf_brute_row<CC, FMA>(&L.qrows[qr][0], sbase, Ns, lane) : ~0ull;
+                }
+                emit(qr, k, lane);
+            }
+        }
+    }
+}
+
 static inline size_t pad32(size_t n) { return (n + 31) & ~(size_t)31; }
 static bool knn_sweep_f16_enabled() {
     static const bool off = getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0;   // A/B: fp32 sweep kernel
@@ -1261,6 +1575,17 @@ static int knn_sweep_launch_t(const float* dst, const float* src, const int32_t*
         if (dst != src) {   // same centre for both sets: the candidates' first rows
             rc = knn_prep_launch(dst, src, Ns, B, dst_n, dst_npad, D, dq, ndst, idst, (int32_t*)nullptr, 0LL, st);
             if (rc != LS_OK) return rc;
+        }
+        static const bool fused_on = !(getenv("LS_KNN_FUSED") && atoi(getenv("LS_KNN_FUSED")) == 0);   // A/B: the multi-launch paths below
+        if (fused_on && ns_pad <= KF_MAXNS && K <= 16 && Ns >= 1) {   // one kernel per (instance, 32 queries): see knn_fused_kernel   // one kernel per (instance, 32 queries): see knn_fused_kernel
+            const int qtiles = cdiv(Nd, KF_QT), tpw = cdiv(ns_pad / 32, KF_WAVES);
+            const float epsF = 1.02f * 0.0009765625f + 6.0f * (float)(D + 4) * 5.9604645e-8f + 9.5367431640625e-7f + 4.76837158203125e-7f;   // eps_b of the f16 sweep + 2^-21 (d^, lo, hi)
+#define LS_KF(T) do { if (fma) hipLaunchKernelGGL((knn_fused_kernel<CC, true, T>), dim3(B * qtiles), dim3(64 * KF_WAVES), 0, st, dst, src, dst_rows, dq, sq, ndst, nsrc, idst, isrc, Nd, dst_n, dst_npad, Ns, ns_pad, K, qtiles, epsF, idx_out, dist_out, surv_cnt); \
+                   else hipLaunchKernelGGL((knn_fused_kernel<CC, false, T>), dim3(B * qtiles), dim3(64 * KF_WAVES), 0, st, dst, src, dst_rows, dq, sq, ndst, nsrc, idst, isrc, Nd, dst_n, dst_npad, Ns, ns_pad, K, qtiles, epsF, idx_out, dist_out, surv_cnt); } while (0)
+            if (tpw <= 1) LS_KF(1); else if (tpw == 2) LS_KF(2); else LS_KF(4);
+#undef LS_KF
+            LS_LAUNCH_CHECK();
+            return LS_OK;
         }
         static const bool one_sweep_on = !(getenv("LS_KNN_ONE_SWEEP") && atoi(getenv("LS_KNN_ONE_SWEEP")) == 0);   // A/B: the two-sweep auto-hint path
         if (!seed_idx && one_sweep_on && ns_pad <= KO_MAXNS && K <= 16) {   // un-seeded, few candidates: one sweep + one finish (see above)
