@@ -469,7 +469,9 @@ def main():
         if dom["kind"] == "knn":
             roof["note"] = ("one k-NN graph build = the launch sequence of that layer (seeded layers 1 / 2: f16 image incl. centre, seed, sweep, finish = 4 - 5 launches; un-seeded layers 3 / 4: image, sweep, finish = 3); "
                             "bound by fp32 VALU issue on the direct-difference-equivalent count -- see `basis`")
-        seeded_layers = {i for i, L in enumerate(layer_plan(ecfg, N)) if i >= 1 and L["Cin"] == 32}   # model.hip: the previous layer's lists seed the C = 32 layers
+        # the fused k-NN kernel (knn_mfma.hip: knn_fused_kernel, round 5) uses no hints: every exact distance is a survivor's, counted on the device.
+        # LS_KNN_FUSED=0 (dev A/B): the multi-launch paths, where the previous layer's lists seed the C = 32 layers (16 more exact distances per query)
+        seeded_layers = ({i for i, L in enumerate(layer_plan(ecfg, N)) if i >= 1 and L["Cin"] == 32} if os.environ.get("LS_KNN_FUSED") == "0" else set())
 
         def with_hw(e, q):
             if q["kind"] == "knn" and q["layer"] in knn_stats and knn_stats[q["layer"]][1]:

@@ -1247,11 +1247,13 @@ __device__ __noinline__ u64 kf_brute_row(const float* __restrict__ qrow, const f
     return best;     // lanes 0 .. 15: the 16 smallest keys, ascending
 }
 
+// Compiled for four waves per SIMD = two workgroups per CU (116 - 128 registers, no spills).  Measured (round 5): one workgroup per CU by LDS padding
+// 151 / 81 us at layers 1 / 2 against 110 / 71 us.
 #ifndef LS_KF_WPE
-#define LS_KF_WPE 4      // waves per SIMD the kernel is compiled for (dev A/B: scripts/dev/build_variants.py)
+#define LS_KF_WPE(TPW) 4
 #endif
 template <int CC, bool FMA, int TPW>
-__global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE) void knn_fused_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf, const int32_t* __restrict__ dst_rows,
+__global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW)) void knn_fused_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf, const int32_t* __restrict__ dst_rows,
                                                                   const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
                                                                   const float* __restrict__ nrm_dst, const float* __restrict__ nrm_src,
                                                                   const float* __restrict__ isc_dst, const float* __restrict__ isc_src, int Nd, int dst_n,
