@@ -94,10 +94,10 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
     down = Nd != Ns   # neighbour-side columns on the Ns source points, destination-side columns on the Nd selected points
     # attention layers with C_out in {64, 128} compute the destination side inside the edge kernel (edge.hip, edge_attn_fq_kernel): the
     # table holds the neighbour-side columns only; the edge kernel reads the destination points' feature rows + the weights instead
-    fused = L["attn"] and os.environ.get("LS_EDGE_FUSE_Q", "1") != "0" and ((Co == 64 and Cin in (32, 64)) or (Co == 128 and Cin == 64))
+    fused = L["attn"] and bf16x3 and os.environ.get("LS_GEMM_MODE") is None and ((Co == 64 and Cin in (32, 64)) or (Co == 128 and Cin == 64))
     # attention layers with 32 destination points and 128 / 256 input channels (released layers 5, 6): NO table (csrc/edge_fused.hip) -- "gemm_edge" is
     # the operand image of the feature rows (f16 fragment planes), "edge_attn" forms its table slices in LDS on the matrix cores and consumes them there
-    fused_t = (L["attn"] and bf16x3 and os.environ.get("LS_EDGE_FUSE_T", "1") != "0" and os.environ.get("LS_GEMM_MODE") != "bf16x3" and Nd == 32
+    fused_t = (L["attn"] and bf16x3 and os.environ.get("LS_GEMM_MODE") is None and Nd == 32
                and ((Cin == 128 and Ns == 128 and down) or (Cin == 256 and Ns == 32 and not down)))
     if fused_t and kind == "gemm_edge":
         rows = B * 3 * (Ns + (Nd if down else 0))
@@ -125,7 +125,7 @@ def algorithmic_cost(kind, layer, cfg, B, N, bf16x3=True):
         return B * Ns * 12 + B * Nd * 16 * 4 + B * Nd * 3 * Co * f4, 2.0 * B * Nd * 16 * Co * 40, FP32_PEAK_TFLOPS, "fp32 VALU flops"
     if kind == "gemm_glob":
         # fused with the VN activation (gemm.hip: gemm_vn_kernel) where C_out % 64 == 0: reads f, writes the activated f' (no [rows, 2C] table)
-        glob_fused = Co % 64 == 0 and bf16x3 and os.environ.get("LS_GEMM_MODE") != "bf16x3" and os.environ.get("LS_GLOB_FUSE", "1") != "0"
+        glob_fused = Co % 64 == 0 and bf16x3 and os.environ.get("LS_GEMM_MODE") is None
         return (B * Nd * 3 * (2 if glob_fused else 3) * Co * f4 + 4 * Co * Co * f4, mm_mult * 2.0 * B * Nd * 3 * Co * 2 * Co, mm_peak,
                 mm_what + (" (+ the VN activation in the epilogue)" if glob_fused else ""))
     if kind == "vn_act":
@@ -314,8 +314,6 @@ def main():
     from livingscenes_amd.lib_more.matcher_new import sequential_matcher
     from livingscenes_amd.model_utils import Shape_Prior
 
-    if args.inflight > 1:
-        os.environ.setdefault("LS_GEMM_OVERLAP", "0")
     ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
     if rank == 0:
         ew, dw = synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0)
@@ -325,15 +323,19 @@ def main():
     nfl = max(1, args.inflight)
     if nfl > 1:
         # A/B on MI355X (scripts in DESIGN.md 6): intra-step GEMM||k-NN stream overlap is +5 % for a single in-flight step but
-        # -3.5 % once two whole steps already overlap; the library default stays on, the bench turns it off (before ANY handle is
-        # created: the option is read at ls_model_create).
-        os.environ.setdefault("LS_GEMM_OVERLAP", "0")
+        # -3.5 % once two whole steps already overlap; the library default stays on, the bench turns it off on every handle
+        # (ls_model_set_option(LS_OPT_GEMM_OVERLAP, 0), below)
+        pass
     sp = Shape_Prior.from_state(ecfg, dcfg, ew, dw, device=dev)
     if multi:
         parallel.broadcast_weights(sp, src=0)
     # one model handle (packed weights + side stream + workspace) per in-flight step; weights are shared tensors
     sps = [sp] + [Shape_Prior.from_state(ecfg, dcfg, sp.encoder.state_dict(), sp.decoder.F.state_dict(), device=dev) for _ in range(nfl - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+    if nfl > 1:
+        from livingscenes_amd import _lib as _ls_lib
+        for s_ in sps:
+            s_.hip_model().set_option(_ls_lib.OPT_GEMM_OVERLAP, 0)
 
     B, N = args.batch, args.points
     n_obj = B // 2
@@ -447,7 +449,7 @@ def main():
         assert allc["z_inv"].shape[0] == B * world
 
     roof = None
-    bf16x3 = not (os.environ.get("LS_GEMM_BF16X3") and int(os.environ["LS_GEMM_BF16X3"]) == 0)
+    bf16x3 = os.environ.get("LS_GEMM_MODE") != "fp32"      # (False: exact fp32 MFMA chains, LS_GEMM_MODE=fp32)
     if rank == 0 and not args.no_profile:
         hip = sp.hip_model()
         prof_steps = min(args.steps, 24)      # per-launch hipEvent pairs: a bounded, serial pass on one stream
@@ -469,9 +471,8 @@ def main():
         if dom["kind"] == "knn":
             roof["note"] = ("one k-NN graph build = the launch sequence of that layer (seeded layers 1 / 2: f16 image incl. centre, seed, sweep, finish = 4 - 5 launches; un-seeded layers 3 / 4: image, sweep, finish = 3); "
                             "bound by fp32 VALU issue on the direct-difference-equivalent count -- see `basis`")
-        # the fused k-NN kernel (knn_mfma.hip: knn_fused_kernel, round 5) uses no hints: every exact distance is a survivor's, counted on the device.
-        # LS_KNN_FUSED=0 (dev A/B): the multi-launch paths, where the previous layer's lists seed the C = 32 layers (16 more exact distances per query)
-        seeded_layers = ({i for i, L in enumerate(layer_plan(ecfg, N)) if i >= 1 and L["Cin"] == 32} if os.environ.get("LS_KNN_FUSED") == "0" else set())
+        # the fused k-NN kernel (knn_mfma.hip: knn_fused_kernel, round 5) uses no hints: every exact distance is a survivor's, counted on the device
+        seeded_layers = set()
 
         def with_hw(e, q):
             if q["kind"] == "knn" and q["layer"] in knn_stats and knn_stats[q["layer"]][1]:

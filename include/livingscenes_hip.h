@@ -57,9 +57,10 @@ typedef enum {
 #define LS_MAX_LAYERS 8
 
 /* version of this C ABI: bumped whenever a signature or struct layout changes incompatibly (101: double-precision Adam hyper-parameters in
- * ls_adam_group / ls_adam_step_f32 / ls_se3_adam_step_f32, LS_OPT_EDGE_STAGED).  ls_version() returns the value the LIBRARY was built with; a
+ * ls_adam_group / ls_adam_step_f32 / ls_se3_adam_step_f32, LS_OPT_EDGE_STAGED; 102: LS_OPT_EDGE_FUSE_Q / _T, LS_OPT_GLOB_FUSE, LS_OPT_DEBUG_EDGE; the
+ * library reads no development switches from the environment any more).  ls_version() returns the value the LIBRARY was built with; a
  * binding compares it with the header it was written against and refuses a mismatch (livingscenes_amd/_lib.py: load). */
-#define LS_ABI_VERSION 101
+#define LS_ABI_VERSION 102
 int ls_version(void);
 const char* ls_last_error(void);
 /* number of HIP devices visible, or a negative ls_status */
@@ -246,6 +247,15 @@ void ls_model_destroy(ls_model_t* m);
                                      (edge_staged.hip): 0 = never (row gathers through L1: edge_attn_fq_kernel), 1 = when one workgroup per CU fills the chip
                                      (B * Nd / 128 >= 128), 2 = whenever the layer shape fits.  The two kernels agree to ~1e-6 of the tensor maximum.  Off by
                                      default: measured at B = 64 (round 5) 132 / 104 / 105 us against 96 / 107 / 82 us at layers 2 / 3 / 4 */
+#define LS_OPT_EDGE_FUSE_Q 5      /* [1] attention layers 2 - 4: the destination-side column groups computed inside the edge kernel (edge.hip: edge_attn_fq_kernel);
+                                     0 = as table columns written by the table GEMM (the general path; also taken under LS_GEMM_MODE=bf16x3 / fp32) */
+#define LS_OPT_EDGE_FUSE_T 6      /* [1] the 32-point attention layers (released layers 5, 6) without a table (edge_fused.hip); 0 = table GEMM + edge kernel */
+#define LS_OPT_GLOB_FUSE 7        /* [1] residual global conv as one mean + GEMV launch and one GEMM + VN-activation launch (gemm.hip: gemm_vn_kernel);
+                                     0 = mean, GEMM -> table, per-instance GEMM, VN activation as separate launches (same products in the same order) */
+#define LS_OPT_DEBUG_EDGE 8       /* [0] ls_vn_edgeconv_*: 1 = run the table GEMM only, 2 = run the edge kernel only on the tables already in the workspace
+                                     (per-operator counter passes: scripts/pmc_ops.py); 0 = both */
+#define LS_OPT_GEMM_OVERLAP 9     /* [1] ls_encode runs a layer's table GEMM on a side stream beside its k-NN build (+5 % with one call in flight); 0 = on the caller's
+                                     stream (better once several ls_encode calls overlap on different streams: bench.py turns it off, -3.5 % otherwise) */
 int ls_model_set_option(ls_model_t* m, int option, int value);
 /* the handle's CURRENT value of an option (what ls_model_create read from the environment, or the last ls_model_set_option): the only
  * way a caller can change an option temporarily and put back exactly what was there */

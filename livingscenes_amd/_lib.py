@@ -16,8 +16,8 @@ FLAG_CONTRACT_FMA = 1
 FLAG_KNN_MFMA_FILTER = 2
 FLAG_KNN_VALU_ONLY = 4
 FLAG_KABSCH_RAW_WEIGHTS = 8
-OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2, OPT_ENCODE_GRAPH, OPT_EDGE_STAGED = 1, 2, 3, 4
-ABI_VERSION = 101   # == LS_ABI_VERSION in include/livingscenes_hip.h: a library of another version is refused (argument layouts differ)
+OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2, OPT_ENCODE_GRAPH, OPT_EDGE_STAGED, OPT_EDGE_FUSE_Q, OPT_EDGE_FUSE_T, OPT_GLOB_FUSE, OPT_DEBUG_EDGE, OPT_GEMM_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8, 9
+ABI_VERSION = 102   # == LS_ABI_VERSION in include/livingscenes_hip.h: a library of another version is refused (argument layouts differ)
 KABSCH_OK, KABSCH_RANK1, KABSCH_RANK0, KABSCH_NONFINITE = 0, 1, 2, 3
 
 

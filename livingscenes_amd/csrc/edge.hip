@@ -33,13 +33,12 @@ constexpr int EK = 16;  // neighbours per point (num_knn)
 // pts [B,N,3]; w0 [6][Co] = {W[:,0], W[:,1], W[:,2], (Wd W)[:,0], (Wd W)[:,1], (Wd W)[:,2]}; out [B,N,3,Co]
 __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ pts, const int32_t* __restrict__ knn,
                                                       const float* __restrict__ w0, int N, int Co, float oms,
-                                                      float* __restrict__ out, int total, const int32_t* __restrict__ perm) {
+                                                      float* __restrict__ out, int total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 5, o = lane & 31;  // two points per wave, 32 lanes each (Co <= 32 per pass)
     int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * 2 + sub;
     const bool live = pid < total;
     if (!live) pid = total - 1;
-    if (perm) pid = perm[pid];      // processing order (pointwise.hip: morton_order_kernel): which point this slot works on; results do not depend on it
     const int b = pid / N;
     const float* P = pts + (size_t)b * N * 3;
     const float cx = pts[(size_t)pid * 3 + 0], cy = pts[(size_t)pid * 3 + 1], cz = pts[(size_t)pid * 3 + 2];
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void edge_l0_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
                                                         int NQ, int q_via_rows, const int32_t* __restrict__ knn,
                                                         const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
-                                                        float oms, float* __restrict__ out, int total, const int32_t* __restrict__ perm) {
+                                                        float oms, float* __restrict__ out, int total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lpp = Co <= 32 ? 32 : 64;         // lanes per point
     const int ppw = 64 / lpp;                   // points per wave
@@ -105,7 +104,6 @@ __global__ __launch_bounds__(256) void edge_pool_kernel(const float* __restrict_
     int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * ppw + sub;
     const bool live = pid < total;
     if (!live) pid = total - 1;
-    if (perm) pid = perm[pid];      // processing order (morton_order_kernel)
     const int b = pid / Nd;
     const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
     const float* Tb = T + (size_t)b * Ns * 3 * ldt;
@@ -333,14 +331,13 @@ __device__ __forceinline__ void fma43(F43& acc, float w, const F43& y) {
 template <int LPP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void edge_pool_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq, int NQ,
                                                            int q_via_rows, const int32_t* __restrict__ knn, const int32_t* __restrict__ dst_rows,
-                                                           int Nd, int Ns, float oms, float* __restrict__ out, int total, const int32_t* __restrict__ perm) {
+                                                           int Nd, int Ns, float oms, float* __restrict__ out, int total) {
     constexpr int PPW = 64 / LPP, Co = 4 * LPP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPP, ll = lane % LPP;
     int pid = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * PPW + sub;
     const bool live = pid < total;
     if (!live) pid = total - 1;
-    if (perm) pid = perm[pid];
     const int b = pid / Nd;
     const int drow = (dst_rows && q_via_rows) ? dst_rows[pid] : (pid % Nd);
     const float* Td = Tq + ((size_t)b * NQ + drow) * 3 * ldq;
@@ -598,7 +595,7 @@ template <int LPP, int CIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
                                                            const uint4* __restrict__ Wp, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, float oms, float inv_sqrt_dk,
-                                                           float* __restrict__ out, int total, float* __restrict__ rowmax, const int32_t* __restrict__ perm) {
+                                                           float* __restrict__ out, int total, float* __restrict__ rowmax) {
     constexpr int PPW = 64 / LPP, PW = 4 * PPW, ROWS = 3 * PW, MT = (ROWS + 31) / 32, Co = LPP * 4, SC = 2 * Co, NT = SC / 32, SLD = SC + 4,
                   KS = CIN / 16, ASTR = CIN * 2 + 16;   // A plane row stride in bytes (+16: conflict-free 16-byte fragment reads)
     static_assert(MT * NT == 8, "two output tiles per wave");
@@ -614,7 +611,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     int pid = pid0 + pwl;
     const bool live = pid < total;
     if (!live) pid = total - 1;
-    if (perm) pid = perm[pid];      // processing order (pointwise.hip: morton_order_kernel): the workgroup's PW slots -> PW spatially adjacent points
     const int b = pid / Nd;
     const float* Tb = T + (size_t)b * Ns * 3 * ldt;
     const int32_t* ki = knn + (size_t)pid * EK;
@@ -627,7 +623,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < ROWS) {
             const int pw = r / 3, x = r - 3 * pw;
-            const int ps = min(pid0 + pw, total - 1), pa = perm ? perm[ps] : ps, ba = pa / Nd;
+            const int pa = min(pid0 + pw, total - 1), ba = pa / Nd;
             const int sp = dst_rows ? dst_rows[pa] : pa - ba * Nd;
             v = *reinterpret_cast<const float4*>(cur + (((size_t)ba * Ns + sp) * 3 + x) * CIN + kq * 4);
         }
@@ -820,12 +816,12 @@ bool edge_attn_fq_fits(int B, int Ns, int ldt) {   // the table is addressed by 
     return (unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24);
 }
 int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, const void* wq_planes, const int32_t* knn, const int32_t* dst_rows, int B,
-                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax, const int32_t* perm) {
+                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax) {
     LS_REQUIRE(head_c == 16 && edge_attn_fq_supported(Co, Cin) && ldt % 4 == 0 && wq_planes, "edge_attn_fq: unsupported shape (Co=%d Cin=%d ldt=%d)", Co, Cin, ldt);
     LS_REQUIRE(edge_attn_fq_fits(B, Ns, ldt), "edge_attn_fq: the table is addressed by 32-bit byte offsets (B=%d Ns=%d ldt=%d)", B, Ns, ldt);
     const float isd = 1.0f / sqrtf(3.0f * head_c), oms = 1.0f - neg_slope;
     const int total = B * Nd;
-#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax, perm)
+#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax)
     if (Co == 64 && Cin == 32) LS_FQ(16, 32);
     else if (Co == 64) LS_FQ(16, 64);
     else LS_FQ(32, 64);
@@ -839,38 +835,36 @@ static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int
                           const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float isd, float* out,
                           hipStream_t st, float* rowmax) {
     const int total = B * Nd, ppb = 4 * (64 / LPP);
-    static const int lds_pad = getenv("LS_EDGE_LDS_PAD") ? atoi(getenv("LS_EDGE_LDS_PAD")) : 0;   // A/B: unused dynamic LDS = fewer workgroups per CU
-    if (lds_pad > 30000) (void)hipFuncSetAttribute((const void*)edge_attn_v4_kernel<LPP, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
-    hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), lds_pad, st, T, ldt, Tq, ldq, NQ, qvr, knn,
+    hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn,
                        dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total, rowmax);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
 
 int edge_l0_launch(const float* pts, const int32_t* knn, const float* w0, int B, int N, int Co, float neg_slope, float* out,
-                   hipStream_t st, const int32_t* perm) {
+                   hipStream_t st) {
     const int total = B * N;
-    hipLaunchKernelGGL(edge_l0_kernel, dim3(cdiv(total, 8)), dim3(256), 0, st, pts, knn, w0, N, Co, 1.0f - neg_slope, out, total, perm);
+    hipLaunchKernelGGL(edge_l0_kernel, dim3(cdiv(total, 8)), dim3(256), 0, st, pts, knn, w0, N, Co, 1.0f - neg_slope, out, total);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
 
 int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
-                     const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st, const int32_t* perm) {
+                     const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float* out, hipStream_t st) {
     const int total = B * Nd;
-    static const bool scalar_pool = getenv("LS_EDGE_POOL_SCALAR") && atoi(getenv("LS_EDGE_POOL_SCALAR")) != 0;   // A/B: the one-channel-per-lane kernel
+    static const bool scalar_pool = dev_knob("LS_EDGE_POOL_SCALAR", 0) != 0;   // dev A/B: the one-channel-per-lane kernel (bit-identical)
     const bool off32 = edge_attn_fq_fits(B, Ns, ldt);
     if (!scalar_pool && off32 && ldt % 4 == 0 && ldq % 4 == 0 && (Co == 32 || Co == 64)) {   // (the float4 kernel addresses the table by 32-bit byte offsets)
         if (Co == 32)
-            hipLaunchKernelGGL((edge_pool_v4_kernel<8>), dim3(cdiv(total, 32)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total, perm);
+            hipLaunchKernelGGL((edge_pool_v4_kernel<8>), dim3(cdiv(total, 32)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total);
         else
-            hipLaunchKernelGGL((edge_pool_v4_kernel<16>), dim3(cdiv(total, 16)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total, perm);
+            hipLaunchKernelGGL((edge_pool_v4_kernel<16>), dim3(cdiv(total, 16)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns, 1.0f - neg_slope, out, total);
         LS_LAUNCH_CHECK();
         return LS_OK;
     }
     const int ppb = (Co <= 32) ? 8 : 4;
     hipLaunchKernelGGL(edge_pool_kernel, dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, Nd, Ns,
-                       Co, 1.0f - neg_slope, out, total, perm);
+                       Co, 1.0f - neg_slope, out, total);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

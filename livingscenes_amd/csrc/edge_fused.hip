@@ -568,9 +568,8 @@ int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, 
     const dim3 grid((H / HG) * B);
     // workgroup order: instance major (an instance's head groups side by side on an XCD: its A image stays in that XCD's L2 and is read by all of
     // them) or head-group major (the 64 instances of one W slice side by side).  Measured (us per launch, q/k | v): layer 5 36.9 | 41.6 instance
-    // major vs 54.9 | 60.6 head major; layer 6 59.2 | 46.6 vs 65.9 | 48.1 -- the A fragments are the stream that matters.  LS_FT_ORDER=0: head major (A/B).
-    static const int order_env = getenv("LS_FT_ORDER") ? atoi(getenv("LS_FT_ORDER")) : -1;
-    const int im = order_env >= 0 ? order_env : 1;
+    // major vs 54.9 | 60.6 head major; layer 6 59.2 | 46.6 vs 65.9 | 48.1 -- the A fragments are the stream that matters.  LS_FT_ORDER=0 (dev library): head major.
+    static const int im = dev_knob("LS_FT_ORDER", 1);
     if (Cin == 128) {
         hipLaunchKernelGGL((edge_ft_qk_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp, im);
         LS_LAUNCH_CHECK();

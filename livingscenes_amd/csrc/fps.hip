@@ -564,30 +564,29 @@ static int launch_block(const float* pts, const int32_t* lengths, int B, int N, 
 template <bool FMA>
 static int fps_mode(const float* pts, const int32_t* lengths, int B, int N, int K, int32_t* idx, float* po, void* ws, size_t ws_bytes,
                     hipStream_t st) {
-    static const bool one_wave = getenv("LS_FPS_ONE_WAVE") && atoi(getenv("LS_FPS_ONE_WAVE")) != 0;   // A/B: the one-wave kernel
     if (N <= 128) return launch_wave<2, FMA>(pts, lengths, B, N, K, idx, po, st);
-    if (!one_wave) {
-        if (N <= 256) return launch_quad<1, FMA>(pts, lengths, B, N, K, idx, po, st);
-        if (N <= 512) return launch_quad<2, FMA>(pts, lengths, B, N, K, idx, po, st);
-        if (N <= 1024) return launch_quad<4, FMA>(pts, lengths, B, N, K, idx, po, st);
-        if (N <= 2048) return launch_quad<8, FMA>(pts, lengths, B, N, K, idx, po, st);
-    }
-    if (N <= 512) return launch_wave<8, FMA>(pts, lengths, B, N, K, idx, po, st);
-    if (N <= 1024) return launch_wave<16, FMA>(pts, lengths, B, N, K, idx, po, st);
-    if (N <= 2048) return launch_wave<32, FMA>(pts, lengths, B, N, K, idx, po, st);
+#ifdef LS_DEV_KNOBS      // dev A/B: the one-wave kernels for 256 .. 2048 points (same indices)
+    static const bool one_wave = dev_knob("LS_FPS_ONE_WAVE", 0) != 0;
+    if (one_wave && N <= 512) return launch_wave<8, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (one_wave && N <= 1024) return launch_wave<16, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (one_wave && N <= 2048) return launch_wave<32, FMA>(pts, lengths, B, N, K, idx, po, st);
+#endif
+    if (N <= 256) return launch_quad<1, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 512) return launch_quad<2, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 1024) return launch_quad<4, FMA>(pts, lengths, B, N, K, idx, po, st);
+    if (N <= 2048) return launch_quad<8, FMA>(pts, lengths, B, N, K, idx, po, st);
     if (N <= 8192) return launch_block<8, FMA>(pts, lengths, B, N, K, idx, po, st);
     if (N <= 65536) {
-        static const bool full_scan = getenv("LS_FPS_FULL_SCAN") && atoi(getenv("LS_FPS_FULL_SCAN")) != 0;   // A/B: the un-bucketed block kernel
+        // 8 193 .. 65 536 points: exact bucket pruning in the caller's workspace (ls_fps_workspace_bytes).  (Until round 5 a call without workspace fell
+        // back to a full scan per step -- fps_block_kernel<64>, 82 spilled registers, ~30x slower; it is an error now.)
         const size_t per = fps_scratch_bytes_per_cloud(N);
-        if (ws && ws_bytes >= per * (size_t)B && !full_scan) {
-            static const int nt = getenv("LS_FPS_BUCKET_THREADS") ? atoi(getenv("LS_FPS_BUCKET_THREADS")) : 1024;   // A/B
-            if (nt == 256) hipLaunchKernelGGL((fps_bucket_kernel<FMA, 256>), dim3(B), dim3(256), 0, st, pts, lengths, N, K, idx, po, (char*)ws, per);
-            else if (nt == 512) hipLaunchKernelGGL((fps_bucket_kernel<FMA, 512>), dim3(B), dim3(512), 0, st, pts, lengths, N, K, idx, po, (char*)ws, per);
-            else hipLaunchKernelGGL((fps_bucket_kernel<FMA, 1024>), dim3(B), dim3(1024), 0, st, pts, lengths, N, K, idx, po, (char*)ws, per);
-            LS_LAUNCH_CHECK();
-            return LS_OK;
+        if (!ws || ws_bytes < per * (size_t)B) {
+            set_error("fps: N=%d needs a workspace of %zu bytes (ls_fps_workspace_bytes), got %zu", N, per * (size_t)B, ws ? ws_bytes : (size_t)0);
+            return LS_ERR_WORKSPACE;
         }
-        return launch_block<64, FMA>(pts, lengths, B, N, K, idx, po, st);   // no scratch handed in: the full scan per step (same result)
+        hipLaunchKernelGGL((fps_bucket_kernel<FMA, 1024>), dim3(B), dim3(1024), 0, st, pts, lengths, N, K, idx, po, (char*)ws, per);
+        LS_LAUNCH_CHECK();
+        return LS_OK;
     }
     set_error("fps: N=%d too large (max 65536)", N);
     return LS_ERR_INVALID;

@@ -1830,6 +1830,17 @@ int gemm_presplit_w_launch(const float* W, int rows, int K, int ldw, const float
     return LS_OK;
 }
 
+// How an fp32 product is formed, process-wide (read once): 0 = two f16 pieces with per-row power-of-two scaling, three MFMAs per 16 k (default);
+// 1 = LS_GEMM_MODE=bf16x3: three bf16 pieces, six MFMAs, any finite fp32 range without scaling; 2 = LS_GEMM_MODE=fp32: exact fp32 FMA chains on
+// v_mfma_f32_32x32x2_f32 (bit-for-bit comparison with an fp32 VALU GEMM).  The fused edge / global-conv kernels exist for mode 0 only.
+int gemm_mode() {
+    static const int mode = [] {
+        const char* v = getenv("LS_GEMM_MODE");
+        return !v ? 0 : (!strcmp(v, "bf16x3") ? 1 : (!strcmp(v, "fp32") ? 2 : 0));
+    }();
+    return mode;
+}
+
 // Under-filled grids with a long K loop (the per-instance "mean" rows of the residual global conv: M = 3B rows against
 // K = C up to 512; conv_c) are pure latency: 32 workgroups x 16 dependent k-steps = 44 us for 0.2 GFLOP.  They are split
 // along K into slices written as partial slabs and combined by a second launch.
@@ -1848,13 +1859,13 @@ size_t gemm_scratch_floats(int M, int N, int K) {
 int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const float* bias, float* out, int ldc, int M, int N, int K,
                        int relu, const int32_t* a_rows, int gNd, int gNs, float* scratch, hipStream_t st, bool latency_path = false,
                        int pieces = 3, const float* mask = nullptr, GemmAux aux = GemmAux()) {
-    static const bool range_off = getenv("LS_GEMM_RANGE") && atoi(getenv("LS_GEMM_RANGE")) == 0;   // A/B: the unscaled round-2 split
+    static const bool range_off = dev_knob("LS_GEMM_RANGE", 1) == 0;   // dev A/B: the unscaled round-2 split
     if (range_off) aux.noscale = 1;
     LS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem (M=%d N=%d K=%d)", M, N, K);
     LS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K, lda, ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     LS_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: A and W must be 16-byte aligned");
     const int tm = cdiv(M, GM), tn = cdiv(N, GN);
-    static const bool split_on = !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
+    const bool split_on = gemm_mode() != 2;      // LS_GEMM_MODE=fp32: exact fp32 FMA chains on v_mfma_f32_32x32x2_f32
     // (fp32 mode only: with three-piece bf16 products the tiled kernel below is faster on the K = 32 tables too -- 27.8 / 42.8 /
     // 34.5 us vs 28.8 / 47.2 / 38.8 us for the three layer-1/2 shapes -- and the arithmetic then depends on nothing but K)
     if (K == 32 && tm >= 16 && !split_on) {
@@ -1878,11 +1889,11 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
     const bool split = split_on && !latency_path;
     // how an fp32 product is formed on the 16-bit matrix cores: 22 = two f16 pieces (three MFMAs per 16 k, the
     // default), 3 = three bf16 pieces (six MFMAs, any fp32 range: LS_GEMM_MODE=bf16x3), 2 = two bf16 pieces (opt-in decode mode)
-    static const bool h2_unpipelined = getenv("LS_GEMM_H2_SIMPLE") && atoi(getenv("LS_GEMM_H2_SIMPLE")) != 0;   // A/B: the two-barrier kernel
-    static const bool planes_off = getenv("LS_GEMM_WPLANES") && atoi(getenv("LS_GEMM_WPLANES")) == 0;   // A/B: split W inside the kernel
+    static const bool h2_unpipelined = dev_knob("LS_GEMM_H2_SIMPLE", 0) != 0;   // dev A/B: the two-barrier kernel
+    static const bool planes_off = dev_knob("LS_GEMM_WPLANES", 1) == 0;         // dev A/B: split W inside the kernel
     const bool wpl = aux.w_planes && aux.w_rowmax && !aux.noscale && !planes_off && K % 32 == 0 && K > 64 && !h2_unpipelined;
 #define LS_H2_KERNEL ((h2_unpipelined || K <= 64) ? gemm_f32_kernel<true, 22> : (K % 32 == 0 ? (wpl ? gemm_h2_kernel<true, true> : gemm_h2_kernel<true, false>) : gemm_h2_kernel<false, false>))
-    static const int default_pieces = (getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) ? 3 : 22;
+    const int default_pieces = gemm_mode() == 1 ? 3 : 22;
     if (pieces == 3) pieces = default_pieces;
     const int nsplit = (scratch && !mask) ? gemm_choose_splits(M, N, K) : 1;   // (a split launch writes no out_rowmax: callers check gemm_scratch_floats)
     if (nsplit > 1) {
@@ -1905,9 +1916,9 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         LS_LAUNCH_CHECK();
         return LS_OK;
     }
-    static const bool persist = !(getenv("LS_GEMM_PERSIST") && atoi(getenv("LS_GEMM_PERSIST")) == 0);   // A/B: K = 32 / 64 on the tiled kernel
+    static const bool persist = dev_knob("LS_GEMM_PERSIST", 1) != 0;   // dev A/B: K = 32 / 64 on the tiled kernel
     // 256 x 256 tiles once they fill the chip (LS_GEMM_WIDE=0 / 1: never / always -- same arithmetic, bit-identical results)
-    static const int wide_mode = getenv("LS_GEMM_WIDE") ? atoi(getenv("LS_GEMM_WIDE")) : -1;
+    static const int wide_mode = dev_knob("LS_GEMM_WIDE", -1);
     // measured (scripts/diag/gemm_wide_probe.py): the wide kernel wins when its grid fills whole rounds of the 256 CUs (one workgroup per
     // CU): 480 tiles 88 -> 73 us, 768 tiles 355 -> 280 us, 3072 tiles 1186 -> 1002 us; ties at 384 tiles, loses below one round
     const long long wtiles = (long long)cdiv(M, 256) * cdiv(N, 256);
@@ -1918,8 +1929,7 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
                    aux.slice_rows % 32 == 0 && M % aux.slice_rows == 0 && N % aux.slice_cols == 0 && ((uintptr_t)out & 15) == 0,
                    "gemm: slice-major output needs the K = 32 / 64 f16-split kernel (M=%d N=%d K=%d slice %d x %d)", M, N, K, aux.slice_rows, aux.slice_cols);
     if (split && pieces == 22 && (sliced || (persist && tm >= 16 && !h2_unpipelined)) && !mask && (K == 32 || K == 64) && !aux.out_rowmax) {
-        static const int sk_wgs32 = getenv("LS_GEMM_PERSIST_WGS32") ? atoi(getenv("LS_GEMM_PERSIST_WGS32")) : 512;   // A/B
-        static const int sk_wgs64 = getenv("LS_GEMM_PERSIST_WGS64") ? atoi(getenv("LS_GEMM_PERSIST_WGS64")) : 512;
+        static const int sk_wgs32 = dev_knob("LS_GEMM_PERSIST_WGS32", 512), sk_wgs64 = dev_knob("LS_GEMM_PERSIST_WGS64", 512);   // dev A/B
         int per_n = cdiv(K == 32 ? sk_wgs32 : sk_wgs64, tn);   // resident workgroups per CU x 256, spread evenly over the N-tiles
         if (per_n > tm) per_n = tm;
 #define LS_H2SK(KK, G) hipLaunchKernelGGL((gemm_h2_smallk_kernel<KK, G>), dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, bias, out, ldc, M, N, relu, tm, per_n, a_rows, gNd, gNs, aux)
@@ -1938,21 +1948,25 @@ int gemm_dispatch_full(const float* A, int lda, const float* W, int ldw, const f
         if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
 #define LS_W2_ATTR(MK, PL, PG) LS_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w2_kernel<MK, PL, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             LS_W2_ATTR(false, 0, false); LS_W2_ATTR(true, 0, false); LS_W2_ATTR(false, 1, false); LS_W2_ATTR(true, 1, false);
+#ifdef LS_DEV_KNOBS
             LS_W2_ATTR(false, 0, true); LS_W2_ATTR(true, 0, true); LS_W2_ATTR(false, 1, true); LS_W2_ATTR(true, 1, true);
             LS_W2_ATTR(false, 2, false); LS_W2_ATTR(true, 2, false);
+#endif
 #undef LS_W2_ATTR
             attr_devices.fetch_or(dev_bit, std::memory_order_release);
         }
-        // LS_GEMM_W2_PERSIST=1: one workgroup per CU walking the tiles (measured: 942 - 944 vs 950 - 956 us at the decoder shape, but 73 -> 79 us at
-        // 480 tiles, where the static assignment balances worse than the dispatcher) -- off by default
-        static const bool w2_persist = getenv("LS_GEMM_W2_PERSIST") && atoi(getenv("LS_GEMM_W2_PERSIST")) != 0;
+        // dev variants (-DLS_DEV_KNOBS; all bit-identical to the default, all measured and not kept -- docs/history.md): LS_GEMM_W2_PERSIST=1 one workgroup
+        // per CU walking the tiles (942 - 944 vs 950 - 956 us at the decoder shape, 73 -> 79 us at 480 tiles); LS_GEMM_W2_PP=1 the two waves of a SIMD half
+        // a slab step apart (957 vs 928 us); LS_GEMM_W2_DIRECT=1 the W planes by LDS-direct loads (907 / 933 vs 915 / 925 us: the kernel is power-bound)
+        static const bool w2_persist = dev_knob("LS_GEMM_W2_PERSIST", 0) != 0;
         const int w2_grid = w2_persist ? std::min(wtm * wtn, 256) : wtm * wtn;
-        static const bool w2_pp = getenv("LS_GEMM_W2_PP") && atoi(getenv("LS_GEMM_W2_PP")) != 0;   // A/B: the two waves of a SIMD half a step apart (bit-identical, measured slower: see the kernel)
-        // LS_GEMM_W2_DIRECT=1: the W planes by LDS-direct loads (bit-identical; measured 907 / 933 us against 915 / 925 us through registers on two
-        // boxes at the decoder shape: no difference -- the kernel is power-bound, see the kernel's header)
-        static const bool w2_direct = getenv("LS_GEMM_W2_DIRECT") && atoi(getenv("LS_GEMM_W2_DIRECT")) != 0;
 #define LS_W2(MK, PL, PG) hipLaunchKernelGGL((gemm_w2_kernel<MK, PL, PG>), dim3(w2_grid), dim3(512), lds, st, A, lda, W, ldw, bias, out, ldc, M, N, K, relu, wtn, wtm * wtn, mask, aux)
+#ifdef LS_DEV_KNOBS
+        static const bool w2_pp = dev_knob("LS_GEMM_W2_PP", 0) != 0, w2_direct = dev_knob("LS_GEMM_W2_DIRECT", 0) != 0;
 #define LS_W2P(MK, PL) do { if (w2_pp) LS_W2(MK, PL, true); else if (PL == 1 && w2_direct) LS_W2(MK, 2, false); else LS_W2(MK, PL, false); } while (0)
+#else
+#define LS_W2P(MK, PL) LS_W2(MK, PL, false)
+#endif
         if (mask) { if (wpl) LS_W2P(true, 1); else LS_W2P(true, 0); }
         else { if (wpl) LS_W2P(false, 1); else LS_W2P(false, 0); }
 #undef LS_W2P
@@ -1997,19 +2011,17 @@ int gemm_dispatch_masked(const float* A, int lda, const float* W, int ldw, float
 // out [M = B * npts * 3, C] = VN-act(A W[0:C]^T + G lin part, A W[C:2C]^T + G dir part): see gemm_vn_kernel.  false = shape / mode not
 // supported (the caller runs GEMM + vn_act_rows instead)
 bool gemm_vn_supported(int M, int C, int K) {
-    static const bool on = !(getenv("LS_GLOB_FUSE") && atoi(getenv("LS_GLOB_FUSE")) == 0);
-    static const bool h2 = !(getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) && !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
-    return on && h2 && C % 64 == 0 && K % 4 == 0 && K >= 32 && M % 3 == 0;
+    return gemm_mode() == 0 && C % 64 == 0 && K % 4 == 0 && K >= 32 && M % 3 == 0;
 }
 int gemm_vn_dispatch(const float* A, int lda, const float* W, int ldw, const float* G, int ldg, float* out, int M, int C, int K, int npts, float oms,
                      hipStream_t st, GemmAux aux) {
-    static const bool range_off = getenv("LS_GEMM_RANGE") && atoi(getenv("LS_GEMM_RANGE")) == 0;
+    static const bool range_off = dev_knob("LS_GEMM_RANGE", 1) == 0;
     if (range_off) aux.noscale = 1;
     LS_REQUIRE(gemm_vn_supported(M, C, K) && lda % 4 == 0 && ldw % 4 == 0, "gemm_vn: unsupported shape (M=%d C=%d K=%d)", M, C, K);
     const int tm = cdiv(M, 120), tn = C / 64;
-    static const bool persist = !(getenv("LS_GLOB_PERSIST") && atoi(getenv("LS_GLOB_PERSIST")) == 0);   // A/B: K = 32 / 64 on the tiled kernel
+    static const bool persist = dev_knob("LS_GLOB_PERSIST", 1) != 0;   // dev A/B: K = 32 / 64 on the tiled kernel
     if (persist && (K == 32 || K == 64) && tm >= 16 && lda == K) {
-        static const int vn_wgs32 = getenv("LS_GLOB_PERSIST_WGS32") ? atoi(getenv("LS_GLOB_PERSIST_WGS32")) : 512;   // A/B
+        static const int vn_wgs32 = dev_knob("LS_GLOB_PERSIST_WGS32", 512);   // dev A/B
         int per_n = cdiv(K == 32 ? vn_wgs32 : 512, tn);   // resident workgroups per CU x 256
         if (per_n > tm) per_n = tm;
         if (K == 32) hipLaunchKernelGGL(gemm_vn_smallk_kernel<32>, dim3(tn * per_n), dim3(256), 0, st, A, lda, W, ldw, G, ldg, out, M, C, npts, oms, tm, per_n, tn, aux);

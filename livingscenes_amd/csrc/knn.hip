@@ -239,7 +239,7 @@ static int knn_choose_splits(int B, int Nd, int Ns) {
     if (blocks >= 512 || ctiles < 2) return 1;  // >= 2 workgroups per CU: splitting would only add merge work (and un-seeded splits)
     // one workgroup per CU is the target: every split re-stages the 64 x 3C query tile and only split 0 is seeded, so at the
     // layer-4 shape (128 x 512, D = 192) 2 splits run in 0.14 ms where 8 splits (1024 workgroups) took 0.23 ms and 1 split 0.19 ms
-    static const int target = getenv("LS_KNN_SPLIT_TARGET") ? atoi(getenv("LS_KNN_SPLIT_TARGET")) : 256;
+    static const int target = dev_knob("LS_KNN_SPLIT_TARGET", 256);
     int sp = cdiv(target, blocks);
     if (sp > ctiles) sp = ctiles;
     if (sp > 16) sp = 16;
@@ -250,17 +250,11 @@ static size_t knn_partial_bytes(int B, int Nd, int Ns) {
     const int sp = knn_choose_splits(B, Nd, Ns);
     return sp > 1 ? (size_t)B * Nd * sp * 16 * sizeof(u64) : 0;
 }
-// the MFMA sweep kernel (knn_mfma.hip) takes the seeded C == 32 launches unless the caller forces the all-VALU kernel
-// ... and, with hints of its own making (knn_mfma.hip, "auto hints"), the un-seeded ones whose candidates fit the f16 sweep's bitmap
-static bool knn_autohints_enabled() {
-    static const bool off = (getenv("LS_KNN_AUTOHINTS") && atoi(getenv("LS_KNN_AUTOHINTS")) == 0) ||
-                            (getenv("LS_KNN_SWEEP_FP32") && atoi(getenv("LS_KNN_SWEEP_FP32")) != 0);
-    return !off;
-}
-static bool knn_uses_sweep(int C, bool seeded, int Ns, unsigned flags) {
+// the fused MFMA-filtered kernel (knn_mfma.hip) takes the C == 32 / 64 calls whose candidates fit it, unless the caller forces the all-VALU kernel
+int knn_sweep_max_ns();
+static bool knn_uses_sweep(int C, bool /*seeded*/, int Ns, unsigned flags) {
     if (!(C == 32 || C == 64) || (flags & LS_FLAG_KNN_VALU_ONLY)) return false;
-    if (seeded) return Ns <= 65535;
-    return knn_autohints_enabled() && Ns >= 64 && Ns <= 2048;
+    return Ns >= 1 && ((Ns + 31) & ~31) <= knn_sweep_max_ns();
 }
 size_t knn_sweep_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C);
 int knn_sweep_launch(const float*, const float*, const int32_t*, int, int, int, int, int, int, bool, int32_t*, float*, const int32_t*, int,
@@ -272,75 +266,6 @@ size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, u
     return knn_partial_bytes(B, Nd, Ns);
 }
 
-// ---- hints for the layer AFTER a down-sampling layer.  That layer's own lists index the larger source set, so they are
-// mapped through the inverse of the FPS selection (~half of the entries survive a 2x down-sampling) and topped up with the
-// mapped lists of the surviving neighbours, nearest first, until 16 distinct hints are found.  Hints only steer the MFMA
-// sweep's thresholds; the result never depends on them.
-__global__ __launch_bounds__(256) void knn_inverse_rows_kernel(const int32_t* __restrict__ rows, int Nd, int Ns, int32_t* __restrict__ inv,
-                                                               int total) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int b = i / Nd, r = rows[i];
-    if (r >= 0 && r < Ns) inv[(size_t)b * Ns + r] = i % Nd;
-}
-// one 16-lane row per query (a destination point of the down-sampling layer); lane e <-> list entry e
-__global__ __launch_bounds__(256) void knn_compose_hints_kernel(const int32_t* __restrict__ knn, const int32_t* __restrict__ inv, int Nd, int Ns,
-                                                                int32_t* __restrict__ out, int total) {
-    __shared__ int lrow[16][16];
-    const int tid = threadIdx.x, e = tid & 15, row = tid >> 4, sh = tid & 48;   // sh: this row's bit offset in a wave ballot
-    int q = blockIdx.x * 16 + row;
-    const bool live = q < total;
-    if (!live) q = total - 1;
-    const int b = q / Nd;
-    const int32_t* ib = inv + (size_t)b * Ns;
-    auto mapped = [&](int s) { return (s >= 0 && s < Ns) ? ib[s] : -1; };
-    auto row_ballot = [&](bool p) { return (unsigned)(__ballot(p) >> sh) & 0xFFFFu; };
-    const unsigned below = (1u << e) - 1u;
-    const int v1 = mapped(knn[(size_t)q * 16 + e]);
-    unsigned m = row_ballot(v1 >= 0);
-    lrow[row][e] = -1;
-    __builtin_amdgcn_wave_barrier();
-    if (v1 >= 0) lrow[row][__builtin_popcount(m & below)] = v1;
-    __builtin_amdgcn_wave_barrier();
-    int n = __builtin_popcount(m);
-    for (int t = 0; t < 16; ++t) {
-        const bool act = t < n && n < 16;       // breadth first: lists of the 1-hop survivors, then of what they contributed
-        if (!__any(act)) break;
-        const int nb = act ? lrow[row][t] : 0;
-        const int w = act ? mapped(knn[((size_t)b * Nd + nb) * 16 + e]) : -1;
-        bool dup = false;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) dup |= (w == lrow[row][j]);
-        const bool ok = act && w >= 0 && !dup;
-        m = row_ballot(ok);
-        const int pos = n + __builtin_popcount(m & below);
-        __builtin_amdgcn_wave_barrier();
-        if (ok && pos < 16) lrow[row][pos] = w;
-        __builtin_amdgcn_wave_barrier();
-        n = min(16, n + __builtin_popcount(m));
-    }
-    // an isolated point (all of its neighbourhood was dropped by the down-sampling): top up with arbitrary distinct rows, so
-    // that the query still gets a finite (if loose) threshold instead of the brute-force path
-    int v = lrow[row][e];
-    if (e >= n) {
-        v = (q % Nd + 1 + (e - n) * 37) % Nd;
-        bool dup = false;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) dup |= (j < n) & (v == lrow[row][j]);
-        if (dup) v = -1;
-    }
-    if (live) out[(size_t)q * 16 + e] = v;
-}
-int knn_compose_hints_launch(const int32_t* prev_knn, const int32_t* prev_rows, int B, int Nd, int Ns, int32_t* inv, int32_t* hints,
-                             hipStream_t st) {
-    LS_HIP_CHECK(hipMemsetAsync(inv, 0xFF, (size_t)B * Ns * sizeof(int32_t), st));
-    const int total = B * Nd;
-    hipLaunchKernelGGL(knn_inverse_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, prev_rows, Nd, Ns, inv, total);
-    LS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(knn_compose_hints_kernel, dim3(cdiv(total, 16)), dim3(256), 0, st, prev_knn, inv, Nd, Ns, hints, total);
-    LS_LAUNCH_CHECK();
-    return LS_OK;
-}
 bool knn_would_sweep(int C, int Ns, unsigned flags) { return knn_uses_sweep(C, true, Ns, flags); }
 
 template <int CC, bool FMA>
@@ -371,19 +296,15 @@ int knn_dispatch(const float* dst, const float* src, const int32_t* dst_rows, in
     LS_REQUIRE(K >= 1 && K <= KNN_MAXK, "knn: K=%d unsupported (1..16)", K);
     LS_REQUIRE(C == 1 || C % 32 == 0, "knn: C=%d must be 1 or a multiple of 32", C);
     const bool fma = (flags & LS_FLAG_CONTRACT_FMA) != 0;
-    // seeded C == 32 / 64 layers, and un-seeded calls with more than a handful of queries: (auto hints /) seed / MFMA sweep / finish
+    // C == 32 / 64 rows, at most 1024 candidates, more than a handful of queries: f16 image + the fused kernel (knn_mfma.hip)
     if (scratch && knn_uses_sweep(C, seed_idx != nullptr, Ns, flags) && (seed_idx != nullptr || Nd > 32))
         return knn_sweep_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, seed_idx, seed_n, seed_by_row, scratch, st);
     if (C == 1) {
-        // raw clouds: wave-per-query kernel (knn_xyz.hip); LS_KNN_XYZ_TILED=1 keeps the tiled kernel for A/B timing
-        static const bool tiled = getenv("LS_KNN_XYZ_TILED") && atoi(getenv("LS_KNN_XYZ_TILED")) != 0;
-        if (!tiled) return knn_xyz_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, st);
-        return fma ? launch_knn<1, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st)
-                   : launch_knn<1, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, nullptr, 0, 0, st);
+        // raw clouds: wave-per-query kernel (knn_xyz.hip)
+        return knn_xyz_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, K, fma, idx_out, dist_out, st);
     }
     // few queries per instance (encoder layers 5, 6): one pair per thread on whole rows (knn_xyz.hip) instead of 64 x 64 tiles
-    static const bool small_off = getenv("LS_KNN_SMALL") && atoi(getenv("LS_KNN_SMALL")) == 0;
-    if (Nd <= 32 && !small_off) return knn_small_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, st);
+    if (Nd <= 32) return knn_small_launch(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, fma, idx_out, dist_out, st);
     return fma ? launch_knn<32, true>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, seed_idx, seed_n, seed_by_row, st)
                : launch_knn<32, false>(dst, src, dst_rows, B, Nd, dst_n, Ns, C, K, idx_out, dist_out, scratch, seed_idx, seed_n, seed_by_row, st);
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <float.h>
 #include <limits.h>
 
@@ -37,6 +38,15 @@ void set_error(const char* fmt, ...);
             return LS_ERR_HIP;                                                       \
         }                                                                            \
     } while (0)
+
+// Development A/B switches: a library built with -DLS_DEV_KNOBS (scripts/dev/build_variants.py) reads them from the environment; in the RELEASE
+// library every knob is its default, a compile-time constant -- the release library reads nothing from the environment beyond what
+// ls_model_create documents (LS_ENCODE_GRAPH, LS_EDGE_STAGED, LS_SDF_BF16X2) and the process-wide arithmetic mode LS_GEMM_MODE (gemm.hip).
+#ifdef LS_DEV_KNOBS
+inline int dev_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int dev_knob(const char*, int dflt) { return dflt; }
+#endif
 
 constexpr int kWave = 64;
 constexpr int kXcds = 8;

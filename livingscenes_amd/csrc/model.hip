@@ -22,7 +22,6 @@ void set_error(const char* fmt, ...) {
 int knn_dispatch(const float*, const float*, const int32_t*, int, int, int, int, int, int, unsigned, int32_t*, float*, void*, const int32_t*, int, int,
                  hipStream_t);
 size_t knn_scratch_bytes(int B, int Nd, int dst_n, int Ns, int C, bool seeded, unsigned flags);
-int knn_compose_hints_launch(const int32_t* prev_knn, const int32_t* prev_rows, int B, int Nd, int Ns, int32_t* inv, int32_t* hints, hipStream_t st);
 bool knn_would_sweep(int C, int Ns, unsigned flags);
 int knn_sweep_stats_launch(const void* scratch, int B, int Nd, int dst_n, int Ns, unsigned long long* out, hipStream_t st);
 int fps_dispatch(const float*, const int32_t*, int, int, int, unsigned, int32_t*, float*, void*, size_t, hipStream_t);
@@ -34,14 +33,13 @@ size_t gemm_w_planes_bytes(size_t rows, int K);
 bool gemm_w_planes_useful(int K);
 int gemm_presplit_w_launch(const float* W, int rows, int K, int ldw, const float* rowmax, void* planes, hipStream_t st);
 int sdf_affine_rowmax_parts(int out_dim);
-int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t, const int32_t* perm = nullptr);
-int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t, const int32_t* perm = nullptr);
+int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
+int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
 int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
 bool edge_attn_emits_rowmax(int Co, int ldt, int ldq);
 bool edge_attn_fq_supported(int Co, int Cin);
 bool edge_attn_fq_fits(int B, int Ns, int ldt);
-int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr, const int32_t* perm = nullptr);
-int morton_order_launch(const float* pts, int B, int N, int32_t* perm, hipStream_t st);
+int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
 size_t edge_wq_planes_bytes(int Co, int Cin);
 // edge_fused.hip: attention layers with 32 destination points (released layers 5 / 6) -- table slices formed and consumed in LDS
 bool edge_ft_supported(int Co, int Cin, int Ns, int Nd, int head_c, bool has_rows);
@@ -66,6 +64,7 @@ int gemm_dispatch_gather(const float*, int, const float*, int, const float*, flo
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 bool gemm_vn_supported(int M, int C, int K);
+int gemm_mode();
 int gemm_vn_dispatch(const float*, int, const float*, int, const float*, int, float*, int, int, int, int, float, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_fast2(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int gemm_dispatch_masked(const float*, int, const float*, int, float*, int, int, int, int, const float*, int, hipStream_t, GemmAux aux = GemmAux());
@@ -116,6 +115,11 @@ struct ls_model {
     void* wq_planes[LS_MAX_LAYERS] = {};   // attention layers 2 - 4: destination-side weights as f16 MFMA fragments (edge.hip, edge_attn_fq_kernel)
     float* wst_w[LS_MAX_LAYERS] = {};      // attention layers 2 - 4, LDS-staged path (edge_staged.hip): neighbour-side weight rows in slice order ...
     void* wst_q[LS_MAX_LAYERS] = {};       // ... and the destination-side weights as per-Q-block f16 MFMA fragments
+    bool fuse_q = true;                    // LS_OPT_EDGE_FUSE_Q: destination side of attention layers 2 - 4 inside the edge kernel (edge.hip: edge_attn_fq_kernel)
+    bool fuse_t = true;                    // LS_OPT_EDGE_FUSE_T: table-free 32-point attention layers (edge_fused.hip)
+    bool glob_fuse = true;                 // LS_OPT_GLOB_FUSE: residual global conv as mean + GEMV launch and GEMM + VN activation in one kernel (gemm.hip: gemm_vn_kernel)
+    int debug_edge = 0;                    // LS_OPT_DEBUG_EDGE: ls_vn_edgeconv_* runs 0 = table GEMM + edge kernel, 1 = the table GEMM only, 2 = the edge kernel only on the
+                                           // tables already in the workspace (per-operator counter passes: scripts/pmc_ops.py)
     int edge_staged = 0;                   // LS_OPT_EDGE_STAGED: 0 = never (default: measured slower than the gather kernel), 1 = when the grid fills the chip
                                            // (B * Nd / PTS >= 128 workgroups), 2 = whenever the shape fits
     float* dec_wt = nullptr;            // transposed decoder weights [kin_l][out_l], built by the first backward call
@@ -133,14 +137,9 @@ struct ls_model {
     hipEvent_t ev_fps[LS_MAX_LAYERS] = {};   // one per FPS level: a down-sampling layer waits for ITS level only (round 3: waiting for the whole chain
                                              // kept layer 2 idle for ~100 us while levels 1 and 2 were still running)
     hipEvent_t ev_feat[LS_MAX_LAYERS] = {}, ev_tab[LS_MAX_LAYERS] = {};
-    bool knn_filter = true;        // LS_KNN_FILTER=0: all-VALU k-NN kernel on the seeded C == 32 layers too (A/B timing)
     bool train_splitk = true;      // ls_model_set_option(LS_OPT_SDF_TRAIN_SPLITK): split-K in the decoder's TRAINING-path GEMMs (under-filled
                                    // M = 1024 problems: 2.43 -> 1.6 ms per step); off = a row's result never depends on the batch it rides in
     bool sdf_bf16x2 = false;       // LS_SDF_BF16X2=1: decoder GEMMs with two-piece bf16 products (2^-16 per product, ~1.7x; opt-in)
-    bool seed_knn = true;          // LS_KNN_SEEDS=0 disables seeding a layer's k-NN lists from the previous layer's graph
-    int hint_policy = 0;           // LS_KNN_HINTS: 0 "mixed" (default) = previous-layer lists for the C = 32 layers, the sweep's own
-                                   // auto hints elsewhere; 1 "prev" = previous-layer lists wherever they exist (composed after a
-                                   // down-sampling layer); 2 "auto" = never use the previous layer
     // captured launch sequences of ls_encode, one per (workspace, B, N, mode): OPT-IN (LS_ENCODE_GRAPH=1 / ls_model_set_option).
     // Measured on MI355X / ROCm 7.2 (round 2, bench.py, B = 64): replaying the ~170-node graph costs the host MORE than enqueueing
     // the kernels directly -- one step in flight 22.2k obj/s (2.53 ms of host time per step) vs 29.6k (1.98 ms) direct; eight steps in
@@ -151,10 +150,6 @@ struct ls_model {
     bool graph_broken = false;     // a capture / instantiate failed once on this handle: stay on the direct path
     int debug_layers = -1;         // LS_DEBUG_LAYERS=n: ls_encode stops after n layers (outputs undefined) and prints the workspace plan:
                                    // race hunting by comparing workspaces (scripts/diag/)
-    bool order_pts = false;        // LS_ORDER=1: the gather kernels take their points in Morton order of their xyz instead of storage (FPS) order (same
-                                   // results).  OFF: measured neutral -- 16 Morton-adjacent points share their neighbours (62 - 90 distinct rows of 256, against
-                                   // ~230 in FPS order), yet the attention kernels did not move (110 / 109 / 81 us either way; bench 51.0k vs 50.8k): they are
-                                   // not bound by L2 -> L1 traffic but by L1 delivery (6.1 MB per CU at 64 B/clk = 46 us) next to ~60 us of arithmetic
     bool fps_side = true;          // LS_FPS_SIDE=0 runs the FPS chain on the caller's stream (A/B timing, race hunting)
     bool overlap_gemm = true;      // LS_GEMM_OVERLAP=0 serialises the table GEMMs on the caller's stream (A/B timing)
     unsigned skip_mask = 0;        // (always 0 unless built with -DLS_DEV_KNOBS) LS_SKIP=knn,attn,...: dev timing knob -- after LS_SKIP_AFTER (default 3) ls_encode calls on this handle the named
@@ -198,8 +193,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_perm[LS_MAX_LAYERS + 1];   // processing order of each level's points (Morton order of their xyz; pointwise.hip)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_hint, o_inv, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -263,7 +257,6 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     for (int l = 0; l <= p.nlevels; ++l) {
         p.o_pts[l] = take((size_t)B * p.levelN[l] * 3 * 4);
         p.o_fps[l] = take((size_t)B * p.levelN[l] * 4);
-        p.o_perm[l] = take((size_t)B * p.levelN[l] * 4);
     }
     p.o_centroid = take((size_t)B * 3 * 4);
     p.o_scale0 = take((size_t)B * 4);
@@ -271,8 +264,6 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_knn = take((size_t)B * maxKnn * 4);
     p.o_knn2 = take((size_t)B * maxKnn * 4);
     p.o_knns = take(maxKs + 256);
-    p.o_hint = take((size_t)B * maxKnn * 4);   // composed hints of a layer that follows a down-sampling layer
-    p.o_inv = take((size_t)B * N * 4);         // inverse of that layer's FPS selection
     p.o_fA = take((size_t)B * maxF * 4);
     p.o_fB = take((size_t)B * maxF * 4);
     p.o_msg = take((size_t)B * maxF * 4);
@@ -357,22 +348,16 @@ struct EdgeTables { const float* Tq; int ldp, ldq, NQ, qvr; const float* cur = n
 
 // where the table(s) of layer i live in T and how the edge kernel reads them (no launch)
 static bool edge_fused(const ls_model* m, int i) {
-    // LS_EDGE_FUSE_Q=0: destination side as table columns (A/B).  The fused kernel forms its products from f16 pieces like the default
-    // GEMM mode; under LS_GEMM_MODE=bf16x3 / LS_GEMM_BF16X3=0 (any fp32 range, or the fp32-MFMA kernels) the table path is kept so that
-    // every product of the layer is formed the same way
-    static const bool fuse_q = !(getenv("LS_EDGE_FUSE_Q") && atoi(getenv("LS_EDGE_FUSE_Q")) == 0) &&
-                               !(getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) &&
-                               !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
-    return fuse_q && m->wq_planes[i];
+    // LS_OPT_EDGE_FUSE_Q = 0: destination side as table columns.  The fused kernel forms its products from f16 pieces like the default GEMM
+    // mode; under LS_GEMM_MODE=bf16x3 / fp32 (any fp32 range, or the fp32-MFMA kernels) the table path is kept so that every product of the layer
+    // is formed the same way
+    return m->fuse_q && gemm_mode() == 0 && m->wq_planes[i];
 }
-// table-free path of the 32-point attention layers (edge_fused.hip).  LS_EDGE_FUSE_T=0: the table GEMM + edge_attn_v4_kernel pair (A/B); like the
-// destination-side fusion it forms its products from f16 pieces, so the table path is kept under LS_GEMM_MODE=bf16x3 / LS_GEMM_BF16X3=0.
+// table-free path of the 32-point attention layers (edge_fused.hip).  LS_OPT_EDGE_FUSE_T = 0: the table GEMM + edge_attn_v4_kernel pair; like the
+// destination-side fusion it forms its products from f16 pieces, so the table path is kept under LS_GEMM_MODE=bf16x3 / fp32.
 static bool edge_fused_t(const ls_model* m, int i, int B, int Ns, int Nd, bool has_rows) {
-    static const bool on = !(getenv("LS_EDGE_FUSE_T") && atoi(getenv("LS_EDGE_FUSE_T")) == 0) &&
-                           !(getenv("LS_GEMM_MODE") && !strcmp(getenv("LS_GEMM_MODE"), "bf16x3")) &&
-                           !(getenv("LS_GEMM_BF16X3") && atoi(getenv("LS_GEMM_BF16X3")) == 0);
     const ls_model_desc& d = m->d;
-    if (!on || !m->wt_planes[i] || i < d.atten_start_layer) return false;
+    if (!m->fuse_t || gemm_mode() != 0 || !m->wt_planes[i] || i < d.atten_start_layer) return false;
     const int Cin = layer_cin(d, i), Co = d.feat_dim[i];
     return edge_ft_supported(Co, Cin, Ns, Nd, d.atten_head_c, has_rows) &&
            edge_ft_scratch_bytes(B, Ns, Nd, Cin, Co, has_rows) <= edge_table_floats(d, i, B, Ns, Nd, has_rows) * sizeof(float);
@@ -431,8 +416,7 @@ static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_
 // gather + VN activation + mean-pool | attention of layer i >= 1 over the tables
 // rm_out (nullable) [B*Nd*3]: receives max|out[row, :]| when the kernel taken can write it; *rm_written says whether it did
 static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, const int32_t* knn, const int32_t* dst_rows, int B, int Nd,
-                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr, int* rm_parts = nullptr,
-                      const int32_t* perm = nullptr) {   // perm (nullable) [B*Nd]: processing order of the destination points (morton_order_kernel)
+                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr, int* rm_parts = nullptr) {
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
     if (rm_written) *rm_written = false;
@@ -450,14 +434,14 @@ static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, 
         }
         if (et.cur) {
             if (rm_written) *rm_written = rm_out != nullptr;
-            return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out, perm);
+            return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
         }
         if (!edge_attn_emits_rowmax(Co, et.ldp, et.ldq)) rm_out = nullptr;
         if (rm_written) *rm_written = rm_out != nullptr;
         return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
     }
     PROF(LS_K_EDGE_POOL, i, st);
-    return edge_pool_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, out, st, perm);
+    return edge_pool_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, out, st);
 }
 // residual global conv of layer i (vec_dgcnn_atten.py:222-225): out = VecLNA_G(cat(msg, mean_n msg))
 static size_t global_conv_gws_floats(const ls_model_desc& d, int i, int B, int Nd) {
@@ -473,8 +457,7 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
     const float* Wg = m->blob + d.off_glob[i];
     if (rm_written) *rm_written = false;
     int rc;
-    static const bool mean_fused = !(getenv("LS_GLOB_MEAN_FUSE") && atoi(getenv("LS_GLOB_MEAN_FUSE")) == 0);   // A/B: mean + 192-row GEMM (+ split-K reduce) launches
-    if (gemm_vn_supported(B * Nd * 3, Co, Co) && mean_fused) {
+    if (m->glob_fuse && gemm_vn_supported(B * Nd * 3, Co, Co)) {
         // per-instance part: mean over the points and its contraction with the W_b / Wd W_b rows in ONE launch (pointwise.hip) ...
         { PROF(LS_K_MEAN, i, st); rc = glob_mean_gemv_launch(msg, B, Nd, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st); }
         if (rc != LS_OK) return rc;
@@ -488,17 +471,6 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
     }
     { PROF(LS_K_MEAN, i, st); rc = mean_points_launch(msg, B, Nd, Co, g, st); }
     if (rc != LS_OK) return rc;
-    if (gemm_vn_supported(B * Nd * 3, Co, Co)) {
-        // per-instance part first, then ONE launch for the per-point contraction + the VN activation (gemm.hip: gemm_vn_kernel)
-        PROF(LS_K_GEMM_GLOB, i, st);
-        rc = gemm_dispatch_small(g, Co, Wg, Co, nullptr, G, 4 * Co, B * 3, 4 * Co, Co, 0, gws, st);
-        if (rc != LS_OK) return rc;
-        GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
-        ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? rm_msg_parts : 0;
-        ax.out_rowmax = rm_out;
-        if (rm_written) *rm_written = rm_out != nullptr;
-        return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st, ax);
-    }
     {
         PROF(LS_K_GEMM_GLOB, i, st);
         GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
@@ -661,16 +633,11 @@ int ls_model_create(const ls_model_desc* desc, const float* blob_host, ls_model_
     LS_REQUIRE(desc->blob_floats > 0, "model_create: empty blob");
     ls_model* m = new ls_model();
     m->d = *desc;
-    if (const char* ev = getenv("LS_GEMM_OVERLAP")) m->overlap_gemm = atoi(ev) != 0;
-    if (const char* ev = getenv("LS_DEBUG_LAYERS")) m->debug_layers = atoi(ev);
     if (const char* ev = getenv("LS_ENCODE_GRAPH")) m->use_graph = atoi(ev) != 0;
-    if (const char* ev = getenv("LS_FPS_SIDE")) m->fps_side = atoi(ev) != 0;
-    if (const char* ev = getenv("LS_KNN_SEEDS")) m->seed_knn = atoi(ev) != 0;
-    if (const char* ev = getenv("LS_KNN_HINTS")) m->hint_policy = !strcmp(ev, "prev") ? 1 : (!strcmp(ev, "auto") ? 2 : 0);
     if (const char* ev = getenv("LS_SDF_BF16X2")) m->sdf_bf16x2 = atoi(ev) != 0;
-    if (const char* ev = getenv("LS_KNN_FILTER")) m->knn_filter = atoi(ev) != 0;
-    if (const char* ev = getenv("LS_ORDER")) m->order_pts = atoi(ev) != 0;
 #ifdef LS_DEV_KNOBS   // only in the variant library scripts/dev/marginal_cost.sh builds (-DLS_DEV_KNOBS): the release library cannot be made to skip work
+    if (const char* ev = getenv("LS_FPS_SIDE")) m->fps_side = atoi(ev) != 0;
+    if (const char* ev = getenv("LS_DEBUG_LAYERS")) m->debug_layers = atoi(ev);
     if (const char* ev = getenv("LS_SKIP")) {
         const char* names[] = {"knn", "attn", "pool", "l0", "tables", "glob", "fps", "tail", "prologue", "hi32"};   // hi32: the attention of the 32-point layers only (with their operand images)
         for (int i = 0; i < 10; ++i) if (strstr(ev, names[i])) m->skip_mask |= 1u << i;
@@ -779,6 +746,11 @@ int ls_model_set_option(ls_model_t* m, int option, int value) {
         case LS_OPT_SDF_BF16X2: m->sdf_bf16x2 = value != 0; return LS_OK;
         case LS_OPT_ENCODE_GRAPH: m->use_graph = value != 0; return LS_OK;
         case LS_OPT_EDGE_STAGED: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_EDGE_STAGED takes 0, 1 or 2"); m->edge_staged = value; return LS_OK;
+        case LS_OPT_EDGE_FUSE_Q: m->fuse_q = value != 0; return LS_OK;
+        case LS_OPT_EDGE_FUSE_T: m->fuse_t = value != 0; return LS_OK;
+        case LS_OPT_GLOB_FUSE: m->glob_fuse = value != 0; return LS_OK;
+        case LS_OPT_DEBUG_EDGE: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_DEBUG_EDGE takes 0, 1 or 2"); m->debug_edge = value; return LS_OK;
+        case LS_OPT_GEMM_OVERLAP: m->overlap_gemm = value != 0; return LS_OK;
         default: set_error("model_set_option: unknown option %d", option); return LS_ERR_INVALID;
     }
 }
@@ -790,6 +762,11 @@ int ls_model_get_option(const ls_model_t* m, int option, int* value) {
         case LS_OPT_SDF_BF16X2: *value = m->sdf_bf16x2 ? 1 : 0; return LS_OK;
         case LS_OPT_ENCODE_GRAPH: *value = m->use_graph ? 1 : 0; return LS_OK;
         case LS_OPT_EDGE_STAGED: *value = m->edge_staged; return LS_OK;
+        case LS_OPT_EDGE_FUSE_Q: *value = m->fuse_q ? 1 : 0; return LS_OK;
+        case LS_OPT_EDGE_FUSE_T: *value = m->fuse_t ? 1 : 0; return LS_OK;
+        case LS_OPT_GLOB_FUSE: *value = m->glob_fuse ? 1 : 0; return LS_OK;
+        case LS_OPT_DEBUG_EDGE: *value = m->debug_edge; return LS_OK;
+        case LS_OPT_GEMM_OVERLAP: *value = m->overlap_gemm ? 1 : 0; return LS_OK;
         default: set_error("model_get_option: unknown option %d", option); return LS_ERR_INVALID;
     }
 }
@@ -825,14 +802,6 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
         else rc = prologue_launch(x, B, N, pts0, centroid, scale0, F(p.o_pro), st);
     }
     if (rc != LS_OK) return rc;
-    // processing order of each level's points for the gather kernels (levels of at least 64 and at most 1024 points): level 0 here, the others
-    // behind their FPS launch on the side stream
-    auto ordered = [&](int level) { return m->order_pts && p.levelN[level] >= 64 && p.levelN[level] <= 1024; };
-    if (ordered(0)) {
-        rc = morton_order_launch(pts0, B, p.levelN[0], I(p.o_perm[0]), st);
-        if (rc != LS_OK) return rc;
-    }
-
     // ---- FPS chain on the side stream: depends on xyz only, overlaps with layers 0..first down-sample
     hipStream_t fs = m->fps_side ? m->side : st;
     if (p.nlevels > 0) {
@@ -849,10 +818,6 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
                 rc = (skip & SK_FPS) ? LS_OK : fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), nullptr, 0, fs);
             }
             if (rc != LS_OK) return rc;
-            if (ordered(l + 1) && !(skip & SK_FPS)) {
-                rc = morton_order_launch(F(p.o_pts[l + 1]), B, p.levelN[l + 1], I(p.o_perm[l + 1]), fs);
-                if (rc != LS_OK) return rc;
-            }
             if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_fps[l], fs));
         }
         if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_join, fs));
@@ -864,18 +829,15 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
     float* T = F(p.o_T);
     bool joined = false;
     size_t knn_off = 0, fps_off = 0;
-    const int32_t* prev_knn = nullptr;
-    const int32_t* prev_rows = nullptr;   // the previous layer's FPS selection (rows of its source set), if it down-sampled
     const float* cur_rm = nullptr;        // row maxima of `cur` ([rows][cur_rm_parts]) when the kernel that wrote it emitted them (GemmAux)
     int cur_rm_parts = 0;
-    int dst_level = 0;      // level of the current layer's destination points (0 = the input cloud)
     for (int i = 0; i < p.L; ++i) {
         if (i == m->debug_layers) {
             static bool printed = false;
             if (!printed) {
                 printed = true;
-                fprintf(stderr, "LS_PLAN knn=%zu knn2=%zu knns=%zu hint=%zu inv=%zu fA=%zu fB=%zu msg=%zu T=%zu TG=%zu g=%zu G=%zu Tc=%zu gws=%zu total=%zu\n",
-                        p.o_knn, p.o_knn2, p.o_knns, p.o_hint, p.o_inv, p.o_fA, p.o_fB, p.o_msg, p.o_T, p.o_TG, p.o_g, p.o_G, p.o_Tc, p.o_gws, p.total);
+                fprintf(stderr, "LS_PLAN knn=%zu knn2=%zu knns=%zu fA=%zu fB=%zu msg=%zu T=%zu TG=%zu g=%zu G=%zu Tc=%zu gws=%zu total=%zu\n",
+                        p.o_knn, p.o_knn2, p.o_knns, p.o_fA, p.o_fB, p.o_msg, p.o_T, p.o_TG, p.o_g, p.o_G, p.o_Tc, p.o_gws, p.total);
             }
             if (p.nlevels > 0 && !joined && m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
             return LS_OK;
@@ -887,9 +849,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             joined = p.level[i] == p.nlevels - 1;                                            // the last level joins the whole side chain
             dst_rows = trace_fps ? trace_fps + fps_off : I(p.o_fps[p.level[i] + 1]);
             fps_off += (size_t)B * Nd;
-            dst_level = p.level[i] + 1;
         }
-        const int32_t* perm = ordered(dst_level) ? I(p.o_perm[dst_level]) : nullptr;   // processing order of the destination points (same results either way)
         int32_t* knn = trace_knn ? trace_knn + knn_off : I((i & 1) ? p.o_knn2 : p.o_knn);  // ping-pong: layer i+1 is seeded by layer i
         knn_off += (size_t)B * Nd * 16;
         const bool attn = i >= d.atten_start_layer;
@@ -901,7 +861,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             { PROF(LS_K_KNN, i, st); rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
             if (rc != LS_OK) return rc;
             LS_REQUIRE(!attn, "encoder: attention at layer 0 unsupported (atten_start_layer >= 1)");
-            { PROF(LS_K_EDGE_L0, i, st); rc = (skip & SK_L0) ? LS_OK : edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st, perm); }
+            { PROF(LS_K_EDGE_L0, i, st); rc = (skip & SK_L0) ? LS_OK : edge_l0_launch(pts0, knn, W + d.off_l0, B, Ns, Co, d.neg_slope, mp, st); }
             if (rc != LS_OK) return rc;
         } else {
             const int Cin = p.Cin[i];
@@ -917,31 +877,19 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             else rc = edge_tables(m, i, cur, dst_rows, B, Ns, Nd, T, gs, et, cur_rm, cur_rm_parts);
             if (rc != LS_OK) return rc;
             if (m->overlap_gemm) LS_HIP_CHECK(hipEventRecord(m->ev_tab[i], gs));
-            { PROF(LS_K_KNN, i, st); // hints: the previous layer's list of the same point, valid when that layer did not down-sample (its destination set
-                // == this layer's source set, so its indices address this layer's candidates directly)
-                // Measured per layer (bench, B = 64): the previous layer's lists are the better hints where features change little
-                // (C = 32 layers 1, 2: 0.136 / 0.106 ms vs 0.166 / 0.121 ms with auto hints); after a down-sampling layer (composed
-                // two-hop hints) and on the C = 64 layers the sweep's own class-winner hints are tighter (layer 3: 0.144 vs 0.207 ms,
-                // layer 4: 0.088 vs 0.100 ms).
-                const bool want_prev = m->seed_knn && prev_knn && m->hint_policy != 2 && (m->hint_policy == 1 || Cin == 32);
-                const int32_t* seeds = (want_prev && p.level[i - 1] < 0) ? prev_knn : nullptr;
-                const unsigned kflags = flags | (m->knn_filter ? 0u : LS_FLAG_KNN_VALU_ONLY);
-                if (want_prev && prev_rows && knn_would_sweep(Cin, Ns, kflags)) {
-                    // the previous layer down-sampled: map its lists into this layer's (smaller) source set, two hops deep
-                    rc = knn_compose_hints_launch(prev_knn, prev_rows, B, Ns, p.Ns[i - 1], I(p.o_inv), I(p.o_hint), st);
-                    if (rc != LS_OK) return rc;
-                    seeds = I(p.o_hint);
-                }
-                rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, kflags, knn, nullptr, ws + p.o_knns, seeds, Ns, 1, st); }
+            {   // (no hints: the fused k-NN kernel derives its thresholds from its own sweep -- knn_mfma.hip)
+                PROF(LS_K_KNN, i, st);
+                rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(cur, cur, dst_rows, B, Nd, Ns, Ns, Cin, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st);
+            }
             if (rc != LS_OK) return rc;
-            if (m->profiling && m->knn_stats && !(skip & SK_KNN) && knn_would_sweep(Cin, Ns, flags | (m->knn_filter ? 0u : LS_FLAG_KNN_VALU_ONLY))) {
+            if (m->profiling && m->knn_stats && !(skip & SK_KNN) && knn_would_sweep(Cin, Ns, flags)) {
                 // (outside the launch's event bracket) how many candidates got a canonical distance: ls_profile_knn_stats
                 rc = knn_sweep_stats_launch(ws + p.o_knns, B, Nd, Ns, Ns, m->knn_stats + 2 * i, st);
                 if (rc != LS_OK) return rc;
             }
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if ((skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) || ((skip & SK_HI32) && Nd == 32)) rc = LS_OK;
-            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts, perm);
+            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts);
             if (rc != LS_OK) return rc;
         }
         cur_rm = nullptr; cur_rm_parts = 0;
@@ -954,8 +902,6 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             if (out_rm) { cur_rm = F(p.o_rm_out[i & 1]); cur_rm_parts = Co / 32; }
         }
         std::swap(cur, nxt);
-        prev_knn = knn;
-        prev_rows = dst_rows;
     }
     if (p.nlevels > 0 && !joined && m->fps_side) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
 
@@ -1054,14 +1000,13 @@ static int edgeconv_export(ls_model_t* m, int layer, const float* src_f, const i
     if (!workspace || workspace_bytes < need) { set_error("%s: workspace %zu < required %zu", who, workspace_bytes, need); return LS_ERR_WORKSPACE; }
     EdgeTables et;
     int rc = LS_OK;
-    const char* dbg = getenv("LS_DEBUG_EDGE");   // race hunting: "notab" = tables already in the workspace, "tabonly" = stop after them
-    if (dbg && !strcmp(dbg, "notab")) {
+    if (m->debug_edge == 2) {   // LS_OPT_DEBUG_EDGE: the tables are already in the workspace
         et = edge_tables_layout(m, layer, src_f, dst_rows, B, Ns, Nd, (float*)workspace);
     } else {
         rc = edge_tables(m, layer, src_f, dst_rows, B, Ns, Nd, (float*)workspace, st, et);
     }
     if (rc != LS_OK) return rc;
-    if (dbg && !strcmp(dbg, "tabonly")) return LS_OK;
+    if (m->debug_edge == 1) return LS_OK;
     return edge_apply(m, layer, (const float*)workspace, et, knn, dst_rows, B, Nd, Ns, out, st);
 }
 int ls_vn_edgeconv_pool_f32(ls_model_t* m, int layer, const float* src_f, const int32_t* knn, const int32_t* dst_rows, int B, int Ns, int Nd,

@@ -438,66 +438,6 @@ int scatter_codes_launch(const float* packed, int B, int c, float* z_so3, float*
 }
 
 size_t prologue_scratch_floats(int B) { (void)B; return 0; }
-// ---------------------------------------------------------------------------------------------------------------- processing order
-// The ORDER in which an instance's destination points are handed to the gather kernels (round 4).  The encoder's point sets are in FPS order --
-// spatially scattered by construction -- so the 16 points of an edge-kernel workgroup had ~230 DISTINCT neighbour rows among their 16 x 16
-// neighbours and every gather went to the L2 (the attention kernel with its arithmetic removed ran as long as the whole kernel: it is bound by
-// the L2 -> L1 path, 1.6 GB per launch).  The feature-space k-NN graphs are spatially local (features describe local geometry): in Morton (Z-curve)
-// order of the xyz coordinates 16 consecutive points share their neighbours -- 62 - 90 distinct rows per group at layers 0 - 3 -- and the rows are
-// served by the CU's own L1.  Only the assignment of points to workgroups changes: every point's arithmetic is the same, the results are bit-identical.
-// MEASURED NEUTRAL (round 4) and therefore off by default (LS_ORDER=1 turns it on): see ls_model::order_pts.
-// perm[b N + slot] = b N + (index of the slot-th point in Morton order); one workgroup per instance, N <= 1024: 30-bit keys (10 bits per axis on the
-// instance's bounding box) with the point index in the low word (unique keys -> a deterministic order), bitonic sort in LDS.
-__global__ __launch_bounds__(1024) void morton_order_kernel(const float* __restrict__ pts, int N, int32_t* __restrict__ perm) {
-    __shared__ unsigned long long keys[1024];
-    __shared__ float red[6][16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* p = pts + (size_t)b * N * 3;
-    const bool live = tid < N;
-    const float x = live ? p[tid * 3] : 0.f, y = live ? p[tid * 3 + 1] : 0.f, z = live ? p[tid * 3 + 2] : 0.f;
-    float mn[3] = {live ? x : INFINITY, live ? y : INFINITY, live ? z : INFINITY}, mx[3] = {live ? x : -INFINITY, live ? y : -INFINITY, live ? z : -INFINITY};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
-        if (lane == 0) { red[a][wave] = mn[a]; red[3 + a][wave] = mx[a]; }
-    }
-    __syncthreads();
-    unsigned q[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float lo = red[a][0], hi = red[3 + a][0];
-#pragma unroll
-        for (int w = 1; w < 16; ++w) { lo = fminf(lo, red[a][w]); hi = fmaxf(hi, red[3 + a][w]); }
-        const float v = a == 0 ? x : (a == 1 ? y : z);
-        const float t = (v - lo) / fmaxf(hi - lo, 1e-30f) * 1023.0f;
-        q[a] = (unsigned)fminf(fmaxf(t, 0.0f), 1023.0f);          // (NaN coordinates land in cell 0: any order is a valid order)
-    }
-    auto part = [](unsigned v) { v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; return (v | (v << 2)) & 0x09249249u; };
-    const unsigned code = part(q[0]) | (part(q[1]) << 1) | (part(q[2]) << 2);
-    keys[tid] = live ? (((unsigned long long)code << 32) | (unsigned)tid) : ~0ull;
-    int NP = 64;
-    while (NP < N) NP <<= 1;
-    __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int partner = tid ^ j;
-            if (tid < NP && partner > tid) {
-                const unsigned long long a = keys[tid], c = keys[partner];
-                const bool up = (tid & k) == 0;
-                if ((a > c) == up) { keys[tid] = c; keys[partner] = a; }
-            }
-            __syncthreads();
-        }
-    if (live) perm[(size_t)b * N + tid] = b * N + (int)(unsigned)keys[tid];
-}
-int morton_order_launch(const float* pts, int B, int N, int32_t* perm, hipStream_t st) {
-    LS_REQUIRE(N >= 1 && N <= 1024, "morton_order: N=%d unsupported (1..1024)", N);
-    hipLaunchKernelGGL(morton_order_kernel, dim3(B), dim3(1024), 0, st, pts, N, perm);
-    LS_LAUNCH_CHECK();
-    return LS_OK;
-}
-
 int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, float* /*unused*/, hipStream_t st) {
     LS_REQUIRE(N >= 3 && N <= 8192, "prologue: N=%d out of range (3..8192)", N);
     hipLaunchKernelGGL(prologue_kernel, dim3(B), dim3(256), (size_t)4 * N * sizeof(float), st, x, N, pts, centroid, scale0);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """dev: the attention layers 2 - 4 of the bench batch (B = 64 x 1024 points, released widths) ALONE -- table GEMM once, then the attention kernel `reps`
-times (LS_DEBUG_EDGE=notab) -- under each LS_OPT_EDGE_STAGED mode given: hipEvent time per launch.  Run it under rocprofv3 --pmc for counters
+times (LS_OPT_DEBUG_EDGE = 2) -- under each LS_OPT_EDGE_STAGED mode given: hipEvent time per launch.  Run it under rocprofv3 --pmc for counters
 (scripts/dev/attn_counters.sh)."""
 import argparse
 import os
@@ -46,16 +46,16 @@ def main():
     for mode in [int(v) for v in args.modes.split(",")]:
         m.set_option(_lib.OPT_EDGE_STAGED, mode)
         for i in [int(v) for v in args.layers.split(",")]:
-            os.environ.pop("LS_DEBUG_EDGE", None)
+            m.set_option(_lib.OPT_DEBUG_EDGE, 0)
             ref = m.edgeconv(i, src[i], knn_l[i], rows[i])          # table + attention (also warms up)
-            os.environ["LS_DEBUG_EDGE"] = "notab"
+            m.set_option(_lib.OPT_DEBUG_EDGE, 2)                    # the attention kernel only, on the tables in the workspace
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
             for a, b in evs:
                 a.record()
                 out = m.edgeconv(i, src[i], knn_l[i], rows[i])
                 b.record()
             torch.cuda.synchronize()
-            os.environ.pop("LS_DEBUG_EDGE", None)
+            m.set_option(_lib.OPT_DEBUG_EDGE, 0)
             ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
             res[(mode, i)] = ts[len(ts) // 2]
             assert os.environ.get("LS_LIB_PATH") or torch.equal(out, ref)      # (timing-variant libraries compute garbage on purpose)

@@ -10,8 +10,8 @@ splits the dispatch stream of the counter CSVs at the markers.
     done
     python scripts/pmc_ops_summary.py gpurun_out/pmc > profiles/pmc_latest.json
 
-The operators are the C-ABI per-layer exports (ls_knn_f32 with the encoder's hint policy, ls_vn_edgeconv_* split into its table
-GEMM and its gather kernel by LS_DEBUG_EDGE, ls_vn_lna_f32, ls_encoder_tail_f32, FPS, prologue) on the REAL per-layer tensors of
+The operators are the C-ABI per-layer exports (ls_knn_f32, ls_vn_edgeconv_* split into its table
+GEMM and its gather kernel by LS_OPT_DEBUG_EDGE, ls_vn_lna_f32, ls_encoder_tail_f32, FPS, prologue) on the REAL per-layer tensors of
 the bench batch (computed once by the same operators).  Without rocprofv3 the script also prints hipEvent timings per operator."""
 import argparse
 import json
@@ -68,10 +68,7 @@ def main():
     for i in range(L):
         f = src[i].reshape(B, -1, 3, 1) if i == 0 else src[i]
         Cin = 1 if i == 0 else cfg["feat_dim"][i - 1]
-        seeds = None
-        if i >= 1 and Cin == 32 and (i - 1) not in ds:      # the encoder's default hint policy ("mixed"): previous layer's lists on the C = 32 layers
-            seeds = knn_l[i - 1] if rows[i] is None else torch.gather(knn_l[i - 1], 1, rows[i].long()[..., None].expand(-1, -1, 16)).contiguous()
-        todo.append((f"knn[{i}]", lambda i=i, f=f, seeds=seeds: ops.knn(f, f, 16, dst_rows=rows[i], seeds=seeds)))
+        todo.append((f"knn[{i}]", lambda i=i, f=f: ops.knn(f, f, 16, dst_rows=rows[i])))
         if i == 0:
             todo.append(("edge_l0[0]", lambda: m.edgeconv(0, src[0], knn_l[0])))
         else:
@@ -81,14 +78,14 @@ def main():
             kind = "edge_attn" if i >= cfg["atten_start_layer"] else "edge_pool"
 
             def tab(i=i, ws=ws):
-                os.environ["LS_DEBUG_EDGE"] = "tabonly"
+                m.set_option(_lib.OPT_DEBUG_EDGE, 1)      # the table GEMM only
                 m.edgeconv(i, src[i], knn_l[i], rows[i], _ws=ws)
-                os.environ.pop("LS_DEBUG_EDGE")
+                m.set_option(_lib.OPT_DEBUG_EDGE, 0)
 
             def gather(i=i, ws=ws):
-                os.environ["LS_DEBUG_EDGE"] = "notab"
+                m.set_option(_lib.OPT_DEBUG_EDGE, 2)      # the edge kernel only, on the tables already in the workspace
                 m.edgeconv(i, src[i], knn_l[i], rows[i], _ws=ws)
-                os.environ.pop("LS_DEBUG_EDGE")
+                m.set_option(_lib.OPT_DEBUG_EDGE, 0)
             todo += [(f"gemm_edge[{i}]", tab), (f"{kind}[{i}]", gather)]
         if i >= g0:
             todo.append((f"global_conv[{i}]", lambda i=i: m.vn_lna_global(i, msg[i])))

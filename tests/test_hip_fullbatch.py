@@ -114,60 +114,54 @@ def test_encode_graph_replay_is_bit_identical():
         sp.hip_model().set_option(_lib.OPT_ENCODE_GRAPH, 0)
 
 
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _codes_sha(sp, B, seed):
+    import hashlib
+    x = synth.make_instances(B, 1024, seed=seed)
+    x = (x if isinstance(x, torch.Tensor) else x[0]).to(_dev())
+    with torch.no_grad():
+        c = sp.encode(x)
+    return hashlib.sha1(b"".join(c[k].cpu().numpy().tobytes() for k in ("z_so3", "z_inv", "s", "t"))).hexdigest()
+
+
 def test_fused_destination_side_equals_table_path_bit_for_bit():
     """Attention layers 2 - 4 compute the destination-side column groups inside the edge kernel (edge_attn_fq_kernel: f16-split MFMA
-    product per workgroup) instead of reading them from the table the GEMM wrote (LS_EDGE_FUSE_Q=0).  Same products, same
-    accumulation order, same additions afterwards: the codes of the released-width encoder must be IDENTICAL, ragged batch included."""
-    import hashlib
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import hashlib, torch\n"
-            "from livingscenes_amd import synth\n"
-            "from livingscenes_amd.model_utils import Shape_Prior\n"
-            "dev = torch.device('cuda:0')\n"
-            "ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()\n"
-            "sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=dev)\n"
-            "for B, seed in ((7, 3), (64, 1000)):\n"
-            "    x = synth.make_instances(B, 1024, seed=seed)\n"
-            "    x = (x if isinstance(x, torch.Tensor) else x[0]).to(dev)\n"
-            "    with torch.no_grad():\n"
-            "        c = sp.encode(x)\n"
-            "    print(hashlib.sha1(b''.join(c[k].cpu().numpy().tobytes() for k in ('z_so3', 'z_inv', 's', 't'))).hexdigest())\n")
+    product per workgroup) instead of reading them from the table the GEMM wrote (ls_model_set_option(LS_OPT_EDGE_FUSE_Q, 0)).  Same products,
+    same accumulation order, same additions afterwards: the codes of the released-width encoder must be IDENTICAL, ragged batch included."""
+    from livingscenes_amd import _lib
+    from livingscenes_amd.model_utils import Shape_Prior
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=_dev())
+    hip = sp.hip_model()
     outs = []
-    for env in ({}, {"LS_EDGE_FUSE_Q": "0"}):
-        r = subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
-        outs.append([l for l in r.stdout.split() if len(l) == 40])
-    assert len(outs[0]) == 2 and outs[0] == outs[1]
+    for mode in (1, 0):
+        prev = hip.set_option(_lib.OPT_EDGE_FUSE_Q, mode)
+        outs.append([_codes_sha(sp, B, seed) for B, seed in ((7, 3), (64, 1000))])
+        hip.set_option(_lib.OPT_EDGE_FUSE_Q, prev)
+    assert outs[0] == outs[1]
 
 
 def test_fused_global_conv_matches_the_two_launch_path():
     """The residual global conv as one launch (gemm_vn_kernel: the per-point GEMM with the VN activation as its epilogue) against
-    GEMM -> table -> vn_act_rows (LS_GLOB_FUSE=0): same products in the same order, same activation formula.  Compared through the
+    GEMM -> table -> vn_act_rows (LS_OPT_GLOB_FUSE = 0): same products in the same order, same activation formula.  Compared through the
     operator export on released widths (layers 2, 4, 6), ragged point counts included."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import hashlib, torch, numpy as np\n"
-            "from livingscenes_amd import synth\n"
-            "from livingscenes_amd.model_utils import Shape_Prior\n"
-            "dev = torch.device('cuda:0')\n"
-            "ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()\n"
-            "sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=dev)\n"
-            "hip = sp.hip_model()\n"
-            "g = torch.Generator().manual_seed(5)\n"
-            "for layer, B, N in ((2, 3, 512), (2, 2, 333), (4, 5, 128), (6, 7, 32), (6, 1, 11)):\n"
-            "    C = ecfg['feat_dim'][layer]\n"
-            "    msg = torch.randn(B, N, 3, C, generator=g).to(dev)\n"
-            "    out = hip.vn_lna_global(layer, msg)\n"
-            "    np.save(f'/tmp/_ls_glob_{os.environ.get(\"LS_GLOB_FUSE\", \"1\")}_{layer}_{B}_{N}.npy', out.cpu().numpy())\n")
-    code = "import os\n" + code
-    for env in ({"LS_GLOB_FUSE": "1"}, {"LS_GLOB_FUSE": "0"}):
-        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root)
+    from livingscenes_amd import _lib
+    from livingscenes_amd.model_utils import Shape_Prior
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=_dev())
+    hip = sp.hip_model()
+    g = torch.Generator().manual_seed(5)
     for layer, B, N in ((2, 3, 512), (2, 2, 333), (4, 5, 128), (6, 7, 32), (6, 1, 11)):
-        a, b = np.load(f"/tmp/_ls_glob_1_{layer}_{B}_{N}.npy"), np.load(f"/tmp/_ls_glob_0_{layer}_{B}_{N}.npy")
+        C = ecfg["feat_dim"][layer]
+        msg = torch.randn(B, N, 3, C, generator=g).to(_dev())
+        a = hip.vn_lna_global(layer, msg).cpu().numpy()
+        prev = hip.set_option(_lib.OPT_GLOB_FUSE, 0)
+        b = hip.vn_lna_global(layer, msg).cpu().numpy()
+        hip.set_option(_lib.OPT_GLOB_FUSE, prev)
         assert np.isfinite(a).all()
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), (layer, B, N, np.abs(a - b).max())
 

@@ -53,15 +53,15 @@ def test_knn_bit_exact(shape, contract):
 
 
 @pytest.mark.parametrize("contract", [0, 1])
-@pytest.mark.parametrize("case", ["tiny", "one_chunk", "multi_chunk", "ties", "rows", "tiled"])
+@pytest.mark.parametrize("case", ["tiny", "one_chunk", "multi_chunk", "ties", "rows", "few"])
 def test_knn_xyz_wave_kernel_bit_exact(case, contract, monkeypatch):
     """Raw-cloud (C == 1) k-NN: wave-per-query kernel incl. fewer candidates than K, several 1024-candidate chunks, more exact
-    ties than one sorting round holds, query rows, and the tiled kernel kept for A/B."""
+    ties than one sorting round holds, query rows."""
     from livingscenes_amd import ops
     from oracle import canon
     rng = np.random.default_rng(11)
     B, Nd, Ns = {"tiny": (3, 7, 9), "one_chunk": (2, 300, 1024), "multi_chunk": (2, 130, 2500), "ties": (1, 40, 700),
-                 "rows": (2, 50, 1024), "tiled": (2, 100, 150)}[case]
+                 "rows": (2, 50, 1024), "few": (2, 100, 150)}[case]
     src = rng.standard_normal((B, Ns, 3, 1)).astype(np.float32)
     dst = rng.standard_normal((B, Nd, 3, 1)).astype(np.float32)
     dst_rows = None
@@ -75,18 +75,6 @@ def test_knn_xyz_wave_kernel_bit_exact(case, contract, monkeypatch):
     else:
         ref, refd = canon.knn_c(dst, src, 16, contract=contract, return_dist=True)
         dst_t = torch.from_numpy(dst).to(_dev())
-    if case == "tiled":
-        import subprocess, sys
-        code = ("import numpy as np, torch; from livingscenes_amd import ops; d = np.load(r'%s');"
-                "i = ops.knn(torch.from_numpy(d['dst']).cuda(), torch.from_numpy(d['src']).cuda(), 16, flags=int(d['c']));"
-                "assert np.array_equal(i.cpu().numpy(), d['ref'])")
-        import tempfile, os
-        with tempfile.TemporaryDirectory() as td:
-            f = os.path.join(td, "c.npz")
-            np.savez(f, dst=dst, src=src, ref=ref, c=contract)
-            env = dict(os.environ, LS_KNN_XYZ_TILED="1")
-            subprocess.run([sys.executable, "-c", code % f], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        return
     idx, dist = ops.knn(dst_t, torch.from_numpy(src).to(_dev()), 16, flags=contract, return_dist=True,
                         dst_rows=None if dst_rows is None else torch.from_numpy(dst_rows).to(_dev()))
     assert np.array_equal(idx.cpu().numpy(), ref)
@@ -256,16 +244,6 @@ def test_fps_raw_cloud_bucketed_scan_bit_exact(contract):
                           canon.fps_c(q, 300, lengths=lq))
 
 
-def test_fps_one_wave_switch():
-    """LS_FPS_ONE_WAVE=1 keeps the one-wave kernel for 256..2048-point clouds (A/B): same indices."""
-    import os, subprocess, sys
-    code = ("import numpy as np, torch; from livingscenes_amd import ops; from oracle import canon;"
-            "p = np.random.default_rng(4).standard_normal((2, 1024, 3)).astype(np.float32);"
-            "assert np.array_equal(ops.fps(torch.from_numpy(p).cuda(), 512).cpu().numpy(), canon.fps_c(p, 512))")
-    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_FPS_ONE_WAVE="1"),
-                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-
-
 def test_fps_ragged_and_degenerate():
     from livingscenes_amd import ops
     from oracle import canon
@@ -304,8 +282,8 @@ def test_gemm_split_is_as_accurate_as_the_fp32_chain_and_row_invariant():
     carries (checked here where ls_gemm_f32 does not split K, K < 128; the decoder path, which never splits K, is covered by
     test_ragged_decode_and_batched_mise_equal_per_instance)."""
     from livingscenes_amd import ops
-    if os.environ.get("LS_GEMM_BF16X3") == "0":
-        pytest.skip("the fp32-MFMA A/B mode is an fp32 FMA chain itself (11 - 16 units on these operands)")
+    if os.environ.get("LS_GEMM_MODE") == "fp32":
+        pytest.skip("the fp32-MFMA mode is an fp32 FMA chain itself (11 - 16 units on these operands)")
     for K in (32, 64, 256, 768):
         g = torch.Generator().manual_seed(K)
         A = torch.randn(3000, K, generator=g) * torch.exp(2 * torch.randn(3000, K, generator=g))
@@ -320,35 +298,20 @@ def test_gemm_split_is_as_accurate_as_the_fp32_chain_and_row_invariant():
 
 
 def test_gemm_mode_switches():
-    """LS_GEMM_MODE=bf16x3 (six-MFMA split, any fp32 range -- here with operands far outside the f16 range) keeps the tolerance;
-    the pipelined kernel (K >= 128, default) and the two-barrier kernel (LS_GEMM_H2_SIMPLE=1) compute the same products in the same
-    order: bit-identical outputs, also on ragged shapes."""
-    import hashlib, os, subprocess, sys
+    """The process-wide arithmetic modes (gemm.hip: gemm_mode, read once from LS_GEMM_MODE): bf16x3 -- six-MFMA split, any fp32 range, here with
+    operands far outside the f16 range -- and fp32 -- exact fp32 FMA chains on v_mfma_f32_32x32x2_f32 -- keep the tolerance."""
+    import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import torch; from livingscenes_amd import ops; g = torch.Generator().manual_seed(1);"
             "A = torch.randn(700, 256, generator=g) * 3e6; W = torch.randn(200, 256, generator=g) * 1e-7;"
             "o = ops.gemm(A.cuda(), W.cuda()).cpu().double(); r = A.double() @ W.double().T;"
             "assert torch.isfinite(o).all() and ((o - r).abs().max() / r.abs().max()) < 2e-6")
     subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_GEMM_MODE="bf16x3"), cwd=root)
-    code = ("import hashlib, torch; from livingscenes_amd import ops\n"
-            "for (M, N, K) in ((4099, 500, 136), (20000, 512, 512), (333, 130, 128), (9000, 1024, 256)):\n"
-            "    g = torch.Generator().manual_seed(M + K)\n"
-            "    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.05; b = torch.randn(N, generator=g)\n"
-            "    print(hashlib.sha1(ops.gemm(A.cuda(), W.cuda(), b.cuda(), relu=True).cpu().numpy().tobytes()).hexdigest())\n")
-    outs = [subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), cwd=root, capture_output=True, text=True).stdout.split()
-            for env in ({}, {"LS_GEMM_H2_SIMPLE": "1"})]
-    assert len(outs[0]) == 4 and outs[0] == outs[1]
-
-
-def test_gemm_fp32_chain_switch():
-    """LS_GEMM_BF16X3=0 keeps the v_mfma_f32_32x32x2_f32 kernel (A/B timing): same tolerance."""
-    import os, subprocess, sys
     code = ("import torch; from livingscenes_amd import ops; g = torch.Generator().manual_seed(1);"
             "A = torch.randn(700, 96, generator=g); W = torch.randn(200, 96, generator=g);"
             "o = ops.gemm(A.cuda(), W.cuda()).cpu().double(); r = A.double() @ W.double().T;"
             "assert ((o - r).abs().max() / r.abs().max()) < 2e-6")
-    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_GEMM_BF16X3="0"),
-                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, LS_GEMM_MODE="fp32"), cwd=root)
 
 
 # ------------------------------------------------------------------------------------------------ prologue

@@ -109,28 +109,6 @@ def test_encoder_refuses_a_cloud_too_small_for_its_schedule():
     assert torch.isfinite(sp.encode(synth.make_instances(2, 512, seed=1).to(_dev()))["z_inv"]).all()
 
 
-def test_hint_policy_never_changes_the_codes(tmp_path):
-    """LS_KNN_HINTS=prev|auto (where a layer's k-NN thresholds come from) must give bit-identical codes: hints only steer the
-    filter, every list holds canonical distances."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, torch, numpy as np\n"
-            "from livingscenes_amd import synth\n"
-            "from livingscenes_amd.model_utils import Shape_Prior\n"
-            "ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()\n"
-            "sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=torch.device('cuda:0'))\n"
-            "emb = sp.encode(synth.make_instances(6, 1024, seed=5).cuda())\n"
-            "np.savez(sys.argv[1], **{k: v.cpu().numpy() for k, v in emb.items()})\n")
-    outs = {}
-    for pol in ("mixed", "prev", "auto"):
-        f = str(tmp_path / f"{pol}.npz")
-        subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, LS_KNN_HINTS=pol), cwd=root)
-        outs[pol] = np.load(f)
-    for pol in ("prev", "auto"):
-        for k in ("z_so3", "z_inv", "s", "t"):
-            assert np.array_equal(outs[pol][k], outs["mixed"][k]), (pol, k)
-
-
 def test_use_double_returns_float64_codes_of_the_fp32_path(small_prior):
     """Shape_Prior(use_double=True) (model_utils.py:148-152,166: fp64 encoder in the reference): the fp32 HIP encoder runs and the codes
     are float64 -- equal to the fp32 codes, and within 1e-4 of the oracle evaluated in fp64."""

@@ -10,7 +10,6 @@ import os
 import sys
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-os.environ.setdefault("LS_GEMM_OVERLAP", "0")   # as bench.py with steps in flight
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -36,6 +35,9 @@ def main():
     sps = [sp] + [Shape_Prior.from_state(ecfg, dcfg, sp.encoder.state_dict(), sp.decoder.F.state_dict(), device=dev)
                   for _ in range(nfl - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+    from livingscenes_amd import _lib
+    for s_ in sps:                                             # as bench.py with steps in flight
+        s_.hip_model().set_option(_lib.OPT_GEMM_OVERLAP, 0)
     scene = synth.make_scene_pair(n_obj, N, seed=1000)
     x = torch.cat([scene["ref"], scene["rescan"]], 0).transpose(1, 2).contiguous().to(dev)
 

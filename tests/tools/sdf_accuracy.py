@@ -2,7 +2,7 @@
 infrastructure, hence this lives under tests/).  Run once per GEMM mode:
     python tests/tools/sdf_accuracy.py                      # default: three-piece bf16 products
     LS_SDF_BF16X2=1 python tests/tools/sdf_accuracy.py      # opt-in two-piece mode
-    LS_GEMM_BF16X3=0 python tests/tools/sdf_accuracy.py     # fp32-MFMA kernel
+    LS_GEMM_MODE=fp32 python tests/tools/sdf_accuracy.py     # fp32-MFMA kernel
 """
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
