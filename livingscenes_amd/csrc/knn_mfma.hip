@@ -265,11 +265,13 @@ __device__ __noinline__ u64 kf_brute_row(const float* __restrict__ qrow, const f
 
 // Compiled for four waves per SIMD = two workgroups per CU (116 - 128 registers, no spills).  Measured (round 5): one workgroup per CU by LDS padding
 // 151 / 81 us at layers 1 / 2 against 110 / 71 us.
-#ifndef LS_KF_WPE
-#define LS_KF_WPE(TPW) 4
+#ifdef LS_KF_WPE_ALL            // dev A/B (scripts/dev/build_variants.py)
+#define LS_KF_WPE(TPW, FMA) LS_KF_WPE_ALL
+#else
+#define LS_KF_WPE(TPW, FMA) ((FMA) ? 3 : 4)      // (the fused-multiply-add variants -- LS_FLAG_CONTRACT_FMA, a secondary mode -- spill at four)
 #endif
 template <int CC, bool FMA, int TPW>
-__global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW)) void knn_fused_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf, const int32_t* __restrict__ dst_rows,
+__global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW, FMA)) void knn_fused_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf, const int32_t* __restrict__ dst_rows,
                                                                   const unsigned short* __restrict__ dq, const unsigned short* __restrict__ sq,
                                                                   const float* __restrict__ nrm_dst, const float* __restrict__ nrm_src,
                                                                   const float* __restrict__ isc_dst, const float* __restrict__ isc_src, int Nd, int dst_n,
