@@ -251,7 +251,9 @@ void ls_model_destroy(ls_model_t* m);
                                      0 = as table columns written by the table GEMM (the general path; also taken under LS_GEMM_MODE=bf16x3 / fp32) */
 #define LS_OPT_EDGE_FUSE_T 6      /* [1] the 32-point attention layers (released layers 5, 6) without a table (edge_fused.hip); 0 = table GEMM + edge kernel */
 #define LS_OPT_GLOB_FUSE 7        /* [1] residual global conv as one mean + GEMV launch and one GEMM + VN-activation launch (gemm.hip: gemm_vn_kernel);
-                                     0 = mean, GEMM -> table, per-instance GEMM, VN activation as separate launches (same products in the same order) */
+                                     0 = mean, GEMM -> table, per-instance GEMM, VN activation as separate launches (same products in the same order);
+                                     2 = as 1, and the operator export ls_vn_lna_f32 first takes the exact row maxima of its input, as the encoder's attention
+                                     kernels hand them to this conv (layers of 64 channels then run gemm_vn_direct_kernel: bit-identical, tests/) */
 #define LS_OPT_DEBUG_EDGE 8       /* [0] ls_vn_edgeconv_*: 1 = run the table GEMM only, 2 = run the edge kernel only on the tables already in the workspace
                                      (per-operator counter passes: scripts/pmc_ops.py); 0 = both */
 #define LS_OPT_GEMM_OVERLAP 9     /* [1] ls_encode runs a layer's table GEMM on a side stream beside its k-NN build (+5 % with one call in flight); 0 = on the caller's

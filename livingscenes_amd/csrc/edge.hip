@@ -253,8 +253,18 @@ __global__ __launch_bounds__(256) void edge_attn_kernel(const float* __restrict_
 // (Co = 64/128/256/512 -> 16/32/64/64 lanes, 4/2/1/1 points per wave), an attention head (16 channels) is one DPP
 // quad, and the per-head scores for all 16 neighbours stay in the quad's registers, so the soft-max over neighbours
 // needs no cross-lane traffic and no LDS at all.
+// LS_DPP_NOP=n (dev builds only, scripts/diag/pk_hazard_repro.sh): n + 1 wait states between the instruction that produces a DPP operand and the DPP
+// instruction that reads it from other lanes -- the s_nop sweep of the reproducibility defect described at edge_attn_v4_kernel
+#ifdef LS_DPP_NOP
+#define LS_DPP_STR2(x) #x
+#define LS_DPP_STR(x) LS_DPP_STR2(x)
+#define LS_DPP_FENCE(v) asm volatile("s_nop " LS_DPP_STR(LS_DPP_NOP) : "+v"(v))
+#else
+#define LS_DPP_FENCE(v)
+#endif
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
+    LS_DPP_FENCE(v);
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float quad_sum(float v) { return dpp_add<0x4E>(dpp_add<0xB1>(v)); }
@@ -270,6 +280,7 @@ __device__ __forceinline__ float group_sum(float v) {  // all-reduce over aligne
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_maxf(float v) {
+    LS_DPP_FENCE(v);
     return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false)));
 }
 template <int LPP>
@@ -396,12 +407,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void e
     }
 }
 
+// Partial column sums of an attention kernel's output over its workgroup's PW = 4 (64 / LPP) points (thread tid = (wave, point of the wave, LPP lanes x 4
+// channels) holds ox / oy / oz), ascending point order -> cp [3][Co].  The score slots l_score[k][tid] are lane-private and the caller is done with its
+// own: no barrier before the writes.  Shared by edge_attn_v4_kernel and edge_attn_fq_kernel so that the two paths hand the residual global conv the
+// same mean bit for bit (glob_mean_gemv_kernel finishes the sum over the workgroups).
+template <int LPP>
+__device__ __forceinline__ void attn_colsum(float (*l_score)[256], const float4& ox, const float4& oy, const float4& oz, bool live, int tid, float* __restrict__ cp) {
+    constexpr int PPW = 64 / LPP, PW = 4 * PPW, Co = 4 * LPP;
+    const float z = live ? 1.f : 0.f;   // (a lane past the end recomputed the last point: it must not be counted twice)
+    l_score[0][tid] = ox.x * z; l_score[1][tid] = ox.y * z; l_score[2][tid] = ox.z * z; l_score[3][tid] = ox.w * z;
+    l_score[4][tid] = oy.x * z; l_score[5][tid] = oy.y * z; l_score[6][tid] = oy.z * z; l_score[7][tid] = oy.w * z;
+    l_score[8][tid] = oz.x * z; l_score[9][tid] = oz.y * z; l_score[10][tid] = oz.z * z; l_score[11][tid] = oz.w * z;
+    __syncthreads();
+    for (int col = tid; col < 3 * Co; col += 256) {      // column (axis, channel) <- the PW lanes that hold it
+        const int ax = col / Co, c = col - ax * Co;
+        const float* sp = &l_score[ax * 4 + (c & 3)][c >> 2];
+        float a = 0.f;
+#pragma unroll
+        for (int pw = 0; pw < PW; ++pw) a += sp[(pw / PPW) * 64 + (pw % PPW) * LPP];
+        cp[col] = a;
+    }
+}
+
 template <int LPP, int NCH>
 __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ Tq, int ldq,
                                                            int NQ, int q_via_rows, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, int Co,
                                                            float oms, float inv_sqrt_dk, float* __restrict__ out, int total,
-                                                           float* __restrict__ rowmax) {
+                                                           float* __restrict__ rowmax, float* __restrict__ colsum) {
+    // colsum (nullable, NCH == 1 only) [total / PW][3][Co]: partial column sums of `out`, see attn_colsum
     // rowmax (nullable) [total * 3]: max|out[row, :]| -- the operand range of the GEMM that reads `out` (gemm.hip, GemmAux)
     constexpr int PPW = 64 / LPP;
     // lane-private LDS slots ([neighbour][thread]: conflict-free without padding -> 32 KB per chunk pair, five workgroups per CU):
@@ -510,6 +544,9 @@ __global__ __launch_bounds__(256) void edge_attn_v4_kernel(const float* __restri
             *reinterpret_cast<float4*>(op + 2 * Co) = oz;
         }
         rmx = fmaxf(rmx, amax_f4(ox)); rmy = fmaxf(rmy, amax_f4(oy)); rmz = fmaxf(rmz, amax_f4(oz));
+        if constexpr (NCH == 1) {
+            if (colsum) attn_colsum<LPP>(l_score[0], ox, oy, oz, live, tid, colsum + (size_t)xcd_remap(blockIdx.x, gridDim.x) * 3 * Co);   // kernel-uniform
+        }
     }
     if (rowmax) {   // wave-uniform
         rmx = group_max<LPP>(rmx); rmy = group_max<LPP>(rmy); rmz = group_max<LPP>(rmz);
@@ -595,7 +632,10 @@ template <int LPP, int CIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
                                                            const uint4* __restrict__ Wp, const int32_t* __restrict__ knn,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int Ns, float oms, float inv_sqrt_dk,
-                                                           float* __restrict__ out, int total, float* __restrict__ rowmax) {
+                                                           float* __restrict__ out, int total, float* __restrict__ rowmax, float* __restrict__ colsum) {
+    // colsum (nullable) [total / PW][3][Co]: the column sums of `out` over this workgroup's PW points, in ascending point order -- the residual global
+    // conv's mean over the points (vec_dgcnn_atten.py:223) is finished from these partial sums by glob_mean_gemv_kernel (pointwise.hip) instead of a
+    // second pass over `out` (the launch requires Nd % PW == 0: a workgroup's points then belong to one instance)
     constexpr int PPW = 64 / LPP, PW = 4 * PPW, ROWS = 3 * PW, MT = (ROWS + 31) / 32, Co = LPP * 4, SC = 2 * Co, NT = SC / 32, SLD = SC + 4,
                   KS = CIN / 16, ASTR = CIN * 2 + 16;   // A plane row stride in bytes (+16: conflict-free 16-byte fragment reads)
     static_assert(MT * NT == 8, "two output tiles per wave");
@@ -807,6 +847,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
             const float rmx = group_max<LPP>(amax_f4(ox)), rmy = group_max<LPP>(amax_f4(oy)), rmz = group_max<LPP>(amax_f4(oz));
             if (live && ll == 0) { float* rp = rowmax + (size_t)pid * 3; rp[0] = rmx; rp[1] = rmy; rp[2] = rmz; }
         }
+        if (colsum) attn_colsum<LPP>(l_score, ox, oy, oz, live, tid, colsum + (size_t)(pid0 / PW) * 3 * Co);   // kernel-uniform
     }
 }
 
@@ -815,13 +856,17 @@ bool edge_attn_fq_supported(int Co, int Cin) { return (Co == 64 && (Cin == 32 ||
 bool edge_attn_fq_fits(int B, int Ns, int ldt) {   // the table is addressed by 32-bit byte offsets formed with a 24-bit multiply
     return (unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24);
 }
+// points per workgroup of the fused kernel = rows of `colsum` per Nd / this many points (0: shape not served)
+int edge_attn_fq_points_per_wg(int Co) { return Co == 64 ? 16 : Co == 128 ? 8 : 0; }
 int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, const void* wq_planes, const int32_t* knn, const int32_t* dst_rows, int B,
-                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax) {
+                        int Nd, int Ns, int Co, int head_c, float neg_slope, float* out, hipStream_t st, float* rowmax, float* colsum) {
+    LS_REQUIRE(!colsum || (edge_attn_fq_points_per_wg(Co) > 0 && Nd % edge_attn_fq_points_per_wg(Co) == 0), "edge_attn_fq: column sums need Nd %% %d == 0 (Nd=%d)",
+               edge_attn_fq_points_per_wg(Co), Nd);
     LS_REQUIRE(head_c == 16 && edge_attn_fq_supported(Co, Cin) && ldt % 4 == 0 && wq_planes, "edge_attn_fq: unsupported shape (Co=%d Cin=%d ldt=%d)", Co, Cin, ldt);
     LS_REQUIRE(edge_attn_fq_fits(B, Ns, ldt), "edge_attn_fq: the table is addressed by 32-bit byte offsets (B=%d Ns=%d ldt=%d)", B, Ns, ldt);
     const float isd = 1.0f / sqrtf(3.0f * head_c), oms = 1.0f - neg_slope;
     const int total = B * Nd;
-#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax)
+#define LS_FQ(LPP, CIN) hipLaunchKernelGGL((edge_attn_fq_kernel<LPP, CIN>), dim3(cdiv(total, 4 * (64 / LPP))), dim3(256), 0, st, T, ldt, cur, (const uint4*)wq_planes, knn, dst_rows, Nd, Ns, oms, isd, out, total, rowmax, colsum)
     if (Co == 64 && Cin == 32) LS_FQ(16, 32);
     else if (Co == 64) LS_FQ(16, 64);
     else LS_FQ(32, 64);
@@ -833,10 +878,10 @@ int edge_attn_fq_launch(const float* T, int ldt, const float* cur, int Cin, cons
 template <int LPP, int NCH>
 static int launch_attn_v4(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
                           const int32_t* dst_rows, int B, int Nd, int Ns, int Co, float neg_slope, float isd, float* out,
-                          hipStream_t st, float* rowmax) {
+                          hipStream_t st, float* rowmax, float* colsum = nullptr) {
     const int total = B * Nd, ppb = 4 * (64 / LPP);
     hipLaunchKernelGGL((edge_attn_v4_kernel<LPP, NCH>), dim3(cdiv(total, ppb)), dim3(256), 0, st, T, ldt, Tq, ldq, NQ, qvr, knn,
-                       dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total, rowmax);
+                       dst_rows, Nd, Ns, Co, 1.0f - neg_slope, isd, out, total, rowmax, colsum);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
@@ -873,13 +918,16 @@ int edge_pool_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, 
 bool edge_attn_emits_rowmax(int Co, int ldt, int ldq) { return ldt % 4 == 0 && ldq % 4 == 0 && (Co == 64 || Co == 128 || Co == 256 || Co == 512); }
 int edge_attn_launch(const float* T, int ldt, const float* Tq, int ldq, int NQ, int qvr, const int32_t* knn,
                      const int32_t* dst_rows, int B, int Nd, int Ns, int Co, int head_c, float neg_slope, float* out,
-                     hipStream_t st, float* rowmax) {
+                     hipStream_t st, float* rowmax, float* colsum) {
+    // colsum (nullable): partial column sums, one row per edge_attn_fq_points_per_wg(Co) points (Co = 64 / 128 with 16-byte-aligned tables only)
+    LS_REQUIRE(!colsum || (ldt % 4 == 0 && ldq % 4 == 0 && edge_attn_fq_points_per_wg(Co) > 0 && Nd % edge_attn_fq_points_per_wg(Co) == 0),
+               "edge_attn: no column sums for this shape (Co=%d Nd=%d)", Co, Nd);
     LS_REQUIRE(!rowmax || edge_attn_emits_rowmax(Co, ldt, ldq), "edge_attn: no row maxima from the generic kernel (Co=%d)", Co);
     LS_REQUIRE(head_c == 16 && Co % 16 == 0, "edge_attn: head width must be 16 and divide Co (head_c=%d Co=%d)", head_c, Co);
     const float isd = 1.0f / sqrtf(3.0f * head_c);
     if (ldt % 4 == 0 && ldq % 4 == 0) {
-        if (Co == 64) return launch_attn_v4<16, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
-        if (Co == 128) return launch_attn_v4<32, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
+        if (Co == 64) return launch_attn_v4<16, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax, colsum);
+        if (Co == 128) return launch_attn_v4<32, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax, colsum);
         if (Co == 256) return launch_attn_v4<64, 1>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
         if (Co == 512) return launch_attn_v4<64, 2>(T, ldt, Tq, ldq, NQ, qvr, knn, dst_rows, B, Nd, Ns, Co, neg_slope, isd, out, st, rowmax);
     }

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void edge_ft_qk_kernel(const uint4* __restr
 // invk [B][Nd][16] = 1 / max(|k(n, k)|_F, 1e-12), invq [B][Nd]; grid = B, 256 threads.
 __global__ __launch_bounds__(256) void edge_ft_norms_kernel(const float* __restrict__ sskp, const float* __restrict__ ssqp, int H, float* __restrict__ invk,
                                                             float* __restrict__ invq) {
+    LS_LATENCY_CRITICAL();
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int e = tid; e < FND * FK + FND; e += 256) {
         const bool isk = e < FND * FK;
@@ -404,7 +405,10 @@ __global__ __launch_bounds__(256, 2) void edge_ft_v_kernel(const uint4* __restri
                                                         const int* __restrict__ ae_q, const uint4* __restrict__ wplanes, const int* __restrict__ wexp,
                                                         const int32_t* __restrict__ knn, int B, int H, float oms, float inv_sqrt_dk,
                                                         const float* __restrict__ scores, const float* __restrict__ invk, const float* __restrict__ invq,
-                                                        float* __restrict__ out, int Co, float* __restrict__ rowmax, int rm_parts, int inst_major) {
+                                                        float* __restrict__ out, int Co, float* __restrict__ rowmax, int rm_parts, int inst_major,
+                                                        float* __restrict__ colsum) {
+    // colsum (nullable) [B][3][Co]: the sums of `out` over the instance's 32 points (ascending) -- the mean of the residual global conv
+    // (vec_dgcnn_atten.py:223) without a second pass over `out` (glob_mean_gemv_kernel, pointwise.hip)
     constexpr int KS = CIN / 16, MTP = NS * 3 / 32, MTQ = FND * 3 / 32, SLD = HG * 32 + 4;
     __shared__ __attribute__((aligned(16))) float slab_q[FND * 3 * SLD];    // QV (lin | dir) of the destination points
     __shared__ __attribute__((aligned(16))) float slab_p[NS * 3 * SLD];     // PV (lin | dir) of the source points
@@ -502,6 +506,24 @@ __global__ __launch_bounds__(256, 2) void edge_ft_v_kernel(const uint4* __restri
             rp[0] = rx; rp[rm_parts] = ry; rp[2 * rm_parts] = rz;
         }
     }
+    if (colsum) {   // kernel-uniform: [point][axis][HG x 16 channels] through the q slab, then one thread per column
+        constexpr int CW = HG * 16;
+        __syncthreads();   // every wave is done reading the slabs
+        if (writer) {
+            float* cp = slab_q + mp.n * 3 * CW + mp.hl * 16 + mp.ql * 4;
+            *reinterpret_cast<float4*>(cp) = ox;
+            *reinterpret_cast<float4*>(cp + CW) = oy;
+            *reinterpret_cast<float4*>(cp + 2 * CW) = oz;
+        }
+        __syncthreads();
+        if (tid < 3 * CW) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int n = 0; n < FND; ++n) a += slab_q[n * 3 * CW + tid];
+            const int ax = tid / CW, c = tid - ax * CW;
+            colsum[((size_t)b * 3 + ax) * Co + head0 * 16 + c] = a;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
@@ -558,7 +580,7 @@ int edge_ft_prep_launch(const float* cur, const int32_t* dst_rows, int B, int Ns
     return LS_OK;
 }
 int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, int B, int Ns, int Nd, int Cin, int Co, float neg_slope, void* scratch,
-                        float* out, float* rowmax, hipStream_t st) {
+                        float* out, float* rowmax, hipStream_t st, float* colsum) {
     LS_REQUIRE(edge_ft_supported(Co, Cin, Ns, Nd, 16, has_rows) && wplanes, "edge_ft_attn: unsupported shape (Co=%d Cin=%d Ns=%d Nd=%d)", Co, Cin, Ns, Nd);
     const FtScratch s = ft_layout(scratch, B, Ns, Nd, Cin, Co, has_rows);
     const int H = Co / 16, HG = edge_ft_heads_per_group(Cin), KS = Cin / 16;
@@ -576,14 +598,14 @@ int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, 
         hipLaunchKernelGGL(edge_ft_norms_kernel, dim3(B), dim3(256), 0, st, s.sskp, s.ssqp, H, s.invk, s.invq);
         LS_LAUNCH_CHECK();
         hipLaunchKernelGGL((edge_ft_v_kernel<128, 128, 1>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.invk,
-                           s.invq, out, Co, rowmax, H / HG, im);
+                           s.invq, out, Co, rowmax, H / HG, im, colsum);
     } else {
         hipLaunchKernelGGL((edge_ft_qk_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, s.scores, s.sskp, s.ssqp, im);
         LS_LAUNCH_CHECK();
         hipLaunchKernelGGL(edge_ft_norms_kernel, dim3(B), dim3(256), 0, st, s.sskp, s.ssqp, H, s.invk, s.invq);
         LS_LAUNCH_CHECK();
         hipLaunchKernelGGL((edge_ft_v_kernel<256, 32, 2>), grid, dim3(256), 0, st, s.a_p, s.ae_p, s.a_q, s.ae_q, wp, we, knn, B, H, oms, isd, s.scores, s.invk,
-                           s.invq, out, Co, rowmax, H / HG, im);
+                           s.invq, out, Co, rowmax, H / HG, im, colsum);
     }
     LS_LAUNCH_CHECK();
     return LS_OK;

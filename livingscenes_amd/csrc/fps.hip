@@ -88,6 +88,7 @@ template <int PPL, bool FMA>
 __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
                                                       int N, int K, int32_t* __restrict__ idx_out,
                                                       float* __restrict__ pts_out) {
+    LS_LATENCY_CRITICAL();
     extern __shared__ __attribute__((aligned(16))) float lp[];  // [N][3]
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* p = pts + (size_t)b * N * 3;
@@ -174,6 +175,7 @@ struct FpsRec { float v; unsigned i; float x, y; };
 template <int PPT, bool FMA>
 __global__ __launch_bounds__(256) void fps_quad_kernel(const float* __restrict__ pts, const int32_t* __restrict__ lengths,
                                                        int N, int K, int32_t* __restrict__ idx_out, float* __restrict__ pts_out) {
+    LS_LATENCY_CRITICAL();
     extern __shared__ __attribute__((aligned(16))) float lp[];  // [N][3]
     __shared__ __attribute__((aligned(16))) FpsRec lrec[2][4];  // [buffer][wave] {value, index, x, y}
     __shared__ __attribute__((aligned(16))) float lz[2][4];     // [buffer][wave] z

@@ -1766,6 +1766,123 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The residual global conv of encoder layers 2 / 3 (K = C = 64, 98 304 rows: 25 MB in, 25 MB out, 1.6 GFLOP) as a STREAMING kernel without LDS
+// and without barriers (round 5).  gemm_vn_smallk_kernel moves a 120-row tile through split -> barrier -> 48 MFMAs -> barrier -> LDS staging -> activation
+// -> store with two workgroups per CU: 28 - 31 us for 6 us of HBM traffic.  Here a WAVE owns 32 output channels (lin AND dir columns: two 32-column
+// MFMA tiles) of a stream of M-tiles; both W tiles stay split in 64 VGPRs for the whole launch.  The trick that removes the LDS transpose of the
+// epilogue: an M-tile is EIGHT points laid out as MFMA rows 4 p + axis (axis 3 = a copy of z, dropped), so that in the 32x32 C/D map (col = lane & 31,
+// rows 8 g + 4 (lane >> 5) + 0..3) a lane holds x, y, z of FOUR whole points for its channel in both accumulators: the VN activation is register-local.
+// The A fragments come straight from global memory (a lane reads 8 consecutive k of its row; the 24 rows of a tile are 6 KB contiguous, every line is
+// used in full across the four k-steps; the next tile's rows are in flight under this tile's MFMAs and activation).  Same operands (split2_f16s of the
+// power-of-two scaled rows, scales from GemmAux::a_rowmax / w_rowmax), same three products per 16 k in the same order into one accumulator, ascending k,
+// same integer-exponent epilogue, same activation: BIT-IDENTICAL to gemm_vn_kernel / gemm_vn_smallk_kernel (tests/test_hip_fullbatch.py).  25 % of
+// the MFMA rows are padding: irrelevant, the matrix pipes are idle 90 % of the launch either way.
+template <int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_vn_direct_kernel(
+    const float* __restrict__ A, const float* __restrict__ W, int ldw, const float* __restrict__ G, int ldg, float* __restrict__ out, int ntiles, int npts,
+    float oms, GemmAux aux) {
+    static_assert(C == 64, "two waves per M-stream, K = C");
+    constexpr int KS = C / 16, NWN = C / 32, SPW = 4 / NWN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave % NWN, lr = lane & 31, kh = lane >> 5;
+    const int nstreams = gridDim.x * SPW;
+    const int ch = 32 * wn + lr;
+    // ---- this wave's W tiles: row j C + ch (j = 0 lin, 1 dir), 8 consecutive k per k-step, split once
+    f16x8_t bh[2][KS], bl[2][KS];
+    int we[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int wr = j * C + ch;
+        float sw, iw;
+        pow2_scale(aux.w_rowmax[wr], sw, iw);
+        we[j] = pow2_e(iw);
+        const float* wp = W + (size_t)wr * ldw + kh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint2 h0, l0, h1, l1;
+            split2_f16s<1>(*reinterpret_cast<const float4*>(wp + ks * 16), sw, h0, l0);
+            split2_f16s<1>(*reinterpret_cast<const float4*>(wp + ks * 16 + 4), sw, h1, l1);
+            bh[j][ks] = __builtin_bit_cast(f16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            bl[j][ks] = __builtin_bit_cast(f16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        }
+    }
+    // ---- the M-tiles of this wave's stream
+    const int rofs = (lr >> 2) * 3 + min(lr & 3, 2);      // this lane's A row inside a tile (MFMA row lr = point lr / 4, axis lr % 4)
+    float4 raw[KS][2];
+    float ma = 0.f;
+    auto load_tile = [&](int t) {
+        const size_t R = (size_t)t * 24 + rofs;
+        const float* ap = A + R * C + kh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { raw[ks][0] = *reinterpret_cast<const float4*>(ap + ks * 16); raw[ks][1] = *reinterpret_cast<const float4*>(ap + ks * 16 + 4); }
+        ma = 0.f;
+        for (int q = 0; q < aux.a_parts; ++q) ma = fmaxf(ma, aux.a_rowmax[R * aux.a_parts + q]);
+    };
+    int t = blockIdx.x * SPW + wave / NWN;
+    if (t < ntiles) load_tile(t);
+    for (; t < ntiles; t += nstreams) {
+        float sa, ia;
+        pow2_scale(ma, sa, ia);
+        const int ea_own = pow2_e(ia);
+        f16x8_t ah[KS], al[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint2 h0, l0, h1, l1;
+            split2_f16s<0>(raw[ks][0], sa, h0, l0);
+            split2_f16s<0>(raw[ks][1], sa, h1, l1);
+            ah[ks] = __builtin_bit_cast(f16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            al[ks] = __builtin_bit_cast(f16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        }
+        // the instance's per-channel offsets (G: the mean part of the conv) of this tile
+        const int p0 = t * 8;
+        const float* g = G + (size_t)(p0 / npts) * 3 * ldg + 2 * C + ch;
+        float gl[3], gd[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { gl[x] = g[x * ldg]; gd[x] = g[x * ldg + C]; }
+        if (t + nstreams < ntiles) load_tile(t + nstreams);       // next tile's rows in flight under the MFMAs, the activation and the stores
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[j][ks], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[j][ks], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[j][ks], acc[j], 0, 0, 0);
+        }
+        // epilogue: accumulator rows 4 g + axis of this lane = point 2 g + kh of the tile
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int pl = 2 * gq + kh, pt = p0 + pl;
+            int ea[3];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) ea[x] = __shfl(ea_own, 4 * pl + x, 64);      // the row's scale sits with the lane that loaded the row
+            float y0 = scale_pow2(acc[0][4 * gq + 0], ea[0] + we[0]) + gl[0];
+            float y1 = scale_pow2(acc[0][4 * gq + 1], ea[1] + we[0]) + gl[1];
+            float y2 = scale_pow2(acc[0][4 * gq + 2], ea[2] + we[0]) + gl[2];
+            const float k0 = scale_pow2(acc[1][4 * gq + 0], ea[0] + we[1]) + gd[0];
+            const float k1 = scale_pow2(acc[1][4 * gq + 1], ea[1] + we[1]) + gd[1];
+            const float k2 = scale_pow2(acc[1][4 * gq + 2], ea[2] + we[1]) + gd[2];
+            vn_act(y0, y1, y2, k0, k1, k2, oms);
+            float* op = out + (size_t)pt * 3 * C + ch;
+            op[0] = y0; op[C] = y1; op[2 * C] = y2;
+            if (aux.out_rowmax) {   // kernel-uniform; [M][C / 32]: max|out[row, this wave's 32 channels]| (the half-wave of a point)
+                float m0_ = max16(fabsf(y0)), m1_ = max16(fabsf(y1)), m2_ = max16(fabsf(y2));
+                m0_ = fmaxf(m0_, __shfl_xor(m0_, 16, 64)); m1_ = fmaxf(m1_, __shfl_xor(m1_, 16, 64)); m2_ = fmaxf(m2_, __shfl_xor(m2_, 16, 64));
+                if (lr == 0) {
+                    float* rp = aux.out_rowmax + (size_t)pt * 3 * NWN + wn;
+                    rp[0] = m0_; rp[NWN] = m1_; rp[2 * NWN] = m2_;
+                }
+            }
+        }
+    }
+}
+
 // split-K combine: out[m][n] = act(sum_s slab[s][m][n] + bias[n]), slices summed in ascending order (deterministic)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slabs, size_t slab_stride, int nsplit,
                                                                 const float* __restrict__ bias, float* __restrict__ out, int ldc,
@@ -2019,6 +2136,13 @@ int gemm_vn_dispatch(const float* A, int lda, const float* W, int ldw, const flo
     if (range_off) aux.noscale = 1;
     LS_REQUIRE(gemm_vn_supported(M, C, K) && lda % 4 == 0 && ldw % 4 == 0, "gemm_vn: unsupported shape (M=%d C=%d K=%d)", M, C, K);
     const int tm = cdiv(M, 120), tn = C / 64;
+    static const bool direct = dev_knob("LS_GLOB_DIRECT", 1) != 0;     // dev A/B: the streaming kernel of layers 2 / 3
+    if (direct && K == 64 && C == 64 && lda == K && npts % 8 == 0 && aux.a_rowmax && aux.a_parts > 0 && aux.w_rowmax && !aux.noscale && M >= 24 * 64) {
+        const int ntiles = M / 24;
+        hipLaunchKernelGGL(gemm_vn_direct_kernel<64>, dim3(std::min(512, cdiv(ntiles, 2))), dim3(256), 0, st, A, W, ldw, G, ldg, out, ntiles, npts, oms, aux);
+        LS_LAUNCH_CHECK();
+        return LS_OK;
+    }
     static const bool persist = dev_knob("LS_GLOB_PERSIST", 1) != 0;   // dev A/B: K = 32 / 64 on the tiled kernel
     if (persist && (K == 32 || K == 64) && tm >= 16 && lda == K) {
         static const int vn_wgs32 = dev_knob("LS_GLOB_PERSIST_WGS32", 512);   // dev A/B

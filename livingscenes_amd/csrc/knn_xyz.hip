@@ -152,6 +152,7 @@ template <bool FMA>
 __global__ __launch_bounds__(256, 2) void knn_small_kernel(const float* __restrict__ dstf, const float* __restrict__ srcf,
                                                            const int32_t* __restrict__ dst_rows, int Nd, int dst_n, int Ns, int C, int K,
                                                            int32_t* __restrict__ idx_out, float* __restrict__ dist_out, int qblocks) {
+    LS_LATENCY_CRITICAL();
     __shared__ __attribute__((aligned(16))) float lq[KSM_Q * KSM_ROW];
     __shared__ __attribute__((aligned(16))) float lc[KSM_S * KSM_ROW];
     __shared__ float ldist[KSM_Q][KSM_S + 1];

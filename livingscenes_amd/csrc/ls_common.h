@@ -42,6 +42,16 @@ void set_error(const char* fmt, ...);
 // Development A/B switches: a library built with -DLS_DEV_KNOBS (scripts/dev/build_variants.py) reads them from the environment; in the RELEASE
 // library every knob is its default, a compile-time constant -- the release library reads nothing from the environment beyond what
 // ls_model_create documents (LS_ENCODE_GRAPH, LS_EDGE_STAGED, LS_SDF_BF16X2) and the process-wide arithmetic mode LS_GEMM_MODE (gemm.hip).
+// Latency-bound kernels with one workgroup (or wave) per instance -- FPS, the 32-point k-NN, the heads, matcher, Kabsch -- share their CUs with the chip-filling
+// kernels of other steps in flight (and, inside one step, FPS runs beside layers 0 - 1): a raised wave priority makes the SIMD arbiter issue them first.
+#ifndef LS_PRIO
+#define LS_PRIO 0
+#endif
+#if LS_PRIO > 0
+#define LS_LATENCY_CRITICAL() __builtin_amdgcn_s_setprio(LS_PRIO)
+#else
+#define LS_LATENCY_CRITICAL()
+#endif
 #ifdef LS_DEV_KNOBS
 inline int dev_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 #else

@@ -16,6 +16,7 @@ namespace ls {
 __global__ __launch_bounds__(256) void cosine_scores_kernel(const float* __restrict__ m0, const float* __restrict__ m1, int n,
                                                             int m, int D, float* __restrict__ inv_norm, float* __restrict__ S,
                                                             int phase) {
+    LS_LATENCY_CRITICAL();
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (phase == 0) {  // one wave per row of [m0; m1]: 1 / max(|row|, 1e-12)
@@ -133,6 +134,7 @@ __device__ __forceinline__ int gm_wave_min(int v) {
 }
 __global__ __launch_bounds__(64) void greedy_match_wave_kernel(const float* __restrict__ S, int n, int m, long long* __restrict__ m0,
                                                               long long* __restrict__ m1) {
+    LS_LATENCY_CRITICAL();
     const int lane = threadIdx.x;
     const int total = n * m;
     float v[16];
@@ -172,6 +174,75 @@ __global__ __launch_bounds__(64) void greedy_match_wave_kernel(const float* __re
     }
 }
 
+// n * m <= 1024 on FOUR waves (round 5): four entries per lane instead of sixteen.  The one-wave kernel above executes ~1000 instructions per assignment
+// (sixteen IEEE divisions behind per-lane alive masks: 71 branches) = 1.9 us each, 62 us for 32 x 32 at the end of every encode + match + register step.
+// Here: branch-free selects, four divisions per lane, and TWO workgroup reductions per assignment instead of three -- the maximum of the divided matrix is
+// the divided maximum (a correctly rounded division by one positive denominator is monotone), so only the matrix maximum and the first position that
+// holds the divided maximum are reduced; a non-positive or non-finite denominator (all scores <= -1e-5) takes the three-reduction form.  The matches are
+// collected in LDS and written once.  Same arithmetic on every entry, same tie rule: identical matches (tests/test_hip_parity.py, test_hip_surface.py).
+__global__ __launch_bounds__(256) void greedy_match_quad_kernel(const float* __restrict__ S, int n, int m, long long* __restrict__ m0,
+                                                                long long* __restrict__ m1) {
+    LS_LATENCY_CRITICAL();
+    __shared__ float lmx[4], lmx2[4];
+    __shared__ int lpos[4];
+    __shared__ int lm[2048];     // matches of the rows | of the columns (n, m <= 1024)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = n * m;
+    float v[4];
+    int ri[4], ci[4];
+    bool alive[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + 256 * k;
+        const bool in = e < total;
+        v[k] = in ? S[e] : 0.f;
+        ri[k] = in ? e / m : -1;
+        ci[k] = in ? e - (e / m) * m : -1;
+        alive[k] = in;
+    }
+    for (int i = tid; i < 2048; i += 256) lm[i] = -1;
+    __syncthreads();
+    const int iters = n < m ? n : m;
+    for (int it = 0; it < iters; ++it) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx = fmaxf(mx, alive[k] ? v[k] : -INFINITY);
+        mx = gm_wave_max(mx);
+        if (lane == 0) lmx[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(lmx[0], lmx[1]), fmaxf(lmx[2], lmx[3]));
+        const float denom = mx + 1e-5f;            // S /= (max + 1e-5)   (matcher_new.py:123)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = alive[k] ? v[k] / denom : v[k];
+        float mx2;
+        if (denom > 0.f && denom < INFINITY) mx2 = mx / denom;     // (workgroup-uniform)
+        else {
+            mx2 = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mx2 = fmaxf(mx2, alive[k] ? v[k] : -INFINITY);
+            mx2 = gm_wave_max(mx2);
+            if (lane == 0) lmx2[wave] = mx2;
+            __syncthreads();
+            mx2 = fmaxf(fmaxf(lmx2[0], lmx2[1]), fmaxf(lmx2[2], lmx2[3]));
+        }
+        int pos = INT_MAX;                         // first row-major position holding the maximum: smallest e
+#pragma unroll
+        for (int k = 3; k >= 0; --k) pos = (alive[k] && v[k] == mx2) ? tid + 256 * k : pos;
+        pos = gm_wave_min(pos);
+        if (lane == 0) lpos[wave] = pos;
+        __syncthreads();
+        pos = min(min(lpos[0], lpos[1]), min(lpos[2], lpos[3]));
+        if (pos == INT_MAX) break;                 // NaN scores: the reference would raise here
+        const int r = pos / m, c = pos - r * m;
+        if (tid == 0) { lm[r] = c; lm[1024 + c] = r; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) alive[k] = alive[k] && ri[k] != r && ci[k] != c;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) m0[i] = lm[i];
+    for (int j = tid; j < m; j += 256) m1[j] = lm[1024 + j];
+}
+
 // ---------------------------------------------------------------------------------------------- Kabsch
 // one wave per problem; problem p pairs cloud x1[i1(p)] with x2[i2(p)]:
 //   pair_mode 0: i1 = i2 = p (batched Kabsch);  pair_mode 1: p = i*m + j -> (i, j) (residual matrix)
@@ -181,6 +252,7 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
                                                      float* __restrict__ res, float* __restrict__ res_mean,
                                                      int32_t* __restrict__ flags, const float* __restrict__ off1, const float* __restrict__ off2,
                                                      const long long* __restrict__ sel1, const long long* __restrict__ sel2) {
+    LS_LATENCY_CRITICAL();
     // off1 / off2 (nullable) [*,3]: the point sets are x + off (More_Solver's pseudo-points z_so3 + t, more_solver.py:114-116, formed
     // here instead of by a separate element-wise launch); sel1 / sel2 (nullable) [nprob] int64: problem p reads set sel[p] (a negative
     // entry -- an unmatched row of matches0 -- reads set 0, as matches0.clamp(min=0) does)
@@ -268,7 +340,9 @@ int cosine_scores_launch(const float* m0, const float* m1, int n, int m, int D, 
 }
 int greedy_match_launch(float* S, int n, int m, long long* m0, long long* m1, hipStream_t st) {
     if ((long long)n * m <= 1024) {
-        hipLaunchKernelGGL(greedy_match_wave_kernel, dim3(1), dim3(64), 0, st, S, n, m, m0, m1);
+        static const bool one_wave = dev_knob("LS_GREEDY_ONE_WAVE", 0) != 0;   // dev A/B: the round-3 kernel
+        if (one_wave || n * m <= 64) hipLaunchKernelGGL(greedy_match_wave_kernel, dim3(1), dim3(64), 0, st, S, n, m, m0, m1);
+        else hipLaunchKernelGGL(greedy_match_quad_kernel, dim3(1), dim3(256), 0, st, S, n, m, m0, m1);
         LS_LAUNCH_CHECK();
         return LS_OK;
     }

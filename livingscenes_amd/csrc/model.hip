@@ -35,11 +35,14 @@ int gemm_presplit_w_launch(const float* W, int rows, int K, int ldw, const float
 int sdf_affine_rowmax_parts(int out_dim);
 int edge_l0_launch(const float*, const int32_t*, const float*, int, int, int, float, float*, hipStream_t);
 int edge_pool_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, float, float*, hipStream_t);
-int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
+int edge_attn_launch(const float*, int, const float*, int, int, int, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr,
+                     float* colsum = nullptr);
 bool edge_attn_emits_rowmax(int Co, int ldt, int ldq);
 bool edge_attn_fq_supported(int Co, int Cin);
 bool edge_attn_fq_fits(int B, int Ns, int ldt);
-int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr);
+int edge_attn_fq_launch(const float*, int, const float*, int, const void*, const int32_t*, const int32_t*, int, int, int, int, int, float, float*, hipStream_t, float* rowmax = nullptr,
+                        float* colsum = nullptr);
+int edge_attn_fq_points_per_wg(int Co);
 size_t edge_wq_planes_bytes(int Co, int Cin);
 // edge_fused.hip: attention layers with 32 destination points (released layers 5 / 6) -- table slices formed and consumed in LDS
 bool edge_ft_supported(int Co, int Cin, int Ns, int Nd, int head_c, bool has_rows);
@@ -48,7 +51,7 @@ int edge_ft_presplit_w_launch(const float* W, int Co, int Cin, void* planes, hip
 size_t edge_ft_scratch_bytes(int B, int Ns, int Nd, int Cin, int Co, bool has_rows);
 int edge_ft_prep_launch(const float* cur, const int32_t* dst_rows, int B, int Ns, int Nd, int Cin, int Co, void* scratch, hipStream_t st);
 int edge_ft_attn_launch(const void* wplanes, const int32_t* knn, bool has_rows, int B, int Ns, int Nd, int Cin, int Co, float neg_slope, void* scratch,
-                        float* out, float* rowmax, hipStream_t st);
+                        float* out, float* rowmax, hipStream_t st, float* colsum = nullptr);
 int edge_ft_rowmax_parts(int Co, int Cin);
 int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipStream_t st);
 // edge_staged.hip: attention layers 2 - 4 with LDS-staged neighbour tiles (slice-major table)
@@ -73,7 +76,7 @@ int prologue_launch(const float*, int, int, float*, float*, float*, float*, hipS
 size_t prologue_scratch_floats(int B);
 int transpose_cloud_launch(const float*, int, int, float*, hipStream_t);
 int mean_points_launch(const float*, int, int, int, float*, hipStream_t);
-int glob_mean_gemv_launch(const float*, int, int, int, const float*, int, int, float*, int, hipStream_t);
+int glob_mean_gemv_launch(const float*, int, int, int, const float*, int, int, float*, int, hipStream_t, int npoints = 0);
 int vn_act_rows_launch(const float*, int, const float*, int, int, int, int, float, float*, hipStream_t);
 int tail_launch(const float*, int, int, int, int, const float*, const float*, const float*, float, float, int, int, const float*,
                 const float*, float*, float*, float*, float*, hipStream_t);
@@ -117,7 +120,7 @@ struct ls_model {
     void* wst_q[LS_MAX_LAYERS] = {};       // ... and the destination-side weights as per-Q-block f16 MFMA fragments
     bool fuse_q = true;                    // LS_OPT_EDGE_FUSE_Q: destination side of attention layers 2 - 4 inside the edge kernel (edge.hip: edge_attn_fq_kernel)
     bool fuse_t = true;                    // LS_OPT_EDGE_FUSE_T: table-free 32-point attention layers (edge_fused.hip)
-    bool glob_fuse = true;                 // LS_OPT_GLOB_FUSE: residual global conv as mean + GEMV launch and GEMM + VN activation in one kernel (gemm.hip: gemm_vn_kernel)
+    int glob_fuse = 1;                     // LS_OPT_GLOB_FUSE (0 / 1 / 2; 2 = 1 + the operator export ls_vn_lna_f32 chains exact row maxima like the encoder's producers do): residual global conv as mean + GEMV launch and GEMM + VN activation in one kernel (gemm.hip: gemm_vn_kernel)
     int debug_edge = 0;                    // LS_OPT_DEBUG_EDGE: ls_vn_edgeconv_* runs 0 = table GEMM + edge kernel, 1 = the table GEMM only, 2 = the edge kernel only on the
                                            // tables already in the workspace (per-operator counter passes: scripts/pmc_ops.py)
     int edge_staged = 0;                   // LS_OPT_EDGE_STAGED: 0 = never (default: measured slower than the gather kernel), 1 = when the grid fills the chip
@@ -193,7 +196,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], o_cs, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -202,7 +205,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     int cur = N;
     p.nlevels = 0;
     p.levelN[0] = N;
-    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0, maxKs = 0, maxGws = 0, maxRm = 0;
+    size_t maxF = 0, maxT = 0, maxTG = 0, maxC = 0, maxKnn = 0, maxKs = 0, maxGws = 0, maxRm = 0, maxCs = 0;
     for (int i = 0; i < p.L; ++i) {
         p.Ns[i] = cur;
         const int f = d.down_factor[i] > 1 ? d.down_factor[i] : 1;
@@ -241,6 +244,8 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
             size_t parts = (size_t)p.Co[i] / 32 + 1;
             if (i > 0 && attn && (p.Cin[i] == 128 || p.Cin[i] == 256)) parts = std::max(parts, (size_t)edge_ft_rowmax_parts(p.Co[i], p.Cin[i]));
             maxRm = std::max(maxRm, (size_t)p.Nd[i] * parts);
+            // partial column sums of the message from the attention kernel that wrote it (global_conv): at most one row per 8 points
+            maxCs = std::max(maxCs, (size_t)(p.Nd[i] / 8 + 1) * 3 * p.Co[i]);
         }
         // split-K slabs of the under-filled GEMMs (residual global conv: per-point part and per-instance mean part)
         maxGws = std::max(maxGws, std::max(gemm_scratch_floats(B * p.Nd[i] * 3, 2 * p.Co[i], p.Co[i]), gemm_scratch_floats(B * 3, 4 * p.Co[i], p.Co[i])));
@@ -278,6 +283,7 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_rm_msg = take((size_t)B * maxRm * 3 * 4);      // maxRm = max over the layers of Nd x parts (above)
     p.o_rm_out[0] = take((size_t)B * maxRm * 3 * 4);
     p.o_rm_out[1] = take((size_t)B * maxRm * 3 * 4);
+    p.o_cs = take((size_t)B * maxCs * 4);
     // staging of the captured-graph path: the graph reads x from / writes the codes to FIXED addresses inside the workspace
     p.o_xin = take((size_t)B * 3 * N * 4);
     p.o_out = take((size_t)B * (4 * (size_t)d.c_dim + 4) * 4);
@@ -416,17 +422,22 @@ static int edge_tables(ls_model* m, int i, const float* cur, const int32_t* dst_
 // gather + VN activation + mean-pool | attention of layer i >= 1 over the tables
 // rm_out (nullable) [B*Nd*3]: receives max|out[row, :]| when the kernel taken can write it; *rm_written says whether it did
 static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, const int32_t* knn, const int32_t* dst_rows, int B, int Nd,
-                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr, int* rm_parts = nullptr) {
+                      int Ns, float* out, hipStream_t st, float* rm_out = nullptr, bool* rm_written = nullptr, int* rm_parts = nullptr,
+                      float* cs_out = nullptr, int* cs_rows = nullptr) {
+    // cs_out (nullable): receives partial column sums of `out` ([B][*cs_rows][3][Co], *cs_rows = 0: the kernel taken writes none) -- global_conv
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
     if (rm_written) *rm_written = false;
     if (rm_parts) *rm_parts = 1;
+    if (cs_rows) *cs_rows = 0;
+    if (!cs_rows || !m->glob_fuse) cs_out = nullptr;
     if (i >= d.atten_start_layer) {
         PROF(LS_K_EDGE_ATTN, i, st);
         if (et.Wt) {   // rm_out (if any) must hold [B*Nd*3][edge_ft_rowmax_parts] floats: one maximum per head group and row
             if (rm_written) *rm_written = rm_out != nullptr;
             if (rm_parts) *rm_parts = edge_ft_rowmax_parts(Co, et.Cin);
-            return edge_ft_attn_launch(et.Wt, knn, dst_rows != nullptr, B, Ns, Nd, et.Cin, Co, d.neg_slope, const_cast<float*>(T), out, rm_out, st);
+            if (cs_out) *cs_rows = 1;
+            return edge_ft_attn_launch(et.Wt, knn, dst_rows != nullptr, B, Ns, Nd, et.Cin, Co, d.neg_slope, const_cast<float*>(T), out, rm_out, st, cs_out);
         }
         if (et.Ws) {
             if (rm_written) *rm_written = rm_out != nullptr;
@@ -434,11 +445,15 @@ static int edge_apply(ls_model* m, int i, const float* T, const EdgeTables& et, 
         }
         if (et.cur) {
             if (rm_written) *rm_written = rm_out != nullptr;
-            return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
+            const int pw = edge_attn_fq_points_per_wg(Co);
+            if (cs_out && pw > 0 && Nd % pw == 0) *cs_rows = Nd / pw; else cs_out = nullptr;
+            return edge_attn_fq_launch(T, et.ldp, et.cur, et.Cin, et.Wq, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out, cs_out);
         }
         if (!edge_attn_emits_rowmax(Co, et.ldp, et.ldq)) rm_out = nullptr;
         if (rm_written) *rm_written = rm_out != nullptr;
-        return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out);
+        const int pw = edge_attn_fq_points_per_wg(Co);   // (the float4-lane kernel of Co = 64 / 128 shares the fused kernel's point map and column sums)
+        if (cs_out && pw > 0 && Nd % pw == 0 && et.ldp % 4 == 0 && et.ldq % 4 == 0) *cs_rows = Nd / pw; else cs_out = nullptr;
+        return edge_attn_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.atten_head_c, d.neg_slope, out, st, rm_out, cs_out);
     }
     PROF(LS_K_EDGE_POOL, i, st);
     return edge_pool_launch(T, et.ldp, et.Tq, et.ldq, et.NQ, et.qvr, knn, dst_rows, B, Nd, Ns, Co, d.neg_slope, out, st);
@@ -451,7 +466,9 @@ static size_t global_conv_gws_floats(const ls_model_desc& d, int i, int B, int N
 // rm_msg (nullable) [B*Nd*3]: row maxima of msg from the kernel that wrote it; rm_out (nullable) [B*Nd*3][Co/32]: receives those of `out`
 // (*rm_written: whether the path taken wrote them) -- gemm.hip, GemmAux
 static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, float* g, float* G, float* TG, float* gws, float* out, hipStream_t st,
-                       const float* rm_msg = nullptr, float* rm_out = nullptr, bool* rm_written = nullptr, int rm_msg_parts = 1) {
+                       const float* rm_msg = nullptr, float* rm_out = nullptr, bool* rm_written = nullptr, int rm_msg_parts = 1, const float* cs = nullptr,
+                       int cs_rows = 0) {
+    // cs (nullable) [B][cs_rows][3][Co]: partial column sums of msg from the kernel that wrote it (edge_apply): the mean is finished from them
     const ls_model_desc& d = m->d;
     const int Co = d.feat_dim[i];
     const float* Wg = m->blob + d.off_glob[i];
@@ -459,7 +476,9 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
     int rc;
     if (m->glob_fuse && gemm_vn_supported(B * Nd * 3, Co, Co)) {
         // per-instance part: mean over the points and its contraction with the W_b / Wd W_b rows in ONE launch (pointwise.hip) ...
-        { PROF(LS_K_MEAN, i, st); rc = glob_mean_gemv_launch(msg, B, Nd, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st); }
+        { PROF(LS_K_MEAN, i, st);
+          rc = (cs && cs_rows > 0) ? glob_mean_gemv_launch(cs, B, cs_rows, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st, Nd)
+                                   : glob_mean_gemv_launch(msg, B, Nd, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st); }
         if (rc != LS_OK) return rc;
         // ... then ONE launch for the per-point contraction + the VN activation (gemm.hip: gemm_vn_kernel)
         PROF(LS_K_GEMM_GLOB, i, st);
@@ -748,7 +767,7 @@ int ls_model_set_option(ls_model_t* m, int option, int value) {
         case LS_OPT_EDGE_STAGED: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_EDGE_STAGED takes 0, 1 or 2"); m->edge_staged = value; return LS_OK;
         case LS_OPT_EDGE_FUSE_Q: m->fuse_q = value != 0; return LS_OK;
         case LS_OPT_EDGE_FUSE_T: m->fuse_t = value != 0; return LS_OK;
-        case LS_OPT_GLOB_FUSE: m->glob_fuse = value != 0; return LS_OK;
+        case LS_OPT_GLOB_FUSE: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_GLOB_FUSE takes 0, 1 or 2"); m->glob_fuse = value; return LS_OK;
         case LS_OPT_DEBUG_EDGE: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_DEBUG_EDGE takes 0, 1 or 2"); m->debug_edge = value; return LS_OK;
         case LS_OPT_GEMM_OVERLAP: m->overlap_gemm = value != 0; return LS_OK;
         default: set_error("model_set_option: unknown option %d", option); return LS_ERR_INVALID;
@@ -764,7 +783,7 @@ int ls_model_get_option(const ls_model_t* m, int option, int* value) {
         case LS_OPT_EDGE_STAGED: *value = m->edge_staged; return LS_OK;
         case LS_OPT_EDGE_FUSE_Q: *value = m->fuse_q ? 1 : 0; return LS_OK;
         case LS_OPT_EDGE_FUSE_T: *value = m->fuse_t ? 1 : 0; return LS_OK;
-        case LS_OPT_GLOB_FUSE: *value = m->glob_fuse ? 1 : 0; return LS_OK;
+        case LS_OPT_GLOB_FUSE: *value = m->glob_fuse; return LS_OK;
         case LS_OPT_DEBUG_EDGE: *value = m->debug_edge; return LS_OK;
         case LS_OPT_GEMM_OVERLAP: *value = m->overlap_gemm ? 1 : 0; return LS_OK;
         default: set_error("model_get_option: unknown option %d", option); return LS_ERR_INVALID;
@@ -856,7 +875,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
         const bool glob = i >= d.res_global_start_layer;
         float* mp = glob ? msg : nxt;
         bool msg_rm = false;
-        int msg_rm_parts = 1;
+        int msg_rm_parts = 1, msg_cs_rows = 0;
         if (i == 0) {
             { PROF(LS_K_KNN, i, st); rc = (skip & SK_KNN) ? LS_OK : knn_dispatch(pts0, pts0, nullptr, B, Nd, Ns, Ns, 1, 16, flags, knn, nullptr, ws + p.o_knns, nullptr, 0, 0, st); }
             if (rc != LS_OK) return rc;
@@ -889,7 +908,8 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             }
             if (m->overlap_gemm) LS_HIP_CHECK(hipStreamWaitEvent(st, m->ev_tab[i], 0));
             if ((skip & ((i >= d.atten_start_layer) ? SK_ATTN : SK_POOL)) || ((skip & SK_HI32) && Nd == 32)) rc = LS_OK;
-            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts);
+            else rc = edge_apply(m, i, T, et, knn, dst_rows, B, Nd, Ns, mp, st, glob ? F(p.o_rm_msg) : nullptr, &msg_rm, &msg_rm_parts,
+                                 glob ? F(p.o_cs) : nullptr, &msg_cs_rows);
             if (rc != LS_OK) return rc;
         }
         cur_rm = nullptr; cur_rm_parts = 0;
@@ -897,7 +917,7 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             bool out_rm = false;
             if (skip & SK_GLOB) rc = LS_OK;
             else rc = global_conv(m, i, msg, B, Nd, F(p.o_g), F(p.o_G), F(p.o_TG), F(p.o_gws), nxt, st, msg_rm ? F(p.o_rm_msg) : nullptr,
-                             F(p.o_rm_out[i & 1]), &out_rm, msg_rm_parts);
+                             F(p.o_rm_out[i & 1]), &out_rm, msg_rm_parts, F(p.o_cs), msg_cs_rows);
             if (rc != LS_OK) return rc;
             if (out_rm) { cur_rm = F(p.o_rm_out[i & 1]); cur_rm_parts = Co / 32; }
         }
@@ -1022,7 +1042,7 @@ int ls_vn_edgeconv_attn_f32(ls_model_t* m, int layer, const float* src_f, const 
     return edgeconv_export(m, layer, src_f, knn, dst_rows, B, Ns, Nd, out, workspace, workspace_bytes, (hipStream_t)stream, "vn_edgeconv_attn");
 }
 
-struct LnaPlan { size_t o_g, o_G, o_TG, o_gws, total; };
+struct LnaPlan { size_t o_g, o_G, o_TG, o_gws, o_rm, total; };
 static LnaPlan lna_plan(const ls_model_desc& d, int layer, int B, int N) {
     const size_t Co = (size_t)d.feat_dim[layer];
     LnaPlan q{};
@@ -1032,6 +1052,7 @@ static LnaPlan lna_plan(const ls_model_desc& d, int layer, int B, int N) {
     q.o_G = take((size_t)B * 3 * 4 * Co * 4);
     q.o_TG = take((size_t)B * N * 3 * 2 * Co * 4);
     q.o_gws = take(global_conv_gws_floats(d, layer, B, N) * 4 + 256);
+    q.o_rm = take((size_t)B * N * 3 * 4);
     q.total = off;
     return q;
 }
@@ -1046,8 +1067,15 @@ int ls_vn_lna_f32(ls_model_t* m, int layer, const float* f, int B, int N, float*
     const LnaPlan q = lna_plan(m->d, layer, B, N);
     if (workspace_bytes < q.total) { set_error("vn_lna: workspace %zu < required %zu", workspace_bytes, q.total); return LS_ERR_WORKSPACE; }
     char* ws = (char*)workspace;
+    const float* rm = nullptr;
+    if (m->glob_fuse == 2) {   // the message's exact row maxima, as the encoder's attention kernels hand them over (GemmAux::a_rowmax)
+        const int Co = m->d.feat_dim[layer];
+        const int rc = gemm_rowmax_launch(f, B * N * 3, Co, Co, (float*)(ws + q.o_rm), (hipStream_t)stream);
+        if (rc != LS_OK) return rc;
+        rm = (const float*)(ws + q.o_rm);
+    }
     return global_conv(m, layer, f, B, N, (float*)(ws + q.o_g), (float*)(ws + q.o_G), (float*)(ws + q.o_TG), (float*)(ws + q.o_gws), out,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, rm);
 }
 
 size_t ls_encoder_tail_workspace_bytes(const ls_model_t* m, int B, int NP) {

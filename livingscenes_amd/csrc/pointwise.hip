@@ -56,6 +56,7 @@ __device__ __forceinline__ void block_top3(float& t0, float& t1, float& t2, floa
 // three values (and scale_0) are bit-identical to it; a cloud whose points all lie on a sphere degenerates to the full scan.
 __global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__ x, int N, float* __restrict__ pts_out,
                                                        float* __restrict__ centroid_out, float* __restrict__ scale0_out) {
+    LS_LATENCY_CRITICAL();
     extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N] centred cloud, then [N] outer-point indices
     __shared__ float red[12];
     __shared__ float redv[4];
@@ -172,13 +173,15 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const float* __restric
 // the critical path of every layer >= 2; here a workgroup computes the instance's mean rows into LDS (same summation order as
 // mean_points_kernel where the layer is narrow) and then its block of columns, one column per lane, k ascending.
 __global__ __launch_bounds__(256) void glob_mean_gemv_kernel(const float* __restrict__ f, int N, int C, const float* __restrict__ W, int col0,
-                                                             int cols_per_block, int ncols, float* __restrict__ G, int ldg) {
+                                                             int cols_per_block, int ncols, float* __restrict__ G, int ldg, float inv) {
+    LS_LATENCY_CRITICAL();
+    // f [B][N][3][C]: the features themselves (inv = 1 / N), or N rows of partial column sums per instance written by the kernel that produced the
+    // features (edge_attn_fq_kernel: one row per workgroup; edge_ft_v_kernel: N = 1) with inv = 1 / (points per instance)
     extern __shared__ float lmean[];           // [3][C]
     __shared__ float4 part[16][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = 3 * C;
     const int cg = tid & 15, rs = tid >> 4;
-    const float inv = 1.0f / (float)N;
     if (row >= 512) {
         // wide rows, few points (layers 5, 6: 32 points x 768 / 1536 floats): a thread owns float4 columns and walks all N rows (eight
         // loads in flight); no LDS combine, no barrier per 64-column chunk (24 chunks x 2 barriers of pure latency at layer 6)
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
                                                    const float* __restrict__ centroid, const float* __restrict__ scale0,
                                                    float* __restrict__ z_so3, float* __restrict__ z_inv,
                                                    float* __restrict__ s_out, float* __restrict__ t_out) {
+    LS_LATENCY_CRITICAL();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* X = sm;                 // [3][Cd]
     float* kdir = X + 3 * Cd;      // [NP][3] normalised shared directions
@@ -458,12 +462,14 @@ int mean_points_launch(const float* f, int B, int N, int C, float* out, hipStrea
     return LS_OK;
 }
 // G[b][x][col0 + j] = <mean_n f[b][n][x][:], W[col0 + j][:]>, j < ncols   (f [B,N,3,C], W [*, C], G [B*3, ldg])
-int glob_mean_gemv_launch(const float* f, int B, int N, int C, const float* W, int col0, int ncols, float* G, int ldg, hipStream_t st) {
+int glob_mean_gemv_launch(const float* f, int B, int N, int C, const float* W, int col0, int ncols, float* G, int ldg, hipStream_t st, int npoints) {
+    // npoints > 0: f holds N rows of partial column sums over npoints points per instance (see the kernel)
     LS_REQUIRE(C % 4 == 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024, "glob_mean_gemv: C=%d unsupported", C);
     int nblk = 1;
     while (B * nblk < 512 && ncols / (nblk * 2) >= 64) nblk *= 2;     // ~two workgroups per CU; at least 64 columns (one wave pass) each
     const int cpb = cdiv(ncols, nblk);
-    hipLaunchKernelGGL(glob_mean_gemv_kernel, dim3(B, cdiv(ncols, cpb)), dim3(256), (size_t)3 * C * sizeof(float), st, f, N, C, W, col0, cpb, ncols, G, ldg);
+    hipLaunchKernelGGL(glob_mean_gemv_kernel, dim3(B, cdiv(ncols, cpb)), dim3(256), (size_t)3 * C * sizeof(float), st, f, N, C, W, col0, cpb, ncols, G, ldg,
+                       1.0f / (float)(npoints > 0 ? npoints : N));
     LS_LAUNCH_CHECK();
     return LS_OK;
 }

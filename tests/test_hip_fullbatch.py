@@ -166,6 +166,28 @@ def test_fused_global_conv_matches_the_two_launch_path():
         assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), (layer, B, N, np.abs(a - b).max())
 
 
+def test_streaming_global_conv_equals_the_tiled_kernels_bit_for_bit():
+    """Layers 2 / 3 (64 channels) run the residual global conv as gemm_vn_direct_kernel when the producer hands over the message's row maxima
+    (the encoder always does): no LDS, eight points per MFMA tile, the VN activation on accumulator registers.  Same operands, products and
+    order as gemm_vn_smallk_kernel / gemm_vn_kernel => IDENTICAL bits.  LS_OPT_GLOB_FUSE = 2 makes the operator export take the exact row maxima
+    first (what the tiled kernels compute for themselves), i.e. the streaming kernel; 1 = the tiled kernels."""
+    from livingscenes_amd import _lib
+    from livingscenes_amd.model_utils import Shape_Prior
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=_dev())
+    hip = sp.hip_model()
+    g = torch.Generator().manual_seed(11)
+    for layer, B, N, scale in ((2, 64, 512, 1.0), (3, 5, 512, 30.0), (2, 3, 64, 1e-3), (3, 1, 8 * 67, 1.0)):
+        C = ecfg["feat_dim"][layer]
+        msg = (torch.randn(B, N, 3, C, generator=g) * scale * torch.rand(B, N, 1, 1, generator=g)).to(_dev())   # rows of very different magnitude
+        a = hip.vn_lna_global(layer, msg)
+        prev = hip.set_option(_lib.OPT_GLOB_FUSE, 2)
+        b = hip.vn_lna_global(layer, msg)
+        hip.set_option(_lib.OPT_GLOB_FUSE, prev)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (layer, B, N, float((a - b).abs().max()))
+
+
 def _run_json(cmd, env, timeout=900):
     import json
     import subprocess
