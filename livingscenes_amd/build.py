@@ -25,7 +25,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # pointwise.hip: the LOOP vectoriser (VF = 2) also forms v_pk_*_f32 (15 in tail_kernel): off for that file
 # per-file additions: {"file.hip": [flags]}.  knn_mfma.hip: the 32 x 32 MFMA results of the sweep kernels are consumed element by element by VALU
 # compares; in AGPRs (hipcc's default) every element costs a v_accvgpr_read first -- 16 extra VALU instructions per tile in VALU-bound kernels
-EXTRA_FLAGS = {"pointwise.hip": ["-fno-vectorize"], "knn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# fps.hip: LS_PRIO=3 -- the FPS kernels (one workgroup per instance, 512 dependent steps) run with a raised wave priority (ls_common.h: LS_LATENCY_CRITICAL):
+# they share their CUs with the chip-filling kernels of layers 0 - 1 and are what layer 2 waits for; one step in flight 40.1k -> 41.2k obj/s, steady state
+# unchanged (58.5k / 58.6k); the same priority on the matcher / heads / 32-point k-NN kernels measured neutral and is left off
+EXTRA_FLAGS = {"pointwise.hip": ["-fno-vectorize"], "knn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "fps.hip": ["-DLS_PRIO=3"]}
 # Build-time pin of the determinism fix above: the device code of these files is disassembled after every compile and the build FAILS
 # if a packed fp32 instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) shows up in a kernel whose name contains none of the
 # allowed substrings -- a future hipcc, a dropped flag or an innocent float2 cannot silently bring the defect back.  Allowed: the

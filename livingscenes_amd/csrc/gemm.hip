@@ -1778,16 +1778,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 // power-of-two scaled rows, scales from GemmAux::a_rowmax / w_rowmax), same three products per 16 k in the same order into one accumulator, ascending k,
 // same integer-exponent epilogue, same activation: BIT-IDENTICAL to gemm_vn_kernel / gemm_vn_smallk_kernel (tests/test_hip_fullbatch.py).  25 % of
 // the MFMA rows are padding: irrelevant, the matrix pipes are idle 90 % of the launch either way.
-template <int C>
+// Work split: a workgroup = two M-streams x two channel halves of ONE instance (its tiles t = stream, stream + streams per instance, ...), so the instance's
+// offsets G (the mean part of the conv) are six registers per lane for the whole launch; the A rows of the next TWO tiles are in flight under a tile's
+// MFMAs, activation and stores (one tile = 8 KB per wave: with eight waves per CU that is the 16 MB in flight the HBM latency asks for).
+// cs != null: G is not read but COMPUTED here from the partial column sums the attention kernel left (edge.hip: attn_colsum; [instance][cs_rows][3][C]) --
+// the mean in glob_mean_gemv_kernel's summation order, then the lane's six dot products with the W_b rows, k ascending: the same values that kernel
+// writes, without its launch (10 - 12 us on the critical path of layers 2 and 3).
+template <int C, bool ONEPART>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_vn_direct_kernel(
-    const float* __restrict__ A, const float* __restrict__ W, int ldw, const float* __restrict__ G, int ldg, float* __restrict__ out, int ntiles, int npts,
-    float oms, GemmAux aux) {
+    const float* __restrict__ A, const float* __restrict__ W, int ldw, const float* __restrict__ G, int ldg, float* __restrict__ out, int npts, int wgs_per_inst,
+    float oms, GemmAux aux, const float* __restrict__ cs, int cs_rows, float cs_inv) {
     static_assert(C == 64, "two waves per M-stream, K = C");
     constexpr int KS = C / 16, NWN = C / 32, SPW = 4 / NWN;
+    __shared__ __attribute__((aligned(16))) float lmean[3 * C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave % NWN, lr = lane & 31, kh = lane >> 5;
-    const int nstreams = gridDim.x * SPW;
+    const int b = blockIdx.x / wgs_per_inst, wg = blockIdx.x - b * wgs_per_inst;
+    const int spi = wgs_per_inst * SPW;                  // M-streams per instance
+    const int tiles_inst = npts / 8;
     const int ch = 32 * wn + lr;
+    const int rofs = (lr >> 2) * 3 + min(lr & 3, 2);      // this lane's A row inside a tile (MFMA row lr = point lr / 4, axis lr % 4)
+    // ---- the first two tiles' rows: requested before anything else.  A tile (24 rows x 256 B = 6 KB contiguous) is fetched COALESCED -- six 16-byte loads per
+    // lane, every cache line by one instruction -- and transposed into MFMA fragments through a wave-private LDS scratch.  (First form of this kernel: every
+    // lane read its own row in eight 16-byte pieces straight from global memory -- each 128-byte line was requested by eight different instructions, the L1
+    // does not merge those misses, and the kernel took 25 - 32 us for 50 MB.)
+    __shared__ __attribute__((aligned(16))) float4 stage[4][24 * 16];
+    // (plain arrays and macros, not a struct handed to lambdas by reference: hipcc kept such a struct in scratch memory -- every tile stored and re-loaded)
+    float4 ra0[6], ra1[6];
+    float ma0 = 0.f, ma1 = 0.f;
+#define LS_VND_LOAD(RA, MA, T)                                                                                                        \
+    {                                                                                                                                 \
+        const size_t R0 = ((size_t)b * tiles_inst + (T)) * 24;                                                                        \
+        if constexpr (ONEPART) MA = aux.a_rowmax[R0 + rofs];                                                                          \
+        else { MA = 0.f; for (int q = 0; q < aux.a_parts; ++q) MA = fmaxf(MA, aux.a_rowmax[(R0 + rofs) * aux.a_parts + q]); }         \
+        const float4* ap = reinterpret_cast<const float4*>(A + R0 * C) + lane;                                                        \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) RA[i] = ap[i * 64];                                                             \
+    }
+    int t = wg * SPW + wave / NWN;
+    LS_VND_LOAD(ra0, ma0, min(t, tiles_inst - 1))            // (unconditional, clamped: the last trips re-read the instance's last tile and drop it)
+    LS_VND_LOAD(ra1, ma1, min(t + spi, tiles_inst - 1))
+    // ---- the weights go through LDS too: a [2C rows][C] block is fetched coalesced (eight 16-byte loads per thread) and read back row-per-lane.  (A lane
+    // reading ITS weight row straight from global memory -- 16 + 32 loads of 16 bytes per lane, each its own L2 transaction -- cost 400 MB of L2 traffic
+    // per launch for 64 KB of weights: 30 us.)  Row r's 16-byte slot s is kept at position s ^ (r & 15): conflict-free both ways.
+    __shared__ __attribute__((aligned(16))) float4 wst[2 * C * (C / 4)];
+    auto stage_w = [&](const float* Wb) {     // rows 0 .. 2C - 1 of Wb (row stride ldw) -> wst
+#pragma unroll
+        for (int i = 0; i < 2 * C * (C / 4) / 256; ++i) {
+            const int idx = i * 256 + threadIdx.x, row = idx / (C / 4), slot = idx % (C / 4);
+            wst[row * (C / 4) + (slot ^ (row & 15))] = *reinterpret_cast<const float4*>(Wb + (size_t)row * ldw + slot * 4);
+        }
+    };
+    auto wslot = [&](int row, int slot) -> const float4& { return wst[row * (C / 4) + (slot ^ (row & 15))]; };
+    stage_w(W);
+    // the partial column sums of this instance (cs path), requested together with the weights
+    float csv[32];
+    if (cs && threadIdx.x < 3 * C) {   // (cs: kernel-uniform)
+        const float* pc = cs + (size_t)b * cs_rows * 3 * C + threadIdx.x;
+#pragma unroll
+        for (int n = 0; n < 32; ++n) csv[n] = pc[(size_t)min(n, cs_rows - 1) * 3 * C];      // (clamped address + select below: a conditional load becomes 32 branches, each with its own wait)
+    }
+    __syncthreads();
     // ---- this wave's W tiles: row j C + ch (j = 0 lin, 1 dir), 8 consecutive k per k-step, split once
     f16x8_t bh[2][KS], bl[2][KS];
     int we[2];
@@ -1797,65 +1847,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         float sw, iw;
         pow2_scale(aux.w_rowmax[wr], sw, iw);
         we[j] = pow2_e(iw);
-        const float* wp = W + (size_t)wr * ldw + kh * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             uint2 h0, l0, h1, l1;
-            split2_f16s<1>(*reinterpret_cast<const float4*>(wp + ks * 16), sw, h0, l0);
-            split2_f16s<1>(*reinterpret_cast<const float4*>(wp + ks * 16 + 4), sw, h1, l1);
+            split2_f16s<1>(wslot(wr, 4 * ks + 2 * kh), sw, h0, l0);
+            split2_f16s<1>(wslot(wr, 4 * ks + 2 * kh + 1), sw, h1, l1);
             bh[j][ks] = __builtin_bit_cast(f16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
             bl[j][ks] = __builtin_bit_cast(f16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
         }
     }
-    // ---- the M-tiles of this wave's stream
-    const int rofs = (lr >> 2) * 3 + min(lr & 3, 2);      // this lane's A row inside a tile (MFMA row lr = point lr / 4, axis lr % 4)
-    float4 raw[KS][2];
-    float ma = 0.f;
-    auto load_tile = [&](int t) {
-        const size_t R = (size_t)t * 24 + rofs;
-        const float* ap = A + R * C + kh * 8;
+    // ---- the instance's per-channel offsets: lin part gl[x] = G[b][x][2C + ch], dir part gd[x] = G[b][x][3C + ch]
+    float gl[3], gd[3];
+    if (cs) {   // kernel-uniform
+        // mean, in glob_mean_gemv_kernel's order: sixteen row slices (rows rs, rs + 16, ...) summed each, then the slices ascending, then * 1 / points
+        // (cs_rows <= 32, model.hip; absent rows add 0, which changes nothing)
+        if (threadIdx.x < 3 * C) {
+            float tsum = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { raw[ks][0] = *reinterpret_cast<const float4*>(ap + ks * 16); raw[ks][1] = *reinterpret_cast<const float4*>(ap + ks * 16 + 4); }
-        ma = 0.f;
-        for (int q = 0; q < aux.a_parts; ++q) ma = fmaxf(ma, aux.a_rowmax[R * aux.a_parts + q]);
-    };
-    int t = blockIdx.x * SPW + wave / NWN;
-    if (t < ntiles) load_tile(t);
-    for (; t < ntiles; t += nstreams) {
-        float sa, ia;
-        pow2_scale(ma, sa, ia);
-        const int ea_own = pow2_e(ia);
-        f16x8_t ah[KS], al[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            uint2 h0, l0, h1, l1;
-            split2_f16s<0>(raw[ks][0], sa, h0, l0);
-            split2_f16s<0>(raw[ks][1], sa, h1, l1);
-            ah[ks] = __builtin_bit_cast(f16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
-            al[ks] = __builtin_bit_cast(f16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            for (int rs = 0; rs < 16; ++rs) {
+                const float ssum = (0.f + (rs < cs_rows ? csv[rs] : 0.f)) + (rs + 16 < cs_rows ? csv[rs + 16] : 0.f);
+                tsum = rs == 0 ? ssum : tsum + ssum;
+            }
+            lmean[threadIdx.x] = tsum * cs_inv;
         }
-        // the instance's per-channel offsets (G: the mean part of the conv) of this tile
-        const int p0 = t * 8;
-        const float* g = G + (size_t)(p0 / npts) * 3 * ldg + 2 * C + ch;
-        float gl[3], gd[3];
+        __syncthreads();                                  // every wave has its W tiles: wst may be overwritten; lmean is complete
+        stage_w(W + (size_t)2 * C * ldw);                 // (W = the conv's [4C][C] matrix: rows 2C .. 4C - 1 multiply the mean)
+        __syncthreads();
+        float al[3] = {0.f, 0.f, 0.f}, ad[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k4 = 0; k4 < C / 4; ++k4) {              // k ascending, one fma chain per output: glob_mean_gemv_kernel's order
+            const float4 w0 = wslot(ch, k4), w1 = wslot(C + ch, k4);
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                const float4 mv = *reinterpret_cast<const float4*>(&lmean[x * C + 4 * k4]);
+                al[x] = __builtin_fmaf(mv.x, w0.x, al[x]); al[x] = __builtin_fmaf(mv.y, w0.y, al[x]); al[x] = __builtin_fmaf(mv.z, w0.z, al[x]); al[x] = __builtin_fmaf(mv.w, w0.w, al[x]);
+                ad[x] = __builtin_fmaf(mv.x, w1.x, ad[x]); ad[x] = __builtin_fmaf(mv.y, w1.y, ad[x]); ad[x] = __builtin_fmaf(mv.z, w1.z, ad[x]); ad[x] = __builtin_fmaf(mv.w, w1.w, ad[x]);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { gl[x] = al[x]; gd[x] = ad[x]; }
+    } else {
+        const float* g = G + (size_t)b * 3 * ldg + 2 * C + ch;
 #pragma unroll
         for (int x = 0; x < 3; ++x) { gl[x] = g[x * ldg]; gd[x] = g[x * ldg + C]; }
-        if (t + nstreams < ntiles) load_tile(t + nstreams);       // next tile's rows in flight under the MFMAs, the activation and the stores
+    }
+    // ---- the M-tiles of this wave's stream
+#ifndef LS_VND_SKIP
+#define LS_VND_SKIP 0      // dev timing variants (wrong results): 1 = no epilogue, 2 = no MFMAs, 4 = no tiles, 8 = no LDS transpose
+#endif
+    if (LS_VND_SKIP & 4) { if (bh[0][0][0] == (_Float16)123.f && gl[0] == 5.f) out[0] = 1.f; return; }
+    auto do_tile = [&](float4 v0_, float4 v1_, float4 v2_, float4 v3_, float4 v4_, float4 v5_, float rma, int tt) {
+        const float4 rv[6] = {v0_, v1_, v2_, v3_, v4_, v5_};     // (by value: an array handed over by reference stayed in scratch memory)
+        float sa, ia;
+        pow2_scale(rma, sa, ia);
+        const int ea_own = pow2_e(ia);
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+        // transpose: lane L holds the 16-byte slot L % 16 of rows 4 i + L / 16; row r's slot s is kept at position s ^ (r & 15), so that both the writes
+        // (a wave instruction = four whole rows) and the fragment reads (sixteen lanes = twelve consecutive rows, one slot) are free of bank conflicts
+        float4* sg = stage[wave];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int row = 4 * i + (lane >> 4);
+            if (!(LS_VND_SKIP & 8)) sg[row * 16 + ((lane & 15) ^ (row & 15))] = rv[i];
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            uint2 h0, l0, h1, l1;
+            const float4 v0 = (LS_VND_SKIP & 8) ? rv[ks] : sg[rofs * 16 + ((4 * ks + 2 * kh) ^ (rofs & 15))], v1 = (LS_VND_SKIP & 8) ? rv[ks + 1] : sg[rofs * 16 + ((4 * ks + 2 * kh + 1) ^ (rofs & 15))];
+            split2_f16s<0>(v0, sa, h0, l0);
+            split2_f16s<0>(v1, sa, h1, l1);
+            const f16x8_t ah = __builtin_bit_cast(f16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y)), al = __builtin_bit_cast(f16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            if (LS_VND_SKIP & 2) { acc[0][ks] += (float)ah[0] + (float)al[1] + (float)bh[0][ks][0]; acc[1][ks] += (float)ah[2] + (float)bl[1][ks][0]; continue; }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[j][ks], acc[j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j][ks], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[j][ks], acc[j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j][ks], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[j][ks], acc[j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j][ks], acc[j], 0, 0, 0);
         }
+        if (LS_VND_SKIP & 1) { if (acc[0][0] + acc[1][0] + acc[0][4] + acc[1][5] + acc[0][8] + acc[1][12] == 12345.f) out[tt] = 1.f; return; }
         // epilogue: accumulator rows 4 g + axis of this lane = point 2 g + kh of the tile
+        const int p0 = (b * tiles_inst + tt) * 8;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int pl = 2 * gq + kh, pt = p0 + pl;
@@ -1880,7 +1956,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 }
             }
         }
+    };
+    for (; t < tiles_inst; t += 2 * spi) {      // two tiles per trip: the buffers keep their names (no register copies)
+        do_tile(ra0[0], ra0[1], ra0[2], ra0[3], ra0[4], ra0[5], ma0, t);
+        LS_VND_LOAD(ra0, ma0, min(t + 2 * spi, tiles_inst - 1))
+        if (t + spi < tiles_inst) {
+            do_tile(ra1[0], ra1[1], ra1[2], ra1[3], ra1[4], ra1[5], ma1, t + spi);
+            LS_VND_LOAD(ra1, ma1, min(t + 3 * spi, tiles_inst - 1))
+        }
     }
+#undef LS_VND_LOAD
 }
 
 // split-K combine: out[m][n] = act(sum_s slab[s][m][n] + bias[n]), slices summed in ascending order (deterministic)
@@ -2130,16 +2215,25 @@ int gemm_dispatch_masked(const float* A, int lda, const float* W, int ldw, float
 bool gemm_vn_supported(int M, int C, int K) {
     return gemm_mode() == 0 && C % 64 == 0 && K % 4 == 0 && K >= 32 && M % 3 == 0;
 }
+// does gemm_vn_dispatch take the streaming kernel (gemm_vn_direct_kernel) for this problem?  Only then is GemmAux::cs honoured (model.hip: global_conv)
+bool gemm_vn_streams(int M, int C, int K, int lda, int npts, const GemmAux& aux) {
+    return gemm_vn_supported(M, C, K) && K == 64 && C == 64 && lda == K && npts % 8 == 0 && aux.a_rowmax && aux.a_parts > 0 && aux.w_rowmax && !aux.noscale &&
+           M >= 24 * 64 && dev_knob("LS_GLOB_DIRECT", 1) != 0;
+}
 int gemm_vn_dispatch(const float* A, int lda, const float* W, int ldw, const float* G, int ldg, float* out, int M, int C, int K, int npts, float oms,
                      hipStream_t st, GemmAux aux) {
     static const bool range_off = dev_knob("LS_GEMM_RANGE", 1) == 0;
     if (range_off) aux.noscale = 1;
     LS_REQUIRE(gemm_vn_supported(M, C, K) && lda % 4 == 0 && ldw % 4 == 0, "gemm_vn: unsupported shape (M=%d C=%d K=%d)", M, C, K);
     const int tm = cdiv(M, 120), tn = C / 64;
-    static const bool direct = dev_knob("LS_GLOB_DIRECT", 1) != 0;     // dev A/B: the streaming kernel of layers 2 / 3
-    if (direct && K == 64 && C == 64 && lda == K && npts % 8 == 0 && aux.a_rowmax && aux.a_parts > 0 && aux.w_rowmax && !aux.noscale && M >= 24 * 64) {
-        const int ntiles = M / 24;
-        hipLaunchKernelGGL(gemm_vn_direct_kernel<64>, dim3(std::min(512, cdiv(ntiles, 2))), dim3(256), 0, st, A, W, ldw, G, ldg, out, ntiles, npts, oms, aux);
+    const bool direct = true;   // (dev A/B: LS_GLOB_DIRECT=0 inside gemm_vn_streams)
+    if (direct && gemm_vn_streams(M, C, K, lda, npts, aux) && (G || aux.cs)) {
+        const int B = M / (3 * npts), tiles_inst = npts / 8;
+        int wpi = cdiv(512, B);                                   // ~512 workgroups (two per CU), every one inside one instance
+        wpi = std::max(1, std::min(wpi, cdiv(tiles_inst, 2)));
+#define LS_VND(ONE) hipLaunchKernelGGL((gemm_vn_direct_kernel<64, ONE>), dim3(B * wpi), dim3(256), 0, st, A, W, ldw, G, ldg, out, npts, wpi, oms, aux, aux.cs, aux.cs_rows, 1.0f / (float)npts)
+        if (aux.a_parts == 1) LS_VND(true); else LS_VND(false);
+#undef LS_VND
         LS_LAUNCH_CHECK();
         return LS_OK;
     }

@@ -377,6 +377,9 @@ __global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW, FMA)) void knn_fused_
         if (lane == 0) L.T[qr] = __uint_as_float(tb);
     }
     __syncthreads();
+#if defined(LS_KF_STOP) && LS_KF_STOP == 1      // dev timing variants (wrong results): the kernel up to the threshold
+    if (L.T[0] != 12345.f) return;
+#endif
     // ---- 3. filter
     {
         unsigned mask[TPW];
@@ -424,6 +427,9 @@ __global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW, FMA)) void knn_fused_
         if (c <= KF_LCAP && j < c) L.plist[L.base[qr] + j] = (unsigned)L.list[qr][j] | ((unsigned)qr << 16) | ((unsigned)j << 21);
     }
     __syncthreads();
+#if defined(LS_KF_STOP) && LS_KF_STOP == 2      // ... up to the flat pair list
+    if (L.T[0] != 12345.f) { if (tid == 0) idx_out[(size_t)b * Nd * K + q0] = L.plist[0]; return; }
+#endif
     {
         // Two pairs in flight per quad: the candidate row of step s + 1 is requested before the chain of step s runs (a step is ~2 us of L2
         // gather latency in front of ~600 cycles of dependent adds; a workgroup has ~5 steps).
@@ -479,6 +485,9 @@ __global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW, FMA)) void knn_fused_
         }
     }
     __syncthreads();
+#if defined(LS_KF_STOP) && LS_KF_STOP == 3      // ... up to the exact distances
+    if (L.T[0] != 12345.f) { if (tid == 0) idx_out[(size_t)b * Nd * K + q0] = (int)L.keys[0][0]; return; }
+#endif
     // ---- 5. select: this wave's four queries, two per pass when both lists fit 32 lanes
     auto emit = [&](int qr, u64 k, int e) {
         const int q = q0 + qr;

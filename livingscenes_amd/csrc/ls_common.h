@@ -140,6 +140,8 @@ struct GemmAux {
     // out[(m / slice_rows) * slice_rows * N + (n / slice_cols) * slice_rows * slice_cols + (m % slice_rows) * slice_cols + n % slice_cols] -- per instance
     // N / slice_cols contiguous slices of [slice_rows][slice_cols] floats.  slice_cols = 4 | 8, slice_rows % 32 == 0; K = 32 / 64 GEMMs only (gemm_h2_smallk_kernel)
     int slice_cols = 0, slice_rows = 0;
+    const float* cs = nullptr;         // gemm_vn_dispatch only: partial column sums of A ([instance][cs_rows][3][C], edge.hip: attn_colsum) -- the kernel forms the
+    int cs_rows = 0;                   // mean part of the conv itself instead of reading G (gemm.hip: gemm_vn_direct_kernel); ignored where that kernel is not taken
 };
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

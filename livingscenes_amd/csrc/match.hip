@@ -31,7 +31,13 @@ __global__ __launch_bounds__(256) void cosine_scores_kernel(const float* __restr
         const int i = w / m, j = w % m;
         const float* a = m0 + (size_t)i * D;
         const float* b = m1 + (size_t)j * D;
-        const float ia = inv_norm[i], ib = inv_norm[n + j];
+        float ia, ib;
+        if (phase == 2) {   // single-launch form (small problems): the entry's wave forms both norms itself -- the same sums in the same order as phase 0
+            float sa = 0.f, sb = 0.f;
+            for (int c = lane; c < D; c += 64) { sa += a[c] * a[c]; sb += b[c] * b[c]; }
+            sa = wave_sum(sa); sb = wave_sum(sb);
+            ia = 1.0f / fmaxf(sqrtf(sa), 1e-12f); ib = 1.0f / fmaxf(sqrtf(sb), 1e-12f);
+        } else { ia = inv_norm[i]; ib = inv_norm[n + j]; }
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += (a[c] * ia) * (b[c] * ib);
         s = wave_sum(s);
@@ -333,6 +339,11 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
 }
 
 int cosine_scores_launch(const float* m0, const float* m1, int n, int m, int D, float* inv_norm_ws, float* S, hipStream_t st) {
+    if ((long long)n * m <= 4096) {   // latency-bound: one launch, every entry's wave recomputes its two row norms (bit-identical to the two-launch form)
+        hipLaunchKernelGGL(cosine_scores_kernel, dim3(cdiv((long long)n * m, 4)), dim3(256), 0, st, m0, m1, n, m, D, inv_norm_ws, S, 2);
+        LS_LAUNCH_CHECK();
+        return LS_OK;
+    }
     hipLaunchKernelGGL(cosine_scores_kernel, dim3(cdiv(n + m, 4)), dim3(256), 0, st, m0, m1, n, m, D, inv_norm_ws, S, 0);
     hipLaunchKernelGGL(cosine_scores_kernel, dim3(cdiv((long long)n * m, 4)), dim3(256), 0, st, m0, m1, n, m, D, inv_norm_ws, S, 1);
     LS_LAUNCH_CHECK();

@@ -67,6 +67,7 @@ int gemm_dispatch_gather(const float*, int, const float*, int, const float*, flo
 int gemm_dispatch_ws(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_small(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, float*, hipStream_t);
 bool gemm_vn_supported(int M, int C, int K);
+bool gemm_vn_streams(int M, int C, int K, int lda, int npts, const GemmAux& aux);
 int gemm_mode();
 int gemm_vn_dispatch(const float*, int, const float*, int, const float*, int, float*, int, int, int, int, float, hipStream_t, GemmAux aux = GemmAux());
 int gemm_dispatch_fast2(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -476,15 +477,20 @@ static int global_conv(ls_model* m, int i, const float* msg, int B, int Nd, floa
     int rc;
     if (m->glob_fuse && gemm_vn_supported(B * Nd * 3, Co, Co)) {
         // per-instance part: mean over the points and its contraction with the W_b / Wd W_b rows in ONE launch (pointwise.hip) ...
-        { PROF(LS_K_MEAN, i, st);
-          rc = (cs && cs_rows > 0) ? glob_mean_gemv_launch(cs, B, cs_rows, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st, Nd)
-                                   : glob_mean_gemv_launch(msg, B, Nd, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st); }
-        if (rc != LS_OK) return rc;
-        // ... then ONE launch for the per-point contraction + the VN activation (gemm.hip: gemm_vn_kernel)
-        PROF(LS_K_GEMM_GLOB, i, st);
         GemmAux ax = aux_w(m, Wg, 2 * Co, Co);
         ax.a_rowmax = rm_msg; ax.a_parts = rm_msg ? rm_msg_parts : 0;
         ax.out_rowmax = rm_out;
+        // 64-channel layers with the producer's column sums: the streaming kernel finishes the mean and its contraction itself -- no mean launch
+        const bool self_mean = cs && cs_rows > 0 && cs_rows <= 32 && gemm_vn_streams(B * Nd * 3, Co, Co, Co, Nd, ax);
+        if (self_mean) { ax.cs = cs; ax.cs_rows = cs_rows; }
+        else {
+            PROF(LS_K_MEAN, i, st);
+            rc = (cs && cs_rows > 0) ? glob_mean_gemv_launch(cs, B, cs_rows, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st, Nd)
+                                     : glob_mean_gemv_launch(msg, B, Nd, Co, Wg, 2 * Co, 2 * Co, G, 4 * Co, st);
+            if (rc != LS_OK) return rc;
+        }
+        // ... then ONE launch for the per-point contraction + the VN activation (gemm.hip: gemm_vn_kernel / gemm_vn_smallk_kernel / gemm_vn_direct_kernel)
+        PROF(LS_K_GEMM_GLOB, i, st);
         if (rm_written) *rm_written = rm_out != nullptr;
         return gemm_vn_dispatch(msg, Co, Wg, Co, G, 4 * Co, out, B * Nd * 3, Co, Co, Nd, 1.0f - d.neg_slope, st, ax);
     }

@@ -299,10 +299,30 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __device__ __forceinline__ void tail_gemv3(const float* __restrict__ Wt, int ldw, int Cd, int n_out, const float* X, float* part, float* R) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cq = (Cd + 3) / 4, c0 = wave * cq, c1 = min(Cd, c0 + cq);
-    for (int ob = 0; ob < n_out; ob += 64 * 4) {      // four outputs per lane per pass
+    // four CONSECUTIVE outputs per lane per pass = one 16-byte weight load per c (round 5: the four-dword form issued 4x the load instructions for the same
+    // bytes; every output still accumulates over its wave's c range in ascending order, so the sums are unchanged bit for bit)
+    const bool v4 = (n_out % 4 == 0) && (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(Wt) & 15) == 0);
+    for (int ob = 0; ob < n_out; ob += 64 * 4) {
         float a[4][3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j][0] = a[j][1] = a[j][2] = 0.f;
+        if (v4) {
+            const int o = ob + lane * 4;
+            const bool in = o < n_out;
+#pragma unroll 16  // sixteen 16-byte weight loads in flight: four L2 round trips per wave for a 64-row c range (a batch of loads is one round trip)
+            for (int c = c0; c < c1; ++c) {
+                const float x0 = X[c], x1 = X[Cd + c], x2 = X[2 * Cd + c];
+                const float4 wv = in ? *reinterpret_cast<const float4*>(Wt + (size_t)c * ldw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[0][0] += wv.x * x0; a[0][1] += wv.x * x1; a[0][2] += wv.x * x2;
+                a[1][0] += wv.y * x0; a[1][1] += wv.y * x1; a[1][2] += wv.y * x2;
+                a[2][0] += wv.z * x0; a[2][1] += wv.z * x1; a[2][2] += wv.z * x2;
+                a[3][0] += wv.w * x0; a[3][1] += wv.w * x1; a[3][2] += wv.w * x2;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (o + j < n_out) { part[(wave * 3 + 0) * n_out + o + j] = a[j][0]; part[(wave * 3 + 1) * n_out + o + j] = a[j][1]; part[(wave * 3 + 2) * n_out + o + j] = a[j][2]; }
+            continue;
+        }
 #pragma unroll 4   // sixteen weight loads in flight
         for (int c = c0; c < c1; ++c) {
             const float x0 = X[c], x1 = X[Cd + c], x2 = X[2 * Cd + c];
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ Tc,
     float ss = 0.f, sn = 0.f;
     for (int c = tid; c < Cd; c += 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 8   // 24 loads in flight (un-unrolled: one L2 round trip per point, ~30 us of the kernel's 70)
+#pragma unroll 16  // 48 loads in flight (un-unrolled: one L2 round trip per point, ~30 us of the kernel's 70; 8: 24 in flight)
         for (int n = 0; n < NP; ++n) {
             const float* r = Tb + (size_t)n * 3 * ldc + c;
             float y0 = r[0], y1 = r[ldc], y2 = r[2 * ldc];
