@@ -217,11 +217,17 @@ __global__ __launch_bounds__(256) void fps_quad_kernel(const float* __restrict__
         // wave arg-max in two single-instruction-per-stage DPP reductions: the maximum value, then the smallest index among the lanes that
         // hold it.  (The 64-bit key network of the one-wave kernel costs ~8 dependent instructions per stage.)
         const float wmax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(wave_max_to_lane63(bv)), 63));
-        const unsigned wci = (unsigned)__builtin_amdgcn_readlane((int)wave_min_to_lane63((bv == wmax) ? (unsigned)bi : 0xFFFFFFFFu), 63);
-        // the lane that holds the wave's winner publishes it (a wave without a live point: every lane holds (-inf, INT_MAX) and writes the
-        // same record, which loses against any live point)
-        if ((unsigned)bi == wci && bv == wmax) {
-            lrec[k & 1][wave] = FpsRec{wmax, wci, bx, by};
+        // the lane that holds the wave's winner publishes it.  Almost always ONE lane holds the maximum (round 5: a ballot tells, and the second DPP
+        // reduction -- six dependent stages + a v_readlane on the critical path of every step -- is skipped); only on an exact tie between lanes is the
+        // smallest index among them reduced (a wave without a live point: every lane holds (-inf, INT_MAX), ties, and writes the same record, which
+        // loses against any live point)
+        bool mine = bv == wmax;
+        if (__builtin_popcountll(__ballot(mine)) != 1) {     // (wave-uniform)
+            const unsigned wci = (unsigned)__builtin_amdgcn_readlane((int)wave_min_to_lane63(mine ? (unsigned)bi : 0xFFFFFFFFu), 63);
+            mine = mine && (unsigned)bi == wci;
+        }
+        if (mine) {
+            lrec[k & 1][wave] = FpsRec{wmax, (unsigned)bi, bx, by};
             lz[k & 1][wave] = bz;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the global stores below stay in flight across steps

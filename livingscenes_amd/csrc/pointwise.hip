@@ -172,6 +172,10 @@ __global__ __launch_bounds__(256) void mean_points_kernel(const float* __restric
 // Until round 3 this took three launches (mean_points_kernel, a 192-row fp32-MFMA GEMM split along K, its reduce) of 5 - 14 us each on
 // the critical path of every layer >= 2; here a workgroup computes the instance's mean rows into LDS (same summation order as
 // mean_points_kernel where the layer is narrow) and then its block of columns, one column per lane, k ascending.
+// sum over aligned groups of 16 lanes, every lane receives it (quad_perm, quad_perm, row_half_mirror, row_mirror: fixed order)
+template <int CTRL>
+__device__ __forceinline__ float dpp_addf(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float sum16_dpp(float v) { return dpp_addf<0x140>(dpp_addf<0x141>(dpp_addf<0x4E>(dpp_addf<0xB1>(v)))); }
 __global__ __launch_bounds__(256) void glob_mean_gemv_kernel(const float* __restrict__ f, int N, int C, const float* __restrict__ W, int col0,
                                                              int cols_per_block, int ncols, float* __restrict__ G, int ldg, float inv) {
     LS_LATENCY_CRITICAL();
@@ -218,25 +222,37 @@ __global__ __launch_bounds__(256) void glob_mean_gemv_kernel(const float* __rest
         }
         __syncthreads();
     }
-    // columns: a LANE owns a column (64 per wave pass), k ascending in 16-byte steps -- the lanes of a wave read 64 different weight rows
-    // (one cache line each per 16 k, fully used over the next three steps out of the L1), the mean values are LDS broadcasts; no reduction
+    // columns: SIXTEEN lanes own a column and walk its weight row together (lane l takes k = 4 l, 4 l + 64, ...: every load instruction reads whole
+    // contiguous row segments), three partial dot products per lane, summed over the sixteen lanes on the DPP network.  (Until round 5 a lane owned a
+    // column and read ITS row 16 bytes at a time: each of those loads is its own L2 transaction -- 26 us at layer 6 for 2 MB of weights.)
     const int j0 = blockIdx.y * cols_per_block, j1 = min(ncols, j0 + cols_per_block);
-    for (int jb = j0 + wave * 64; jb < j1; jb += 256) {
-        const int j = jb + lane;
-        const float* wr = W + (size_t)(col0 + min(j, j1 - 1)) * C;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < C; k += 4) {
-            const float4 w = *reinterpret_cast<const float4*>(wr + k);
-            const float4 m0 = *reinterpret_cast<const float4*>(&lmean[k]), m1 = *reinterpret_cast<const float4*>(&lmean[C + k]),
-                         m2 = *reinterpret_cast<const float4*>(&lmean[2 * C + k]);
-            a0 = __builtin_fmaf(m0.x, w.x, a0); a0 = __builtin_fmaf(m0.y, w.y, a0); a0 = __builtin_fmaf(m0.z, w.z, a0); a0 = __builtin_fmaf(m0.w, w.w, a0);
-            a1 = __builtin_fmaf(m1.x, w.x, a1); a1 = __builtin_fmaf(m1.y, w.y, a1); a1 = __builtin_fmaf(m1.z, w.z, a1); a1 = __builtin_fmaf(m1.w, w.w, a1);
-            a2 = __builtin_fmaf(m2.x, w.x, a2); a2 = __builtin_fmaf(m2.y, w.y, a2); a2 = __builtin_fmaf(m2.z, w.z, a2); a2 = __builtin_fmaf(m2.w, w.w, a2);
+    const int kl = lane & 15, jr = wave * 4 + (lane >> 4);
+    for (int jb = j0; jb < j1; jb += 32) {          // two columns per lane group and trip: more loads in flight
+        float a[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = jb + 16 * u + jr;
+            const float* wr = W + (size_t)(col0 + min(j, j1 - 1)) * C;
+            a[u][0] = a[u][1] = a[u][2] = 0.f;
+#pragma unroll 8
+            for (int k = 4 * kl; k < C; k += 64) {
+                const float4 w = *reinterpret_cast<const float4*>(wr + k);
+                const float4 m0 = *reinterpret_cast<const float4*>(&lmean[k]), m1 = *reinterpret_cast<const float4*>(&lmean[C + k]),
+                             m2 = *reinterpret_cast<const float4*>(&lmean[2 * C + k]);
+                a[u][0] = __builtin_fmaf(m0.x, w.x, a[u][0]); a[u][0] = __builtin_fmaf(m0.y, w.y, a[u][0]); a[u][0] = __builtin_fmaf(m0.z, w.z, a[u][0]); a[u][0] = __builtin_fmaf(m0.w, w.w, a[u][0]);
+                a[u][1] = __builtin_fmaf(m1.x, w.x, a[u][1]); a[u][1] = __builtin_fmaf(m1.y, w.y, a[u][1]); a[u][1] = __builtin_fmaf(m1.z, w.z, a[u][1]); a[u][1] = __builtin_fmaf(m1.w, w.w, a[u][1]);
+                a[u][2] = __builtin_fmaf(m2.x, w.x, a[u][2]); a[u][2] = __builtin_fmaf(m2.y, w.y, a[u][2]); a[u][2] = __builtin_fmaf(m2.z, w.z, a[u][2]); a[u][2] = __builtin_fmaf(m2.w, w.w, a[u][2]);
+            }
         }
-        if (j < j1) {
-            float* gp = G + (size_t)b * 3 * ldg + col0 + j;
-            gp[0] = a0; gp[ldg] = a1; gp[2 * ldg] = a2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = jb + 16 * u + jr;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) a[u][x] = sum16_dpp(a[u][x]);
+            if (kl == 0 && j < j1) {
+                float* gp = G + (size_t)b * 3 * ldg + col0 + j;
+                gp[0] = a[u][0]; gp[ldg] = a[u][1]; gp[2 * ldg] = a[u][2];
+            }
         }
     }
 }

@@ -1,5 +1,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/t7.log
-python bench.py > gpurun_out/b7.json 2> gpurun_out/b7.err
-python bench.py --steps 20 --warmup 5 > gpurun_out/b7_20.json 2> /dev/null
-python __graft_entry__.py --smoke > gpurun_out/smoke7.log 2>&1
+python -m pytest tests/test_hip_layers.py tests/test_hip_fullbatch.py tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -5 > gpurun_out/t8.log
+bash scripts/dev/prof_kernels.sh prof1fl . --inflight 1 > /dev/null 2>&1
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['value']), round(d['ms_per_step'],4), d['check']['handles_bit_identical'][:5])"; }
+python bench.py --cpu-instances 0 --no-fma-variant --no-profile --inflight 1 2>/dev/null | tail -1 | line rel_1fl >> gpurun_out/ab8.log
+python bench.py --cpu-instances 0 --no-fma-variant --no-profile --steps 20 --warmup 5 2>/dev/null | tail -1 | line rel_20 >> gpurun_out/ab8.log
+python bench.py --cpu-instances 0 --no-fma-variant --no-profile 2>/dev/null | tail -1 | line rel >> gpurun_out/ab8.log
