@@ -260,7 +260,8 @@ def main():
         # 12 in the steady state (480 steps: 8 -> 45.9k, 12 -> 47.5k); a short timed region is mostly ramp and drain of that pipeline and
         # the shallower one wastes less of it (20 steps, three repetitions each: 8 -> 44.2 - 44.9k, 10 -> 42.8 - 43.3k, 12 -> 43.9 - 44.1k,
         # 20 -> 42.8 - 43.0k)
-        args.inflight = 12 if args.steps >= 48 else 8
+        # (round 5, after the latency work on the single step: 20 steps at 5 / 7 / 8 / 10 / 12 in flight = 52.2 / 45.5 / 54.3 / 53.2 / 55.0k -- 12 for every run length)
+        args.inflight = 12
 
     # --gpus N is the number of RANKS (one process per GPU).  Started plainly with N > 1 this re-executes itself under
     # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (does not return); started by a launcher it

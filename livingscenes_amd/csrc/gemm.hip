@@ -971,6 +971,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
                 __builtin_amdgcn_sched_barrier(0);
                 continue;
             }
+#ifdef LS_W2_MFMA16
+            // dev TIMING variant (verdict r4 item 8a; wrong results -- the epilogue still assumes the 32 x 32 accumulator map): the same flops as
+            // v_mfma_f32_16x16x32_f16 -- a wave tile = 8 x 4 tiles of 16 x 16, one instruction per 32-k slab and product term; this half step takes the
+            // tiles of rows 64 s2 .. 64 s2 + 63.  Same LDS planes and operand bytes per slab (12 fragments of each piece), same accumulator registers.
+            {
+                typedef float f32x4w __attribute__((ext_vector_type(4)));
+                const int l15 = lane & 15, q4 = lane >> 4;
+                f16x8_t a16[4][2], b16[4][2];
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int r = wn * 64 + j * 16 + l15; b16[j][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bc + pc * PLANE + r * 64 + ((q4 ^ ((r >> 2) & 3)) << 4))); }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + (4 * s2 + i) * 16 + l15; a16[i][pc] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Ac + pc * PLANE + r * 64 + ((q4 ^ ((r >> 2) & 3)) << 4))); }
+                }
+                f32x4w c16[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) c16[i][j][e] = acc[2 * s2 + (i >> 1)][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[i][1], b16[j][0], c16[i][j], 0, 0, 0);
+                if (s2 == 0) { lstore2(An, ra[0], ea[0], swz[0]); lstore2(An, ra[1], ea[1], swz[1]); }
+                else { stage_w(Bn, 0); stage_w(Bn, 1); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[i][0], b16[j][0], c16[i][j], 0, 0, 0);
+                if (s2 == 0) { lstore2(An, ra[2], ea[2], swz[2]); lstore2(An, ra[3], ea[3], swz[3]); gload_a(k0 + 64); }
+                else { stage_w(Bn, 2); stage_w(Bn, 3); gload_b(k0 + 64); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[i][0], b16[j][1], c16[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[2 * s2 + (i >> 1)][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + e] = c16[i][j][e];
+                continue;
+            }
+#endif
             // per accumulator and 16-k step: lo(a) hi(w), hi(a) hi(w), hi(a) lo(w) -- the order every unified-accumulator kernel uses
 #pragma unroll
             for (int i = 0; i < 4; ++i)
