@@ -1,7 +1,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-python scripts/dev/build_variants.py w2m16:gemm.hip=-DLS_W2_MFMA16 > /dev/null
-bash scripts/dev/w2_clock.sh w2m16 > gpurun_out/w2_clock_r5.txt 2>&1
-LS_TAG=product python scripts/dev/w2_time.py >> gpurun_out/w2_time_r5.txt 2>&1
-LS_TAG=mfma16x16x32 LS_LIB_PATH=$PWD/livingscenes_amd/lib/variants/w2m16/liblivingscenes_hip.so python scripts/dev/w2_time.py >> gpurun_out/w2_time_r5.txt 2>&1
-LS_TAG=product python scripts/dev/w2_time.py >> gpurun_out/w2_time_r5.txt 2>&1
-bash scripts/dev/marginal_cost.sh marg_r5 > /dev/null 2>&1
+python -m pytest tests/test_hip_layers.py tests/test_hip_fullbatch.py tests/test_hip_parity.py tests/test_hip_range.py -m gpu -x -q 2>&1 | tail -5 > gpurun_out/t11.log
+bash scripts/dev/prof_kernels.sh prof1fl . --inflight 1 > /dev/null 2>&1
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['value']), round(d['ms_per_step'],4), d['check']['handles_bit_identical'][:5])"; }
+python bench.py --cpu-instances 0 --no-fma-variant --no-profile --inflight 1 2>/dev/null | tail -1 | line rel_1fl >> gpurun_out/ab11.log
+python bench.py --cpu-instances 0 --no-fma-variant --no-profile --steps 20 --warmup 5 2>/dev/null | tail -1 | line rel_20 >> gpurun_out/ab11.log
+python bench.py --cpu-instances 0 --no-fma-variant --no-profile 2>/dev/null | tail -1 | line rel >> gpurun_out/ab11.log

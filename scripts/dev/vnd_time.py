@@ -11,8 +11,10 @@ desc, blob = packing.pack_model(synth.make_encoder_weights(cfg, 0), cfg, None, N
 m = ops.HipModel(desc, blob, d)
 m.set_option(_lib.OPT_GLOB_FUSE, 2)
 g = torch.Generator().manual_seed(3)
-msg = torch.randn(64, 512, 3, 64, generator=g).to(d)
+layer = int(os.environ.get("LAYER", "2"))
+npts = {2: 512, 3: 512, 4: 128, 5: 32, 6: 32}[layer]
+msg = torch.randn(64, npts, 3, cfg["feat_dim"][layer], generator=g).to(d)
 for _ in range(30):
-    out = m.vn_lna_global(2, msg)
+    out = m.vn_lna_global(layer, msg)
 torch.cuda.synchronize()
 print("ok", float(out.abs().max()))

@@ -10,7 +10,7 @@ for v in release vnd1 vnd2 vnd3 vnd4 vnd11; do
   f=$(find /tmp/vp -name "*kernel_stats.csv" | head -1)
   python - "$v" "$f" >> $R/gpurun_out/vnd_variants.txt <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[2])) if any(k in r["Name"] for k in ("gemm_vn_direct", "glob_mean", "gemm_rowmax"))]
+rows = [r for r in csv.DictReader(open(sys.argv[2])) if any(k in r["Name"] for k in ("gemm_vn", "glob_mean", "gemm_rowmax"))]
 print(sys.argv[1], " | ".join(f'{r["Name"][:34]} {float(r["AverageNs"]) / 1e3:.1f} us' for r in rows))
 PY
 done
