@@ -400,8 +400,11 @@ __global__ __launch_bounds__(256) void edge_ft_norms_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------- kernel 2: soft-max and v
+#ifndef LS_FT_V_WPE
+#define LS_FT_V_WPE 2      // dev A/B: waves per SIMD the layer-6 instance (NS == 32, 52 KB of LDS) is compiled for
+#endif
 template <int CIN, int NS, int HG>
-__global__ __launch_bounds__(256, 2) void edge_ft_v_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
+__global__ __launch_bounds__(256, (NS == 32 ? LS_FT_V_WPE : 2)) void edge_ft_v_kernel(const uint4* __restrict__ a_p, const int* __restrict__ ae_p, const uint4* __restrict__ a_q,
                                                         const int* __restrict__ ae_q, const uint4* __restrict__ wplanes, const int* __restrict__ wexp,
                                                         const int32_t* __restrict__ knn, int B, int H, float oms, float inv_sqrt_dk,
                                                         const float* __restrict__ scores, const float* __restrict__ invk, const float* __restrict__ invq,

@@ -1829,8 +1829,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 // offsets G (the mean part of the conv) are six registers per lane for the whole launch; the A rows of the next TWO tiles are in flight under a tile's
 // MFMAs, activation and stores (one tile = 8 KB per wave: with eight waves per CU that is the 16 MB in flight the HBM latency asks for).
 // cs != null: G is not read but COMPUTED here from the partial column sums the attention kernel left (edge.hip: attn_colsum; [instance][cs_rows][3][C]) --
-// the mean in glob_mean_gemv_kernel's summation order, then the lane's six dot products with the W_b rows, k ascending: the same values that kernel
-// writes, without its launch (10 - 12 us on the critical path of layers 2 and 3).
+// the mean (sixteen row slices summed each, then the slices ascending), then the lane's six dot products with the W_b rows, k ascending in one fma chain
+// -- what glob_mean_gemv_kernel would hand over up to the order of its dot products (it sums a weight row over sixteen lanes), without its launch (10 - 12 us
+// on the critical path of layers 2 and 3).  Every path of the encoder that reaches this kernel carries column sums, so the two forms are never mixed.
 template <int C, bool ONEPART>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_vn_direct_kernel(
     const float* __restrict__ A, const float* __restrict__ W, int ldw, const float* __restrict__ G, int ldg, float* __restrict__ out, int npts, int wgs_per_inst,
@@ -1906,7 +1907,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     // ---- the instance's per-channel offsets: lin part gl[x] = G[b][x][2C + ch], dir part gd[x] = G[b][x][3C + ch]
     float gl[3], gd[3];
     if (cs) {   // kernel-uniform
-        // mean, in glob_mean_gemv_kernel's order: sixteen row slices (rows rs, rs + 16, ...) summed each, then the slices ascending, then * 1 / points
+        // mean: sixteen row slices (rows rs, rs + 16, ...) summed each, then the slices ascending, then * 1 / points (glob_mean_gemv_kernel's order)
         // (cs_rows <= 32, model.hip; absent rows add 0, which changes nothing)
         if (threadIdx.x < 3 * C) {
             float tsum = 0.f;
@@ -1922,7 +1923,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         __syncthreads();
         float al[3] = {0.f, 0.f, 0.f}, ad[3] = {0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int k4 = 0; k4 < C / 4; ++k4) {              // k ascending, one fma chain per output: glob_mean_gemv_kernel's order
+        for (int k4 = 0; k4 < C / 4; ++k4) {              // k ascending, one fma chain per output
             const float4 w0 = wslot(ch, k4), w1 = wslot(C + ch, k4);
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
