@@ -290,6 +290,89 @@ __device__ __forceinline__ void ft_gemm_phase_g3(const FtJob<KS> (&jobs)[NJ], co
         }
     }
 }
+
+// The same phase with the A fragments SHARED through LDS (round 5, layer 6 only: its jobs all read the SAME three M-tiles -- source and destination points coincide --
+// and its units are (job, head) pairs, one per wave).  ft_gemm_phase_g3 lets every wave stream its own copy of the A batch from L2 (12 of its 16 KB per two k-steps):
+// the L1 does not merge the four waves' misses, so the layer-6 kernels ask the L2 for 8.4 M requests per step, 8 % of everything it serves (profiles/r5_final/
+// l2_requests_per_kernel.txt).  Here the four waves fetch a quarter of the batch each (three fragments) into a double-buffered 24 KB ring, one barrier per batch; the W
+// fragments stay per wave.  Same products in the same order per accumulator: bit-identical slabs.  (All four waves run the loop -- a wave without a unit only feeds the ring.)
+#ifndef LS_FT_SHARE
+#define LS_FT_SHARE 1      // (0: every wave streams its own A copy -- dev A/B: attention layer 6 101 -> 97 us one step in flight, bench +0.1 .. +1.4 % on the same box, L2 requests of the layer-6 kernels -50 %)
+#endif
+template <int KS, int HG, int NJ>
+__device__ __forceinline__ void ft_gemm_phase_shared(const FtJob<KS> (&jobs)[NJ], const uint4* __restrict__ wplanes, const int* __restrict__ wexp, int head0,
+                                                     int wave, int lane, uint4* ring) {
+    // unit of this wave: job wave / HG, head wave % HG (NJ * HG <= 4)
+    const bool has_unit = wave < NJ * HG;
+    const int j = has_unit ? wave / HG : 0, hl = wave % HG;
+    FtJob<KS> jb = jobs[0];
+#pragma unroll
+    for (int q = 1; q < NJ; ++q)
+        if (j == q) jb = jobs[q];
+    const int T = (head0 + hl) * 5 + jb.p;
+    const char* ab = reinterpret_cast<const char*>(jobs[0].a_planes + ((size_t)jobs[0].mt0 * KS * 2) * 64);     // (every job: the same three M-tiles)
+    const char* wb = reinterpret_cast<const char*>(wplanes + ((size_t)T * KS * 2) * 64);
+    const int we = wexp[T * 32 + (lane & 31)];
+    ff16_t acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    unsigned voff = (unsigned)lane * 16u;
+    // fragment f of a batch (two k-steps k0, k0 + 1): u = f / 6 (k-step), m = (f % 6) / 2 (M-tile), pl = f % 2 (hi | lo plane)
+    auto a_addr = [&](int k0, int f) { const int u = f / 6, m = (f % 6) / 2, pl = f % 2; return ab + (size_t)((m * KS + k0 + u) * 2 + pl) * 1024 + voff; };
+    // (named scalars and a macro, not arrays written inside a lambda: hipcc keeps those in scratch memory)
+    uint4 ra0, ra1, ra2, wn0, wn1, wn2, wn3;
+#define LS_FT_LOAD_BATCH(K0)                                                                              \
+    {                                                                                                     \
+        asm volatile("" : "+v"(voff));                                                                    \
+        ra0 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 0));                                \
+        ra1 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 1));                                \
+        ra2 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 2));                                \
+        wn0 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 0) * 2) * 1024 + voff);               \
+        wn1 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 0) * 2 + 1) * 1024 + voff);           \
+        wn2 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 1) * 2) * 1024 + voff);               \
+        wn3 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 1) * 2 + 1) * 1024 + voff);           \
+    }
+    LS_FT_LOAD_BATCH(0)
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += 2) {
+        uint4* rb = ring + ((k0 >> 1) & 1) * 12 * 64;
+        rb[(wave * 3 + 0) * 64 + lane] = ra0;
+        rb[(wave * 3 + 1) * 64 + lane] = ra1;
+        rb[(wave * 3 + 2) * 64 + lane] = ra2;
+        const fh8_t bh0 = __builtin_bit_cast(fh8_t, wn0), bl0 = __builtin_bit_cast(fh8_t, wn1), bh1 = __builtin_bit_cast(fh8_t, wn2), bl1 = __builtin_bit_cast(fh8_t, wn3);
+        if (k0 + 2 < KS) LS_FT_LOAD_BATCH(k0 + 2)
+        __syncthreads();
+        if (has_unit) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const fh8_t bh = u ? bh1 : bh0, bl = u ? bl1 : bl0;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const fh8_t ah = __builtin_bit_cast(fh8_t, rb[(u * 6 + m * 2) * 64 + lane]), al = __builtin_bit_cast(fh8_t, rb[(u * 6 + m * 2 + 1) * 64 + lane]);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef LS_FT_LOAD_BATCH
+    if (has_unit) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int row0 = 32 * m + 4 * (lane >> 5);
+            float* sp = jb.slab + (size_t)row0 * jb.sld + hl * 32 + (lane & 31);
+            const int* ae = jb.a_exp + (jb.mt0 + m) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                sp[dr * jb.sld] = __builtin_ldexpf(acc[m][r], ae[dr] + we);
+            }
+        }
+    }
+}
 #define LS_FT_PHASE ft_gemm_phase_g3
 
 // thread -> (point, head-local, quad lane, neighbour range) of the attention phases: 256 threads = 32 points x HG heads x 4 lanes x (2 / HG) neighbour halves
@@ -316,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void edge_ft_qk_kernel(const uint4* __restr
     constexpr int KS = CIN / 16, MTP = NS * 3 / 32, MTQ = FND * 3 / 32, SLD = HG * 32 + 4;
     __shared__ __attribute__((aligned(16))) float slab_q[FND * 3 * SLD];    // q phase: Qq (lin | dir); k phase: QK (lin | dir) of the destination points
     __shared__ __attribute__((aligned(16))) float slab_p[NS * 3 * SLD];     // k phase: PK (lin | dir) of the source points
+    __shared__ __attribute__((aligned(16))) uint4 a_ring[(LS_FT_SHARE && NS == 32) ? 2 * 12 * 64 : 1];   // shared A batches (ft_gemm_phase_shared)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int ngroups = H / HG;
@@ -326,7 +410,8 @@ __global__ __launch_bounds__(256, 2) void edge_ft_qk_kernel(const uint4* __restr
     // ---- q = VecLNA_Q(dst_f[n]) of the workgroup's heads (vec_dgcnn_atten.py:207,210)
     {
         const FtJob<KS> jq[1] = {{a_q, ae_q, b * MTQ, MTQ, 4, slab_q, SLD}};
-        LS_FT_PHASE<KS, HG, 1>(jq, wplanes, wexp, head0, wave, lane);
+        if constexpr (LS_FT_SHARE && NS == 32) ft_gemm_phase_shared<KS, HG, 1>(jq, wplanes, wexp, head0, wave, lane, a_ring);
+        else LS_FT_PHASE<KS, HG, 1>(jq, wplanes, wexp, head0, wave, lane);
     }
     __syncthreads();
     const int c4 = mp.hl * 32 + mp.ql * 4;
@@ -349,7 +434,8 @@ __global__ __launch_bounds__(256, 2) void edge_ft_qk_kernel(const uint4* __restr
     // ---- k = VecLNA_K(E[n, k]) = act(PK_lin[nbr] + QK_lin[n], PK_dir[nbr] + QK_dir[n])  (:206,209)
     {
         const FtJob<KS> jk[2] = {{a_p, ae_p, b * MTP, MTP, 1, slab_p, SLD}, {a_q, ae_q, b * MTQ, MTQ, 3, slab_q, SLD}};
-        LS_FT_PHASE<KS, HG, 2>(jk, wplanes, wexp, head0, wave, lane);
+        if constexpr (LS_FT_SHARE && NS == 32) ft_gemm_phase_shared<KS, HG, 2>(jk, wplanes, wexp, head0, wave, lane, a_ring);
+        else LS_FT_PHASE<KS, HG, 2>(jk, wplanes, wexp, head0, wave, lane);
     }
     __syncthreads();
     {
@@ -415,6 +501,7 @@ __global__ __launch_bounds__(256, (NS == 32 ? LS_FT_V_WPE : 2)) void edge_ft_v_k
     constexpr int KS = CIN / 16, MTP = NS * 3 / 32, MTQ = FND * 3 / 32, SLD = HG * 32 + 4;
     __shared__ __attribute__((aligned(16))) float slab_q[FND * 3 * SLD];    // QV (lin | dir) of the destination points
     __shared__ __attribute__((aligned(16))) float slab_p[NS * 3 * SLD];     // PV (lin | dir) of the source points
+    __shared__ __attribute__((aligned(16))) uint4 a_ring[(LS_FT_SHARE && NS == 32) ? 2 * 12 * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int ngroups = H / HG;
@@ -443,7 +530,8 @@ __global__ __launch_bounds__(256, (NS == 32 ? LS_FT_V_WPE : 2)) void edge_ft_v_k
     // ---- v tables of the workgroup's heads
     {
         const FtJob<KS> jv[2] = {{a_p, ae_p, b * MTP, MTP, 0, slab_p, SLD}, {a_q, ae_q, b * MTQ, MTQ, 2, slab_q, SLD}};
-        LS_FT_PHASE<KS, HG, 2>(jv, wplanes, wexp, head0, wave, lane);
+        if constexpr (LS_FT_SHARE && NS == 32) ft_gemm_phase_shared<KS, HG, 2>(jv, wplanes, wexp, head0, wave, lane, a_ring);
+        else LS_FT_PHASE<KS, HG, 2>(jv, wplanes, wexp, head0, wave, lane);
     }
     __syncthreads();
     // ---- soft-max over the 16 neighbours of (point, head) (:211-215); every lane of the (point, head) group computes it for itself
