@@ -1814,20 +1814,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The residual global conv of encoder layers 2 / 3 (K = C = 64, 98 304 rows: 25 MB in, 25 MB out, 1.6 GFLOP) as a STREAMING kernel without LDS
-// and without barriers (round 5).  gemm_vn_smallk_kernel moves a 120-row tile through split -> barrier -> 48 MFMAs -> barrier -> LDS staging -> activation
-// -> store with two workgroups per CU: 28 - 31 us for 6 us of HBM traffic.  Here a WAVE owns 32 output channels (lin AND dir columns: two 32-column
-// MFMA tiles) of a stream of M-tiles; both W tiles stay split in 64 VGPRs for the whole launch.  The trick that removes the LDS transpose of the
-// epilogue: an M-tile is EIGHT points laid out as MFMA rows 4 p + axis (axis 3 = a copy of z, dropped), so that in the 32x32 C/D map (col = lane & 31,
-// rows 8 g + 4 (lane >> 5) + 0..3) a lane holds x, y, z of FOUR whole points for its channel in both accumulators: the VN activation is register-local.
-// The A fragments come straight from global memory (a lane reads 8 consecutive k of its row; the 24 rows of a tile are 6 KB contiguous, every line is
-// used in full across the four k-steps; the next tile's rows are in flight under this tile's MFMAs and activation).  Same operands (split2_f16s of the
-// power-of-two scaled rows, scales from GemmAux::a_rowmax / w_rowmax), same three products per 16 k in the same order into one accumulator, ascending k,
-// same integer-exponent epilogue, same activation: BIT-IDENTICAL to gemm_vn_kernel / gemm_vn_smallk_kernel (tests/test_hip_fullbatch.py).  25 % of
-// the MFMA rows are padding: irrelevant, the matrix pipes are idle 90 % of the launch either way.
+// The residual global conv of encoder layers 2 / 3 (K = C = 64, 98 304 rows: 25 MB in, 25 MB out, 1.6 GFLOP) as a STREAMING kernel: no workgroup barrier
+// in its tile loop and no LDS transpose of the accumulators (round 5).  gemm_vn_smallk_kernel moves a 120-row tile through split -> barrier -> 48 MFMAs ->
+// barrier -> LDS staging -> activation -> store with two workgroups per CU: 28 - 31 us for 6 us of HBM traffic.  Here a WAVE owns 32 output channels (lin AND
+// dir columns: two 32-column MFMA tiles) of a stream of M-tiles; both W tiles stay split in 64 VGPRs for the whole launch.  The trick that removes the LDS
+// transpose of the epilogue: an M-tile is EIGHT points laid out as MFMA rows 4 p + axis (axis 3 = a copy of z, dropped), so that in the 32x32 C/D map
+// (col = lane & 31, rows 8 g + 4 (lane >> 5) + 0..3) a lane holds x, y, z of FOUR whole points for its channel in both accumulators: the VN activation is
+// register-local.  Operands: the 24 rows of a tile are 6 KB contiguous -- fetched COALESCED (six 16-byte loads per lane) and turned into MFMA fragments through
+// a wave-private, XOR-swizzled LDS scratch (no barrier: a wave's LDS operations complete in order); the weight blocks go through LDS once per workgroup.  (A
+// lane that reads ITS row of a matrix from global memory 16 bytes at a time costs one L2 transaction per piece: the first forms of this kernel did, and
+// took 25 - 32 us.)  Same operands (split2_f16s of the power-of-two scaled rows, scales from GemmAux::a_rowmax / w_rowmax), same three products per 16 k in
+// the same order into one accumulator, ascending k, same integer-exponent epilogue, same activation: BIT-IDENTICAL to gemm_vn_kernel /
+// gemm_vn_smallk_kernel (tests/test_hip_fullbatch.py).  25 % of the MFMA rows are padding: irrelevant, the matrix pipes are idle 90 % of the launch either way.
+// Measured: 24 us in the encoder (alone 16: prologue 4.1, + loads / transpose / split 2.6, + MFMAs 4, + epilogue 5 -- two waves per SIMD do not overlap the
+// phases of a tile; docs/history.md 13.6).
 // Work split: a workgroup = two M-streams x two channel halves of ONE instance (its tiles t = stream, stream + streams per instance, ...), so the instance's
 // offsets G (the mean part of the conv) are six registers per lane for the whole launch; the A rows of the next TWO tiles are in flight under a tile's
-// MFMAs, activation and stores (one tile = 8 KB per wave: with eight waves per CU that is the 16 MB in flight the HBM latency asks for).
+// MFMAs, activation and stores (one tile = 6 KB per wave).
 // cs != null: G is not read but COMPUTED here from the partial column sums the attention kernel left (edge.hip: attn_colsum; [instance][cs_rows][3][C]) --
 // the mean (sixteen row slices summed each, then the slices ascending), then the lane's six dot products with the W_b rows, k ascending in one fma chain
 // -- what glob_mean_gemv_kernel would hand over up to the order of its dot products (it sums a weight row over sixteen lanes), without its launch (10 - 12 us
