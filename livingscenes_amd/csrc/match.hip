@@ -34,11 +34,13 @@ __global__ __launch_bounds__(256) void cosine_scores_kernel(const float* __restr
         float ia, ib;
         if (phase == 2) {   // single-launch form (small problems): the entry's wave forms both norms itself -- the same sums in the same order as phase 0
             float sa = 0.f, sb = 0.f;
+#pragma unroll 4
             for (int c = lane; c < D; c += 64) { sa += a[c] * a[c]; sb += b[c] * b[c]; }
             sa = wave_sum(sa); sb = wave_sum(sb);
             ia = 1.0f / fmaxf(sqrtf(sa), 1e-12f); ib = 1.0f / fmaxf(sqrtf(sb), 1e-12f);
         } else { ia = inv_norm[i]; ib = inv_norm[n + j]; }
         float s = 0.f;
+#pragma unroll 4
         for (int c = lane; c < D; c += 64) s += (a[c] * ia) * (b[c] * ib);
         s = wave_sum(s);
         if (lane == 0) S[w] = s;
@@ -279,32 +281,52 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
     const float* w = weights ? weights + (size_t)p * n : nullptr;
     // weights / (sum + eps)   (pose_estimation.py:52-54); raw_weights: the caller already applied :52-66 (normalisation,
     // best_k selection, w_threshold zeroing WITHOUT renormalising) and the weights are used as they are
+    // Up to 256 points per problem (the codes' 256 pseudo-points): every point of the lane is fetched ONCE, up front, into registers -- the three passes below
+    // (sums, covariance, residuals) were rolled loops of loads, i.e. one L2 round trip per 64 points and pass (round 5: 15 -> ~8 us at the end of every
+    // encode + match + register step).  Same per-lane order (i = lane, lane + 64, ...), same arithmetic: identical results.  More points: the loops.
+    const bool small = n <= 256;
+    float pa[4][3], pb[4][3], pw[4];
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = lane + 64 * u, ii = i < n ? i : 0;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) { pa[u][x] = A_(ii, x); pb[u][x] = B_(ii, x); }
+            pw[u] = w ? w[ii] : 1.0f;
+        }
+    }
+#define LS_KB_POINTS(...)                                                                                                      \
+    if (small) {                                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                        \
+            const int i = lane + 64 * u;                                                                                       \
+            if (i < n) { const float ax = pa[u][0], ay = pa[u][1], az = pa[u][2], bx = pb[u][0], by = pb[u][1], bz = pb[u][2], wraw = pw[u]; __VA_ARGS__ }  \
+        }                                                                                                                      \
+    } else {                                                                                                                   \
+        for (int i = lane; i < n; i += 64) {                                                                                   \
+            const float ax = A_(i, 0), ay = A_(i, 1), az = A_(i, 2), bx = B_(i, 0), by = B_(i, 1), bz = B_(i, 2), wraw = w ? w[i] : 1.0f; __VA_ARGS__ \
+        }                                                                                                                      \
+    }
     float sw = 0.f;
-    for (int i = lane; i < n; i += 64) sw += w ? w[i] : 1.0f;
+    LS_KB_POINTS({ (void)ax; (void)ay; (void)az; (void)bx; (void)by; (void)bz; sw += wraw; })
     sw = (raw_weights && w) ? 1.0f : wave_sum(sw) + eps;
     // weighted means, divided by (sum of normalised weights + eps)  (:68-69)
     float m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0}, swn = 0.f;
-    for (int i = lane; i < n; i += 64) {
-        const float wi = (w ? w[i] : 1.0f) / sw;
+    LS_KB_POINTS({
+        const float wi = wraw / sw;
         swn += wi;
-#pragma unroll
-        for (int x = 0; x < 3; ++x) { m1[x] += wi * A_(i, x); m2[x] += wi * B_(i, x); }
-    }
+        m1[0] += wi * ax; m2[0] += wi * bx; m1[1] += wi * ay; m2[1] += wi * by; m1[2] += wi * az; m2[2] += wi * bz;
+    })
     swn = wave_sum(swn) + eps;
 #pragma unroll
     for (int x = 0; x < 3; ++x) { m1[x] = wave_sum(m1[x]) / swn; m2[x] = wave_sum(m2[x]) / swn; }
     // covariance H = sum_i w_i (x1_i - mu1)(x2_i - mu2)^T   (:71-77)
     float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = lane; i < n; i += 64) {
-        const float wi = (w ? w[i] : 1.0f) / sw;
-        float c1[3], c2[3];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) { c1[x] = A_(i, x) - m1[x]; c2[x] = B_(i, x) - m2[x]; }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) H[r * 3 + c] += wi * c1[r] * c2[c];
-    }
+    LS_KB_POINTS({
+        const float wi = wraw / sw;
+        const float c1[3] = {ax - m1[0], ay - m1[1], az - m1[2]}, c2[3] = {bx - m2[0], by - m2[1], bz - m2[2]};
+        _Pragma("unroll") for (int r = 0; r < 3; ++r)
+            _Pragma("unroll") for (int c = 0; c < 3; ++c) H[r * 3 + c] += wi * c1[r] * c2[c];
+    })
     double Hd[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) Hd[e] = (double)wave_sum(H[e]);
@@ -324,17 +346,19 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ x
     }
     // residuals |R x1 + t - x2|   (:105-121)
     float rs = 0.f;
-    for (int i = lane; i < n; i += 64) {
+    LS_KB_POINTS({
+        (void)wraw;
+        const float bb[3] = {bx, by, bz};
         float e2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float d = R[r * 3] * A_(i, 0) + R[r * 3 + 1] * A_(i, 1) + R[r * 3 + 2] * A_(i, 2) + t[r] - B_(i, r);
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {
+            const float d = R[r * 3] * ax + R[r * 3 + 1] * ay + R[r * 3 + 2] * az + t[r] - bb[r];
             e2 += d * d;
         }
         const float e = sqrtf(e2);
         if (res) res[(size_t)p * n + i] = e;
         rs += e;
-    }
+    })
+#undef LS_KB_POINTS
     if (res_mean) { rs = wave_sum(rs); if (lane == 0) res_mean[p] = rs / (float)n; }
 }
 
