@@ -20,6 +20,7 @@ __device__ __forceinline__ void top3_insert(float v, float& a, float& b, float& 
 __device__ __forceinline__ void stage_and_centroid(const float* __restrict__ xb, int N, float* sp, float* red, float c[3]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4   // (twelve loads in flight at N = 1024: rolled, the cold cloud costs one HBM round trip per 256 points)
     for (int n = tid; n < N; n += 256) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { const float v = xb[(size_t)a * N + n]; sp[a * N + n] = v; s[a] += v; }
