@@ -9,11 +9,14 @@ namespace ls {
 // scale_0 = mean(top-5 of the N*N entries of cdist(x,x)); x /= scale_0.  The symmetric matrix holds every
 // unordered pair twice, so top-5 = (d1,d1,d2,d2,d3) with d1>=d2>=d3 the three largest pair distances.
 // One workgroup per instance; cloud staged in LDS; each thread keeps a private top-3 of squared distances.
+// (branch-free, five instructions: the nested-branch form diverges per lane inside the pair loops -- the same three values; a NaN v is ignored by fmaxf / fminf
+//  exactly as the comparisons ignored it)
 __device__ __forceinline__ void top3_insert(float v, float& a, float& b, float& c) {
-    if (v > c) {
-        if (v > b) { c = b; if (v > a) { b = a; a = v; } else b = v; }
-        else c = v;
-    }
+    const float m = fminf(a, v);
+    a = fmaxf(a, v);
+    const float m2 = fminf(b, m);
+    b = fmaxf(b, m);
+    c = fmaxf(c, m2);
 }
 
 // centroid of instance b, cloud staged (un-centred) into sp[3][N]
@@ -56,9 +59,9 @@ __device__ __forceinline__ void block_top3(float& t0, float& t1, float& t2, floa
 // centroid).  Those "outer" points are compacted and scanned pairwise with the same fp32 formula as the full scan, so the
 // three values (and scale_0) are bit-identical to it; a cloud whose points all lie on a sphere degenerates to the full scan.
 __global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__ x, int N, float* __restrict__ pts_out,
-                                                       float* __restrict__ centroid_out, float* __restrict__ scale0_out) {
+                                                       float* __restrict__ centroid_out, float* __restrict__ scale0_out, int dense) {
     LS_LATENCY_CRITICAL();
-    extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N] centred cloud, then [N] outer-point indices
+    extern __shared__ __attribute__((aligned(16))) float sp[];  // [3][N] centred cloud, then [N] outer-point indices, then their coordinates [3][N]
     __shared__ float red[12];
     __shared__ float redv[4];
     __shared__ int redi[4];
@@ -109,15 +112,34 @@ __global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__
     }
     __syncthreads();
     const int M = nouter;
-    // all pairs among the outer points: thread -> rows i = tid/32 + 8k of the pair matrix, columns strided by 32
+    // the outer points' coordinates, dense ([3][M] behind the index list): the pair loop then reads its operands directly -- one LDS round trip per pair
+    // instead of two dependent ones (index, then coordinates) -- and its reads are independent, so the unrolled loop keeps several pairs in flight.  (Round 5:
+    // the scan of the slowest instance of a batch -- a few hundred outer points -- was 33 of the kernel's 46 us.)
     t0 = t1 = t2 = -1.f;
-    for (int i = tid >> 5; i < M; i += 8) {
-        const int pi = outer[i];
-        const float px = sp[pi], py = sp[N + pi], pz = sp[2 * N + pi];
-        for (int j = i + 1 + (tid & 31); j < M; j += 32) {
-            const int pj = outer[j];
-            const float dx = px - sp[pj], dy = py - sp[N + pj], dz = pz - sp[2 * N + pj];
-            top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
+    if (dense) {   // (kernel-uniform: the launch reserved the extra 3 N floats)
+        float* ox = reinterpret_cast<float*>(outer + N);
+        float* oy = ox + N;
+        float* oz = oy + N;
+        for (int i = tid; i < M; i += 256) { const int pi = outer[i]; ox[i] = sp[pi]; oy[i] = sp[N + pi]; oz[i] = sp[2 * N + pi]; }
+        __syncthreads();
+        // all pairs among the outer points: thread -> rows i = tid/32 + 8k of the pair matrix, columns strided by 32
+        for (int i = tid >> 5; i < M; i += 8) {
+            const float px = ox[i], py = oy[i], pz = oz[i];
+#pragma unroll 4
+            for (int j = i + 1 + (tid & 31); j < M; j += 32) {
+                const float dx = px - ox[j], dy = py - oy[j], dz = pz - oz[j];
+                top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
+            }
+        }
+    } else {       // large clouds (the dense copy would not fit the default LDS): through the index list
+        for (int i = tid >> 5; i < M; i += 8) {
+            const int pi = outer[i];
+            const float px = sp[pi], py = sp[N + pi], pz = sp[2 * N + pi];
+            for (int j = i + 1 + (tid & 31); j < M; j += 32) {
+                const int pj = outer[j];
+                const float dx = px - sp[pj], dy = py - sp[N + pj], dz = pz - sp[2 * N + pj];
+                top3_insert(dx * dx + dy * dy + dz * dz, t0, t1, t2);
+            }
         }
     }
     block_top3(t0, t1, t2, red);
@@ -481,7 +503,8 @@ int scatter_codes_launch(const float* packed, int B, int c, float* z_so3, float*
 size_t prologue_scratch_floats(int B) { (void)B; return 0; }
 int prologue_launch(const float* x, int B, int N, float* pts, float* centroid, float* scale0, float* /*unused*/, hipStream_t st) {
     LS_REQUIRE(N >= 3 && N <= 8192, "prologue: N=%d out of range (3..8192)", N);
-    hipLaunchKernelGGL(prologue_kernel, dim3(B), dim3(256), (size_t)4 * N * sizeof(float), st, x, N, pts, centroid, scale0);
+    const int dense = (size_t)7 * N * sizeof(float) <= 64 * 1024;   // cloud [3][N], outer indices [N] (, their coordinates [3][N])
+    hipLaunchKernelGGL(prologue_kernel, dim3(B), dim3(256), (size_t)(dense ? 7 : 4) * N * sizeof(float), st, x, N, pts, centroid, scale0, dense);
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
