@@ -526,7 +526,11 @@ int glob_mean_gemv_launch(const float* f, int B, int N, int C, const float* W, i
     // npoints > 0: f holds N rows of partial column sums over npoints points per instance (see the kernel)
     LS_REQUIRE(C % 4 == 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024, "glob_mean_gemv: C=%d unsupported", C);
     int nblk = 1;
-    while (B * nblk < 512 && ncols / (nblk * 2) >= 64) nblk *= 2;     // ~two workgroups per CU; at least 64 columns (one wave pass) each
+    // column blocks per instance: with the mean taken from a few rows of partial sums (npoints > 0) the kernel is two dependent round trips + its column
+    // trips of 32 columns -- one trip per workgroup then (up to 2 048 small workgroups: 18 -> ~8 us at layer 6); reading the whole message (npoints == 0)
+    // every extra block re-reads it: ~two workgroups per CU, at least 64 columns each
+    const int wg_cap = npoints > 0 ? 2048 : 512, min_cols = npoints > 0 ? 32 : 64;
+    while (B * nblk < wg_cap && ncols / (nblk * 2) >= min_cols) nblk *= 2;
     const int cpb = cdiv(ncols, nblk);
     hipLaunchKernelGGL(glob_mean_gemv_kernel, dim3(B, cdiv(ncols, cpb)), dim3(256), (size_t)3 * C * sizeof(float), st, f, N, C, W, col0, cpb, ncols, G, ldg,
                        1.0f / (float)(npoints > 0 ? npoints : N));
