@@ -321,43 +321,55 @@ __device__ __forceinline__ void ft_gemm_phase_shared(const FtJob<KS> (&jobs)[NJ]
     unsigned voff = (unsigned)lane * 16u;
     // fragment f of a batch (two k-steps k0, k0 + 1): u = f / 6 (k-step), m = (f % 6) / 2 (M-tile), pl = f % 2 (hi | lo plane)
     auto a_addr = [&](int k0, int f) { const int u = f / 6, m = (f % 6) / 2, pl = f % 2; return ab + (size_t)((m * KS + k0 + u) * 2 + pl) * 1024 + voff; };
-    // (named scalars and a macro, not arrays written inside a lambda: hipcc keeps those in scratch memory)
-    uint4 ra0, ra1, ra2, wn0, wn1, wn2, wn3;
-#define LS_FT_LOAD_BATCH(K0)                                                                              \
+    // THREE batches of loads in flight per wave (the set consumed in step s was requested in step s - 3): with the A fragments shared a batch costs a wave only
+    // 7 x 16 bytes per lane, so three sets are 84 VGPRs -- the private-copy form had room for one batch (64 VGPRs), and every one of a phase's eight batches waited
+    // ~2 us for its L2 round trip in front of 0.24 us of MFMAs.  (Register sets indexed by compile-time constants of the fully unrolled loop, filled by a macro:
+    // arrays written inside a lambda stay in scratch memory.)
+    constexpr int NB = KS / 2;
+    uint4 sA_r0, sA_r1, sA_r2, sA_w0, sA_w1, sA_w2, sA_w3, sB_r0, sB_r1, sB_r2, sB_w0, sB_w1, sB_w2, sB_w3, sC_r0, sC_r1, sC_r2, sC_w0, sC_w1, sC_w2, sC_w3;
+#define LS_FT_LOAD_BATCH(S, K0)                                                                           \
     {                                                                                                     \
         asm volatile("" : "+v"(voff));                                                                    \
-        ra0 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 0));                                \
-        ra1 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 1));                                \
-        ra2 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 2));                                \
-        wn0 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 0) * 2) * 1024 + voff);               \
-        wn1 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 0) * 2 + 1) * 1024 + voff);           \
-        wn2 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 1) * 2) * 1024 + voff);               \
-        wn3 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 1) * 2 + 1) * 1024 + voff);           \
+        S##_r0 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 0));                             \
+        S##_r1 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 1));                             \
+        S##_r2 = *reinterpret_cast<const uint4*>(a_addr((K0), wave * 3 + 2));                             \
+        S##_w0 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 0) * 2) * 1024 + voff);            \
+        S##_w1 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 0) * 2 + 1) * 1024 + voff);        \
+        S##_w2 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 1) * 2) * 1024 + voff);            \
+        S##_w3 = *reinterpret_cast<const uint4*>(wb + (size_t)(((K0) + 1) * 2 + 1) * 1024 + voff);        \
     }
-    LS_FT_LOAD_BATCH(0)
-#pragma unroll
-    for (int k0 = 0; k0 < KS; k0 += 2) {
-        uint4* rb = ring + ((k0 >> 1) & 1) * 12 * 64;
-        rb[(wave * 3 + 0) * 64 + lane] = ra0;
-        rb[(wave * 3 + 1) * 64 + lane] = ra1;
-        rb[(wave * 3 + 2) * 64 + lane] = ra2;
-        const fh8_t bh0 = __builtin_bit_cast(fh8_t, wn0), bl0 = __builtin_bit_cast(fh8_t, wn1), bh1 = __builtin_bit_cast(fh8_t, wn2), bl1 = __builtin_bit_cast(fh8_t, wn3);
-        if (k0 + 2 < KS) LS_FT_LOAD_BATCH(k0 + 2)
-        __syncthreads();
-        if (has_unit) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const fh8_t bh = u ? bh1 : bh0, bl = u ? bl1 : bl0;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const fh8_t ah = __builtin_bit_cast(fh8_t, rb[(u * 6 + m * 2) * 64 + lane]), al = __builtin_bit_cast(fh8_t, rb[(u * 6 + m * 2 + 1) * 64 + lane]);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
-                }
-            }
-        }
+#define LS_FT_STEP(S, BI)                                                                                                                          \
+    {                                                                                                                                              \
+        uint4* rb = ring + ((BI) & 1) * 12 * 64;                                                                                                   \
+        rb[(wave * 3 + 0) * 64 + lane] = S##_r0;                                                                                                   \
+        rb[(wave * 3 + 1) * 64 + lane] = S##_r1;                                                                                                   \
+        rb[(wave * 3 + 2) * 64 + lane] = S##_r2;                                                                                                   \
+        const fh8_t bh0 = __builtin_bit_cast(fh8_t, S##_w0), bl0 = __builtin_bit_cast(fh8_t, S##_w1), bh1 = __builtin_bit_cast(fh8_t, S##_w2),     \
+                    bl1 = __builtin_bit_cast(fh8_t, S##_w3);                                                                                       \
+        if ((BI) + 3 < NB) LS_FT_LOAD_BATCH(S, 2 * ((BI) + 3))                                                                                     \
+        __syncthreads();                                                                                                                           \
+        if (has_unit) {                                                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                                        \
+                const fh8_t bh = u ? bh1 : bh0, bl = u ? bl1 : bl0;                                                                                \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                                                    \
+                    const fh8_t ah = __builtin_bit_cast(fh8_t, rb[(u * 6 + m * 2) * 64 + lane]), al = __builtin_bit_cast(fh8_t, rb[(u * 6 + m * 2 + 1) * 64 + lane]); \
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);                                                      \
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);                                                      \
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);                                                      \
+                }                                                                                                                                  \
+            }                                                                                                                                      \
+        }                                                                                                                                          \
     }
+    LS_FT_LOAD_BATCH(sA, 0)
+    if (1 < NB) LS_FT_LOAD_BATCH(sB, 2)
+    if (2 < NB) LS_FT_LOAD_BATCH(sC, 4)
+#pragma unroll
+    for (int bi = 0; bi < NB; bi += 3) {
+        LS_FT_STEP(sA, bi)
+        if (bi + 1 < NB) LS_FT_STEP(sB, bi + 1)
+        if (bi + 2 < NB) LS_FT_STEP(sC, bi + 2)
+    }
+#undef LS_FT_STEP
 #undef LS_FT_LOAD_BATCH
     if (has_unit) {
 #pragma unroll
