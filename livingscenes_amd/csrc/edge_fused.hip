@@ -214,9 +214,82 @@ struct FtJob { const uint4* a_planes; const int* a_exp; int mt0; int MT; int p; 
 #ifndef LS_FT_KB
 #define LS_FT_KB 2
 #endif
+// one unit of work: MPU consecutive M-tiles (first: tile `tile0` of the job) x one weight tile -> the job's slab
+template <int KS, int MPU>
+__device__ __forceinline__ void ft_gemm_unit(const FtJob<KS>& jb, int tile0, int hl, int T, const uint4* __restrict__ wplanes, const int* __restrict__ wexp, int lane) {
+    const char* ab = reinterpret_cast<const char*>(jb.a_planes + ((size_t)(jb.mt0 + tile0) * KS * 2) * 64);
+    const char* wb = reinterpret_cast<const char*>(wplanes + ((size_t)T * KS * 2) * 64);
+    const int we = wexp[T * 32 + (lane & 31)];
+    ff16_t acc[MPU];
+#pragma unroll
+    for (int m = 0; m < MPU; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    unsigned voff = (unsigned)lane * 16u;
+    constexpr int KB = LS_FT_KB;   // k-steps per batch
+    struct Stage { fh8_t ah[MPU][KB], al[MPU][KB], bh[KB], bl[KB]; };
+    auto load_stage = [&](Stage& sg, int k0) {
+        asm volatile("" : "+v"(voff));
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            sg.bh[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2) * 1024 + voff));
+            sg.bl[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2 + 1) * 1024 + voff));
+#pragma unroll
+            for (int m = 0; m < MPU; ++m) {
+                sg.ah[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2) * 1024 + voff));
+                sg.al[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2 + 1) * 1024 + voff));
+            }
+        }
+    };
+    auto run_stage = [&](const Stage& sg) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+#pragma unroll
+            for (int m = 0; m < MPU; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.al[m][u], sg.bh[u], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.ah[m][u], sg.bh[u], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.ah[m][u], sg.bl[u], acc[m], 0, 0, 0);
+            }
+#pragma unroll
+        for (int m = 0; m < MPU; ++m) asm volatile("" : "+v"(acc[m])::"memory");
+    };
+    // (Two register stages -- batch b + 1 requested before batch b's MFMAs -- were built and measured: layers 5 / 6 79.3 / 103.4 us against 80.7 / 102.9 us
+    //  alone, bench 53.96k against 54.37k: 64 more VGPRs buy no overlap that an L2 round trip of ~2 us against 576 matrix-pipe cycles could use.
+    //  Batches of one k-step (137 - 165 VGPRs): 88 / 105 us, 53.5k; of four (212 - 238): 82 / 112 us, 53.4k; two it is: 81 / 102 us, 54.1k.)
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += KB) {
+        Stage sg;
+        load_stage(sg, k0);
+        __builtin_amdgcn_sched_barrier(0);   // (all requests of the batch first: the scheduler would sink each load to its MFMA)
+        run_stage(sg);
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int m = 0; m < MPU; ++m) {
+        const int mt = tile0 + m;
+        const int row0 = 32 * mt + 4 * (lane >> 5);
+        float* sp = jb.slab + (size_t)row0 * jb.sld + hl * 32 + (lane & 31);
+        const int* ae = jb.a_exp + (jb.mt0 + mt) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            sp[dr * jb.sld] = __builtin_ldexpf(acc[m][r], ae[dr] + we);
+        }
+    }
+}
 template <int KS, int HG, int NJ>
 __device__ __forceinline__ void ft_gemm_phase_g3(const FtJob<KS> (&jobs)[NJ], const uint4* __restrict__ wplanes, const int* __restrict__ wexp, int head0,
                                                  int wave, int lane) {
+    // Layer 5's two-job phases (one head; 12 source M-tiles + 3 destination M-tiles) were FIVE three-tile units for four waves: wave 0 ran two of them, the
+    // phase took six tile-times.  Round 5: the four source groups first, one per wave, then the destination job as three single-tile units on waves 0 - 2:
+    // four tile-times (the weight tile of the small job is streamed three times instead of once).  Same products per accumulator: identical slabs.
+    if constexpr (NJ == 2 && HG == 1) {
+        if (jobs[0].MT == 12 && jobs[1].MT == 3) {     // (kernel-uniform)
+            ft_gemm_unit<KS, 3>(jobs[0], 3 * wave, 0, head0 * 5 + jobs[0].p, wplanes, wexp, lane);
+            if (wave < 3) ft_gemm_unit<KS, 1>(jobs[1], wave, 0, head0 * 5 + jobs[1].p, wplanes, wexp, lane);
+            return;
+        }
+    }
     int total = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) total += (jobs[j].MT / 3) * HG;
@@ -229,65 +302,8 @@ __device__ __forceinline__ void ft_gemm_phase_g3(const FtJob<KS> (&jobs)[NJ], co
 #pragma unroll
         for (int q = 1; q < NJ; ++q)
             if (j == q) jb = jobs[q];
-        const int ng = jb.MT / 3, hl = off / ng, g = off - hl * ng, T = (head0 + hl) * 5 + jb.p;
-        const char* ab = reinterpret_cast<const char*>(jb.a_planes + ((size_t)(jb.mt0 + 3 * g) * KS * 2) * 64);
-        const char* wb = reinterpret_cast<const char*>(wplanes + ((size_t)T * KS * 2) * 64);
-        const int we = wexp[T * 32 + (lane & 31)];
-        ff16_t acc[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        unsigned voff = (unsigned)lane * 16u;
-        constexpr int KB = LS_FT_KB;   // k-steps per batch
-        struct Stage { fh8_t ah[3][KB], al[3][KB], bh[KB], bl[KB]; };
-        auto load_stage = [&](Stage& sg, int k0) {
-            asm volatile("" : "+v"(voff));
-#pragma unroll
-            for (int u = 0; u < KB; ++u) {
-                sg.bh[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2) * 1024 + voff));
-                sg.bl[u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(wb + (size_t)((k0 + u) * 2 + 1) * 1024 + voff));
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    sg.ah[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2) * 1024 + voff));
-                    sg.al[m][u] = __builtin_bit_cast(fh8_t, *reinterpret_cast<const uint4*>(ab + (size_t)((m * KS + k0 + u) * 2 + 1) * 1024 + voff));
-                }
-            }
-        };
-        auto run_stage = [&](const Stage& sg) {
-#pragma unroll
-            for (int u = 0; u < KB; ++u)
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.al[m][u], sg.bh[u], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.ah[m][u], sg.bh[u], acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sg.ah[m][u], sg.bl[u], acc[m], 0, 0, 0);
-                }
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])::"memory");
-        };
-        // (Two register stages -- batch b + 1 requested before batch b's MFMAs -- were built and measured: layers 5 / 6 79.3 / 103.4 us against 80.7 / 102.9 us
-        //  alone, bench 53.96k against 54.37k: 64 more VGPRs buy no overlap that an L2 round trip of ~2 us against 576 matrix-pipe cycles could use.
-        //  Batches of one k-step (137 - 165 VGPRs): 88 / 105 us, 53.5k; of four (212 - 238): 82 / 112 us, 53.4k; two it is: 81 / 102 us, 54.1k.)
-#pragma unroll
-        for (int k0 = 0; k0 < KS; k0 += KB) {
-            Stage sg;
-            load_stage(sg, k0);
-            __builtin_amdgcn_sched_barrier(0);   // (all requests of the batch first: the scheduler would sink each load to its MFMA)
-            run_stage(sg);
-        }
-        // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const int mt = 3 * g + m;
-            const int row0 = 32 * mt + 4 * (lane >> 5);
-            float* sp = jb.slab + (size_t)row0 * jb.sld + hl * 32 + (lane & 31);
-            const int* ae = jb.a_exp + (jb.mt0 + mt) * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = (r & 3) + 8 * (r >> 2);
-                sp[dr * jb.sld] = __builtin_ldexpf(acc[m][r], ae[dr] + we);
-            }
-        }
+        const int ng = jb.MT / 3, hl = off / ng, g = off - hl * ng;
+        ft_gemm_unit<KS, 3>(jb, 3 * g, hl, (head0 + hl) * 5 + jb.p, wplanes, wexp, lane);
     }
 }
 
