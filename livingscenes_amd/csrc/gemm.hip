@@ -1960,11 +1960,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         // transpose: lane L holds the 16-byte slot L % 16 of rows 4 i + L / 16; row r's slot s is kept at position s ^ (r & 15), so that both the writes
         // (a wave instruction = four whole rows) and the fragment reads (sixteen lanes = twelve consecutive rows, one slot) are free of bank conflicts
         float4* sg = stage[wave];
+        // (wave-private scratch: the fences order this tile's stores after the previous tile's fragment reads and before this tile's -- no instruction,
+        //  but the compiler may not move a may-alias LDS access across them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int row = 4 * i + (lane >> 4);
             if (!(LS_VND_SKIP & 8)) sg[row * 16 + ((lane & 15) ^ (row & 15))] = rv[i];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             uint2 h0, l0, h1, l1;

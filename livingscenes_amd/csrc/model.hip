@@ -197,7 +197,7 @@ struct EncPlan {
     int nlevels = 0, levelN[LS_MAX_LAYERS + 1];
     int NP = 0, Cdp = 0;
     // workspace offsets (bytes)
-    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], o_cs, total;
+    size_t o_pts[LS_MAX_LAYERS + 1], o_fps[LS_MAX_LAYERS + 1], o_centroid, o_scale0, o_pro, o_knn, o_knn2, o_knns, o_fA, o_fB, o_msg, o_T, o_TG, o_g, o_G, o_Tc, o_gws, o_xin, o_out, o_rm_msg, o_rm_out[2], o_cs, o_fpsws, fpsws_bytes, total;
 };
 
 static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
@@ -285,6 +285,15 @@ static int make_plan(const ls_model_desc& d, int B, int N, EncPlan& p) {
     p.o_rm_out[0] = take((size_t)B * maxRm * 3 * 4);
     p.o_rm_out[1] = take((size_t)B * maxRm * 3 * 4);
     p.o_cs = take((size_t)B * maxCs * 4);
+    // FPS scratch of the encoder's own down-sampling chain (fps.hip: exact bucket pruning for 8 193 .. 65 536 source points; 0 bytes below that).  The
+    // levels run one after the other on one stream and share it.  (the chain passed no workspace, so an encode with N > 8192 failed in the
+    // MIDDLE of the enqueue, after the side stream had forked.)
+    p.fpsws_bytes = 0;
+    for (int l = 0; l < p.nlevels; ++l) {
+        LS_REQUIRE(p.levelN[l] <= 65536, "encoder: %d points at down-sampling level %d (FPS handles at most 65536)", p.levelN[l], l);
+        p.fpsws_bytes = std::max(p.fpsws_bytes, fps_scratch_bytes_per_cloud(p.levelN[l]) * (size_t)B);
+    }
+    p.o_fpsws = take(p.fpsws_bytes);
     // staging of the captured-graph path: the graph reads x from / writes the codes to FIXED addresses inside the workspace
     p.o_xin = take((size_t)B * 3 * N * 4);
     p.o_out = take((size_t)B * (4 * (size_t)d.c_dim + 4) * 4);
@@ -764,18 +773,25 @@ void ls_model_destroy(ls_model_t* m) {
     delete m;
 }
 
+// captured launch sequences are keyed on (workspace, B, N, mode, stream) only: an option that selects kernels must drop them, or a replay would
+// run the launch sequence of the OLD setting
+static void drop_graphs(ls_model* m) {
+    for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    m->graphs.clear();
+}
+
 int ls_model_set_option(ls_model_t* m, int option, int value) {
     LS_REQUIRE(m, "model_set_option: null model");
     switch (option) {
         case LS_OPT_SDF_TRAIN_SPLITK: m->train_splitk = value != 0; return LS_OK;
         case LS_OPT_SDF_BF16X2: m->sdf_bf16x2 = value != 0; return LS_OK;
         case LS_OPT_ENCODE_GRAPH: m->use_graph = value != 0; return LS_OK;
-        case LS_OPT_EDGE_STAGED: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_EDGE_STAGED takes 0, 1 or 2"); m->edge_staged = value; return LS_OK;
-        case LS_OPT_EDGE_FUSE_Q: m->fuse_q = value != 0; return LS_OK;
-        case LS_OPT_EDGE_FUSE_T: m->fuse_t = value != 0; return LS_OK;
-        case LS_OPT_GLOB_FUSE: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_GLOB_FUSE takes 0, 1 or 2"); m->glob_fuse = value; return LS_OK;
-        case LS_OPT_DEBUG_EDGE: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_DEBUG_EDGE takes 0, 1 or 2"); m->debug_edge = value; return LS_OK;
-        case LS_OPT_GEMM_OVERLAP: m->overlap_gemm = value != 0; return LS_OK;
+        case LS_OPT_EDGE_STAGED: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_EDGE_STAGED takes 0, 1 or 2"); m->edge_staged = value; drop_graphs(m); return LS_OK;
+        case LS_OPT_EDGE_FUSE_Q: m->fuse_q = value != 0; drop_graphs(m); return LS_OK;
+        case LS_OPT_EDGE_FUSE_T: m->fuse_t = value != 0; drop_graphs(m); return LS_OK;
+        case LS_OPT_GLOB_FUSE: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_GLOB_FUSE takes 0, 1 or 2"); m->glob_fuse = value; drop_graphs(m); return LS_OK;
+        case LS_OPT_DEBUG_EDGE: LS_REQUIRE(value >= 0 && value <= 2, "model_set_option: LS_OPT_DEBUG_EDGE takes 0, 1 or 2"); m->debug_edge = value; drop_graphs(m); return LS_OK;
+        case LS_OPT_GEMM_OVERLAP: m->overlap_gemm = value != 0; drop_graphs(m); return LS_OK;
         default: set_error("model_set_option: unknown option %d", option); return LS_ERR_INVALID;
     }
 }
@@ -840,7 +856,8 @@ static int encode_enqueue(ls_model_t* m, const EncPlan& p, const float* x, int B
             toff += (size_t)B * p.levelN[l + 1];
             {
                 PROF(LS_K_FPS, l, fs);
-                rc = (skip & SK_FPS) ? LS_OK : fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]), nullptr, 0, fs);
+                rc = (skip & SK_FPS) ? LS_OK : fps_dispatch(F(p.o_pts[l]), nullptr, B, p.levelN[l], p.levelN[l + 1], flags, idx, F(p.o_pts[l + 1]),
+                                                              p.fpsws_bytes ? (void*)(ws + p.o_fpsws) : nullptr, p.fpsws_bytes, fs);
             }
             if (rc != LS_OK) return rc;
             if (m->fps_side) LS_HIP_CHECK(hipEventRecord(m->ev_fps[l], fs));

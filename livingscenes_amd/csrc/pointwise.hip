@@ -9,8 +9,9 @@ namespace ls {
 // scale_0 = mean(top-5 of the N*N entries of cdist(x,x)); x /= scale_0.  The symmetric matrix holds every
 // unordered pair twice, so top-5 = (d1,d1,d2,d2,d3) with d1>=d2>=d3 the three largest pair distances.
 // One workgroup per instance; cloud staged in LDS; each thread keeps a private top-3 of squared distances.
-// (branch-free, five instructions: the nested-branch form diverges per lane inside the pair loops -- the same three values; a NaN v is ignored by fmaxf / fminf
-//  exactly as the comparisons ignored it)
+// (branch-free, five instructions: the nested-branch form diverges per lane inside the pair loops -- the same three values for finite input.  A NaN
+//  distance is NOT ignored (fminf(a, NaN) = a duplicates the current maximum into b): clouds with NaN / Inf points are unsupported, as in the reference, whose
+//  topk over a cdist matrix with NaN entries returns NaN and turns every code into NaN -- model_utils.py:175-177)
 __device__ __forceinline__ void top3_insert(float v, float& a, float& b, float& c) {
     const float m = fminf(a, v);
     a = fmaxf(a, v);

@@ -448,6 +448,27 @@ def test_encoder_b3_equals_the_reference_per_instance(golden):
     assert relerr(hz, g["batched_z_so3"]) > 0.1          # ... and not the reference's batched B = 3 result
 
 
+def test_encoder_with_more_than_8192_points_uses_the_planned_fps_scratch():
+    """the encoder's own FPS chain passed no workspace, so a cloud of 8 193 .. 65 536 points (fps.hip: exact bucket pruning, which needs
+    scratch) failed in the middle of the enqueue.  The plan reserves the scratch now: FPS and layer-0 k-NN indices bit-exact, codes within TOL."""
+    from oracle import net
+    cfg = synth.small_encoder_cfg()
+    w = synth.make_encoder_weights(cfg, 7)
+    x = synth.make_instances(1, 9216, seed=5, rigid=False)
+    x = (x - x.mean(-1, keepdim=True)) / 1.1
+    tr = {}
+    center, scale, z_so3, z_inv = net.encoder_forward(w, cfg, x, trace=tr)
+    m = _hip_model(cfg, w)
+    hz, hi, hs, ht, knn_l, fps_l = m.encode(x.to(_dev()), pre_normalised=True, trace=True)
+    assert np.array_equal(fps_l[0].cpu().numpy(), tr["fps_idx_2"].numpy().astype(np.int32))
+    assert np.array_equal(knn_l[0].cpu().numpy(), tr["knn_idx_0"].numpy().astype(np.int32))
+    assert (knn_l[1].cpu().numpy() == tr["knn_idx_1"].numpy()).mean() > 0.995
+    assert relerr(hz, z_so3) < TOL and relerr(hi, z_inv) < TOL and relerr(hs, scale) < TOL and relerr(ht, center.reshape(1, 3)) < TOL
+    # more points than FPS handles: refused BEFORE anything is enqueued (workspace query answers 0, encode raises)
+    with pytest.raises(Exception, match="65536"):
+        m.encode(torch.zeros(1, 3, 70000, device=_dev()), pre_normalised=True)
+
+
 def test_shape_prior_encode_vs_golden(golden):
     """Shape_Prior.encode end to end against the fixture produced by the reference's own model_utils.Shape_Prior."""
     g = golden("shape_prior_full")
@@ -464,6 +485,56 @@ def test_shape_prior_encode_vs_golden(golden):
     code = {k: torch.from_numpy(g[k]).to(_dev()) for k in ("z_so3", "z_inv", "s", "t")}
     sdf = m.sdf_decode(torch.from_numpy(g["query"]).to(_dev()), code["z_so3"], code["z_inv"], code["s"], code["t"])
     assert relerr(sdf, g["sdf"]) < TOL
+
+
+def test_load_ckpt_from_log_on_device_vs_golden(golden, tmp_path, monkeypatch):
+    """the reference's LOADER entry on the device -- eval_3rscan.py:505-510 / eval_flyingshape.py:182 call
+    `load_ckpt_from_log(ckpt_dir)` (model_utils.py:267-283: CWD-relative ./configs/room4cates.yaml, exactly one <ckpt>/checkpoint/*latest.pt and
+    one <ckpt>/files_backup/*.yaml) -> load_models_dict (:65-80, `.to("cuda").eval()`) -> Shape_Prior.__init__ (:85-163: `network_dict.<part>.`
+    prefix strip, load_state_dict(strict=True), FieldWrapper with sdf2occ_factor).  The checkpoint written here holds the weights the fixture was
+    generated with, so the ModuleDict's prior must reproduce `shape_prior_full.npz` -- the output of the reference's OWN Shape_Prior."""
+    import yaml
+    from livingscenes_amd.model_utils import load_ckpt_from_log, slice_code_dict
+    g = golden("shape_prior_full")
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    ew, dw = synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0)
+    log = tmp_path / "log" / "shape_prior_room4cates"
+    (log / "checkpoint").mkdir(parents=True)
+    (log / "files_backup").mkdir()
+    torch.save(synth.to_checkpoint(ew, dw, epoch=11), log / "checkpoint" / "LivingScenes_latest.pt")
+    torch.save({"epoch": 3}, log / "checkpoint" / "12.pt")          # other epochs beside it are ignored by the *latest.pt glob
+    field = {"model": {"model_name": "sim3sdf", "encoder_type": "vecdgcnn_atten", "decoder_type": "inner_deepsdf", "encoder": ecfg, "decoder": dcfg,
+                       "sdf2occ_factor": -1.0}, "dataset": {"n_pcl": 1024}}
+    (log / "files_backup" / "model_config.yaml").write_text(yaml.safe_dump(field))
+    # the released configs/room4cates.yaml layout: field_pt / field_cfg placeholders (overwritten by the loader), solver_global.use_double False
+    (tmp_path / "configs").mkdir()
+    (tmp_path / "configs" / "room4cates.yaml").write_text(yaml.safe_dump(
+        {"shape_priors": {"chair": {"field_pt": "./nowhere/selected.pt", "field_cfg": "./nowhere.yaml", "database_k": {"inv": 23}}},
+         "solver_global": {"use_double": False, "use_sdf": True}}))
+    monkeypatch.chdir(tmp_path)                                     # the reference reads ./configs/room4cates.yaml relative to the CWD (:268)
+    models = load_ckpt_from_log(str(log))
+    assert isinstance(models, torch.nn.ModuleDict) and list(models.keys()) == ["chair"]
+    sp = models["chair"]
+    assert not sp.training and sp.model_id == "chair" and sp.use_double is False and sp.field_input_n == 1024 and sp.cls_head is None
+    assert all(p_.is_cuda for p_ in sp.parameters())
+    for k, v in ew.items():                                          # prefix strip + strict load: every tensor where the reference puts it
+        assert torch.equal(sp.encoder.state_dict()[k].cpu(), v), k
+    x = synth.make_instances(2, 1024, seed=0).to(_dev())
+    with torch.no_grad():
+        emb = sp.encode(x)
+        for k in ("z_so3", "z_inv", "s", "t"):
+            assert emb[k].dtype == torch.float32 and tuple(emb[k].shape) == g[k].shape and relerr(emb[k], g[k]) < TOL, k
+        q = torch.from_numpy(g["query"]).to(_dev())
+        sdf = sp.decoder(q, None, emb, return_sdf=True)              # FieldWrapper.forward on the codes this model just produced
+        assert relerr(sdf, g["sdf"]) < TOL
+        occ = sp.decoder(q, None, emb)                                # default: Bernoulli(logits = sdf2occ_factor * sdf) (model_utils.py:256-263)
+        assert relerr(occ.logits, -g["sdf"]) < TOL
+        one = sp.decoder(q[1:], None, slice_code_dict(emb, 1), return_sdf=True)
+        assert relerr(one, g["sdf"][1:]) < TOL
+    # two checkpoints matching *latest.pt -> the reference's assert (:274)
+    torch.save({"epoch": 0}, log / "checkpoint" / "other_latest.pt")
+    with pytest.raises(AssertionError):
+        load_ckpt_from_log(str(log))
 
 
 def test_sdf_decode_vs_oracle_small_and_chunked():
