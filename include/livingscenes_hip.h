@@ -60,7 +60,7 @@ typedef enum {
  * ls_adam_group / ls_adam_step_f32 / ls_se3_adam_step_f32, LS_OPT_EDGE_STAGED; 102: LS_OPT_EDGE_FUSE_Q / _T, LS_OPT_GLOB_FUSE, LS_OPT_DEBUG_EDGE; the
  * library reads no development switches from the environment any more).  ls_version() returns the value the LIBRARY was built with; a
  * binding compares it with the header it was written against and refuses a mismatch (livingscenes_amd/_lib.py: load). */
-#define LS_ABI_VERSION 102
+#define LS_ABI_VERSION 103
 int ls_version(void);
 const char* ls_last_error(void);
 /* number of HIP devices visible, or a negative ls_status */
@@ -166,6 +166,18 @@ int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, 
  * first row-major arg-max; record; delete row and column }.  `scores` [n,m] is DESTROYED.
  * matches0 [n], matches1 [m] int64, -1 = unmatched. */
 int ls_greedy_match_f32(float* scores, int n, int m, int64_t* matches0, int64_t* matches1, void* stream);
+
+/* nn_matcher after its score matrix, lib_more/matcher_new.py:89-98 (find_nn :73-83 without thresholds, mutual_check :100-105 twice):
+ * matches0[i] = argmax_j S[i][j] if argmax_i S[i][that j] == i else -1; matches1 = mutual_check(argmax over rows, matches0).
+ * First maximum on ties.  scores [n,m] (read only) -> matches0 [n], matches1 [m] int64.  One launch, one workgroup (LDS: about 190 x 190 at most). */
+int ls_nn_match_f32(const float* scores, int n, int m, int64_t* matches0, int64_t* matches1, void* stream);
+
+/* sinkhorn_matcher after its score matrix, matcher_new.py:49-71: couplings = [[S / score_divisor, alpha], [alpha, alpha]], `iters` log-space Sinkhorn
+ * iterations (log_optimal_transport :20-40 with log_sinkhorn_iterations above it), arg-maxes of the inner block of Z, mutual checks, and
+ * exp(max0) > match_threshold (:58-66).  The reference calls it with score_divisor = desc_dim ** 0.5, alpha = 1, iters = 100, threshold 0.
+ * scores [n,m] (read only) -> matches0 [n], matches1 [m] int64, -1 = unmatched.  One launch, one workgroup. */
+int ls_sinkhorn_match_f32(const float* scores, int n, int m, float score_divisor, float alpha, int iters, float match_threshold,
+                          int64_t* matches0, int64_t* matches1, void* stream);
 
 /* kabsch_transformation_estimation(x1, x2, weights, normalize_w=True, eps=1e-7),
  * lib_more/pose_estimation.py:29-102 (+ transformation_residuals :105-121).

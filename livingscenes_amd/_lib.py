@@ -17,7 +17,7 @@ FLAG_KNN_MFMA_FILTER = 2
 FLAG_KNN_VALU_ONLY = 4
 FLAG_KABSCH_RAW_WEIGHTS = 8
 OPT_SDF_TRAIN_SPLITK, OPT_SDF_BF16X2, OPT_ENCODE_GRAPH, OPT_EDGE_STAGED, OPT_EDGE_FUSE_Q, OPT_EDGE_FUSE_T, OPT_GLOB_FUSE, OPT_DEBUG_EDGE, OPT_GEMM_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8, 9
-ABI_VERSION = 102   # == LS_ABI_VERSION in include/livingscenes_hip.h: a library of another version is refused (argument layouts differ)
+ABI_VERSION = 103   # == LS_ABI_VERSION in include/livingscenes_hip.h: a library of another version is refused (argument layouts differ)
 KABSCH_OK, KABSCH_RANK1, KABSCH_RANK0, KABSCH_NONFINITE = 0, 1, 2, 3
 
 
@@ -105,6 +105,8 @@ SIGNATURES = {
     "ls_cosine_scores_workspace_bytes": (_SZ, [_I, _I]),
     "ls_cosine_scores_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "ls_greedy_match_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "ls_nn_match_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "ls_sinkhorn_match_f32": (_I, [_P, _I, _I, _F, _F, _I, _F, _P, _P, _P]),
     "ls_kabsch_batched_f32": (_I, [_P, _P, _P, _I, _I, _U, _P, _P, _P, _P, _P]),
     "ls_kabsch_codes_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "ls_kabsch_residual_matrix_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),

@@ -386,6 +386,123 @@ int greedy_match_launch(float* S, int n, int m, long long* m0, long long* m1, hi
     LS_LAUNCH_CHECK();
     return LS_OK;
 }
+// ---------------------------------------------------------------------------------------------- mutual-NN and Sinkhorn assignment
+// nn_matcher            /root/reference/lib_more/matcher_new.py:85-107   (find_nn without thresholds, two mutual checks)
+// sinkhorn_matcher      matcher_new.py:20-71                             (SuperGlue's log-space optimal transport with a dustbin row / column, 100
+//                                                                         iterations, then mutual arg-maxes of the inner block and the exp(score) > threshold test)
+// Round 5 ran these as ATen kernels: the Sinkhorn loop alone was 200 DEPENDENT logsumexp launches (+ adds), 2 - 4 ms for a 32 x 32 problem.  Here the
+// whole matcher is ONE launch of one workgroup: the coupling matrix lives in LDS ((n+1) x (m+1), row stride odd: the column passes are conflict-free),
+// eight lanes share a row (column), one barrier per half-iteration.  Ties: the FIRST maximum (lowest index), as torch.max / topk return on the reference's
+// devices for the sizes in question.  logsumexp as ATen computes it: max, log(sum exp(x - max)) + max (an all -inf row keeps max = 0).
+// mode 0 = mutual nearest neighbours on `S`; mode 1 = Sinkhorn on S / div.
+__global__ __launch_bounds__(1024) void assign_kernel(const float* __restrict__ S, int n, int m, int mode, float div, float alpha, int iters, float thr,
+                                                      long long* __restrict__ m0, long long* __restrict__ m1) {
+    LS_LATENCY_CRITICAL();
+    extern __shared__ float az[];
+    const int tid = threadIdx.x, g = tid & 7, grp = tid >> 3;
+    const int R = mode ? n + 1 : n, C = mode ? m + 1 : m, ld = C | 1;
+    float* Z = az;                     // [R][ld]
+    float* u = Z + (size_t)R * ld;     // [R]
+    float* v = u + R;                  // [C]
+    float* mx0 = v + C;                // [n]   row maxima of the inner block
+    int* i0 = (int*)(mx0 + n);         // [n]
+    int* i1 = i0 + n;                  // [m]
+    int* ok0 = i1 + m;                 // [n]
+    for (int e = tid; e < R * C; e += 1024) {
+        const int i = e / C, j = e - i * C;
+        Z[i * ld + j] = (i < n && j < m) ? (mode ? S[(size_t)i * m + j] / div : S[(size_t)i * m + j]) : alpha;
+    }
+    for (int i = tid; i < R; i += 1024) u[i] = 0.f;
+    for (int j = tid; j < C; j += 1024) v[j] = 0.f;
+    __syncthreads();
+    float norm = 0.f;
+    if (mode) {
+        norm = -logf((float)n + (float)m);
+        const float mu_bin = logf((float)m) + norm, nu_bin = logf((float)n) + norm;
+        for (int it = 0; it < iters; ++it) {
+            // u = log_mu - logsumexp_j(Z + v)
+            for (int r = grp; r < R; r += 128) {
+                const float* zr = Z + r * ld;
+                float mx = -INFINITY;
+                for (int j = g; j < C; j += 8) mx = fmaxf(mx, zr[j] + v[j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+                const float mf = (mx == INFINITY || mx == -INFINITY) ? 0.f : mx;
+                float sm = 0.f;
+                for (int j = g; j < C; j += 8) sm += expf(zr[j] + v[j] - mf);
+                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                if (g == 0) u[r] = (r < n ? norm : mu_bin) - (logf(sm) + mf);
+            }
+            __syncthreads();
+            // v = log_nu - logsumexp_i(Z + u)
+            for (int c = grp; c < C; c += 128) {
+                float mx = -INFINITY;
+                for (int i = g; i < R; i += 8) mx = fmaxf(mx, Z[i * ld + c] + u[i]);
+                mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+                const float mf = (mx == INFINITY || mx == -INFINITY) ? 0.f : mx;
+                float sm = 0.f;
+                for (int i = g; i < R; i += 8) sm += expf(Z[i * ld + c] + u[i] - mf);
+                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                if (g == 0) v[c] = (c < m ? norm : nu_bin) - (logf(sm) + mf);
+            }
+            __syncthreads();
+        }
+    }
+    // arg-maxes of the inner block of  Z + u + v - norm  (mode 0: of S), first maximum on ties (a NaN entry is never selected)
+    for (int r = grp; r < n; r += 128) {
+        float best = -INFINITY; int bj = 0x7fffffff;
+        for (int j = g; j < m; j += 8) {
+            const float x = mode ? ((Z[r * ld + j] + u[r]) + v[j]) - norm : Z[r * ld + j];
+            if (x > best || (x == best && j < bj)) { best = x; bj = j; }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
+            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        if (g == 0) { i0[r] = bj == 0x7fffffff ? 0 : bj; mx0[r] = best; }
+    }
+    for (int c = grp; c < m; c += 128) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = g; i < n; i += 8) {
+            const float x = mode ? ((Z[i * ld + c] + u[i]) + v[c]) - norm : Z[i * ld + c];
+            if (x > best || (x == best && i < bi)) { best = x; bi = i; }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (g == 0) i1[c] = bi == 0x7fffffff ? 0 : bi;
+    }
+    __syncthreads();
+    // mode 0 (matcher_new.py:93-94): matches0 = mutual_check(i0, i1); matches1 = mutual_check(i1, matches0)
+    // mode 1 (:58-66): valid0 = mutual0 & exp(max0) > thr; valid1 = mutual1 & valid0[i1]
+    for (int i = tid; i < n; i += 1024) {
+        const bool mutual = i1[i0[i]] == i;
+        const bool ok = mode ? (mutual && expf(mx0[i]) > thr) : mutual;
+        ok0[i] = ok;
+        m0[i] = ok ? i0[i] : -1;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += 1024) {
+        const int i = i1[j];
+        const bool ok = mode ? (i0[i] == j && ok0[i]) : (ok0[i] && i0[i] == j);
+        m1[j] = ok ? i : -1;
+    }
+}
+
+size_t assign_lds_bytes(int n, int m, int mode) {
+    const size_t R = mode ? n + 1 : n, C = mode ? m + 1 : m, ld = C | 1;
+    return (R * ld + R + C + (size_t)n + 2 * (size_t)n + (size_t)m) * 4;
+}
+int assign_launch(const float* S, int n, int m, int mode, float div, float alpha, int iters, float thr, long long* m0, long long* m1, hipStream_t st) {
+    const size_t lds = assign_lds_bytes(n, m, mode);
+    LS_REQUIRE(lds <= 150 * 1024, "%s: a %d x %d problem needs %zu bytes of LDS (at most 153600: about 190 x 190)", mode ? "sinkhorn_match" : "nn_match", n, m, lds);
+    if (lds > 64 * 1024) LS_HIP_CHECK(hipFuncSetAttribute((const void*)assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(assign_kernel, dim3(1), dim3(1024), lds, st, S, n, m, mode, div, alpha, iters, thr, m0, m1);
+    LS_LAUNCH_CHECK();
+    return LS_OK;
+}
 int kabsch_launch(const float* x1, const float* x2, const float* w, int nprob, int n, int pair_m, int raw_weights, float* R, float* t,
                   float* res, float* res_mean, int32_t* flags, hipStream_t st, const float* off1, const float* off2, const long long* sel1,
                   const long long* sel2) {

@@ -99,6 +99,7 @@ int sdf_query_grad_launch(const float*, const float*, const float*, const float*
 int transpose_launch(const float*, int, int, float*, hipStream_t);
 int cosine_scores_launch(const float*, const float*, int, int, int, float*, float*, hipStream_t);
 int greedy_match_launch(float*, int, int, long long*, long long*, hipStream_t);
+int assign_launch(const float*, int, int, int, float, float, int, float, long long*, long long*, hipStream_t);
 int kabsch_launch(const float*, const float*, const float*, int, int, int, int, float*, float*, float*, float*, int32_t*, hipStream_t,
                   const float* off1 = nullptr, const float* off2 = nullptr, const long long* sel1 = nullptr, const long long* sel2 = nullptr);
 size_t icp_workspace_bytes(int b, int n);
@@ -634,6 +635,16 @@ int ls_cosine_scores_f32(const float* m0, const float* m1, int n, int m, int D, 
 int ls_greedy_match_f32(float* scores, int n, int m, int64_t* matches0, int64_t* matches1, void* stream) {
     LS_REQUIRE(n > 0 && m > 0, "greedy_match: empty problem");
     return greedy_match_launch(scores, n, m, (long long*)matches0, (long long*)matches1, (hipStream_t)stream);
+}
+int ls_nn_match_f32(const float* scores, int n, int m, int64_t* matches0, int64_t* matches1, void* stream) {
+    LS_REQUIRE(n > 0 && m > 0 && scores && matches0 && matches1, "nn_match: empty problem or null argument");
+    return assign_launch(scores, n, m, 0, 1.0f, 0.0f, 0, 0.0f, (long long*)matches0, (long long*)matches1, (hipStream_t)stream);
+}
+int ls_sinkhorn_match_f32(const float* scores, int n, int m, float score_divisor, float alpha, int iters, float match_threshold, int64_t* matches0,
+                          int64_t* matches1, void* stream) {
+    LS_REQUIRE(n > 0 && m > 0 && scores && matches0 && matches1, "sinkhorn_match: empty problem or null argument");
+    LS_REQUIRE(iters >= 0 && score_divisor != 0.0f, "sinkhorn_match: iters=%d score_divisor=%g", iters, (double)score_divisor);
+    return assign_launch(scores, n, m, 1, score_divisor, alpha, iters, match_threshold, (long long*)matches0, (long long*)matches1, (hipStream_t)stream);
 }
 int ls_kabsch_batched_f32(const float* x1, const float* x2, const float* weights, int b, int n, unsigned flags, float* R, float* t,
                           float* res, int32_t* flags_out, void* stream) {

@@ -38,16 +38,14 @@ def mutual_check(m0, m1):
 
 
 def nn_matcher(desc0, desc1):
-    """matcher_new.py:85-98: mutual nearest neighbours.  desc [1,D,n] (the reference's transposed call convention)."""
-    sim = ops.cosine_scores(desc0[0].T.contiguous(), desc1[0].T.contiguous())[None]
-    m0 = sim.argmax(dim=2)
-    m1 = sim.argmax(dim=1)
-    m0 = mutual_check(m0, m1)
-    m1 = mutual_check(m1, m0)
-    return {"matches0": m0.squeeze(), "matches1": m1.squeeze()}
+    """matcher_new.py:85-98: mutual nearest neighbours.  desc [1,D,n] (the reference's transposed call convention).  Two launches: the cosine scores and
+    ls_nn_match_f32 (both arg-maxes and both mutual checks)."""
+    a, b = ops.nn_match(ops.cosine_scores(desc0[0].T.contiguous(), desc1[0].T.contiguous()))
+    return {"matches0": a.squeeze(), "matches1": b.squeeze()}     # (the reference squeezes its [1, n] results: 0-dim for n == 1)
 
 
 def log_sinkhorn_iterations(Z, log_mu, log_nu, iters):
+    """matcher_new.py:12-18 (kept for callers that want the transport plan itself; sinkhorn_matcher runs the loop inside one HIP launch)."""
     u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
     for _ in range(iters):
         u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
@@ -69,18 +67,9 @@ def log_optimal_transport(scores, alpha, iters):
 
 
 def sinkhorn_matcher(desc0, desc1, desc_dim=256, match_threshold=0.0):
-    """matcher_new.py:45-71: not selected by the evals (they use 'sequential'); small dense torch ops on the device."""
-    scores = ops.cosine_scores(desc0[0].T.contiguous(), desc1[0].T.contiguous())[None] / desc_dim ** 0.5
-    Z = log_optimal_transport(scores, torch.tensor(1.0, device=scores.device), iters=100)
-    max0, max1 = Z[:, :-1, :-1].max(2), Z[:, :-1, :-1].max(1)
-    i0, i1 = max0.indices, max1.indices
-    ar0 = torch.arange(i0.shape[1], device=i0.device)[None]
-    ar1 = torch.arange(i1.shape[1], device=i1.device)[None]
-    mutual0 = ar0 == i1.gather(1, i0)
-    mutual1 = ar1 == i0.gather(1, i1)
-    zero = Z.new_tensor(0)
-    ms0 = torch.where(mutual0, max0.values.exp(), zero)
-    valid0 = mutual0 & (ms0 > match_threshold)
-    valid1 = mutual1 & valid0.gather(1, i1)
-    return {"matches0": torch.where(valid0, i0, i0.new_tensor(-1)).squeeze(),
-            "matches1": torch.where(valid1, i1, i1.new_tensor(-1)).squeeze()}
+    """matcher_new.py:45-71 (not selected by the evals, which use 'sequential').  Two launches: the cosine scores and ls_sinkhorn_match_f32 -- the coupling
+    matrix in LDS, the 100 log-space iterations, the mutual arg-maxes and the threshold test in one workgroup-resident kernel (round 5: 200 dependent
+    ATen logsumexp launches)."""
+    a, b = ops.sinkhorn_match(ops.cosine_scores(desc0[0].T.contiguous(), desc1[0].T.contiguous()), desc_dim ** 0.5, alpha=1.0, iters=100,
+                              match_threshold=match_threshold)
+    return {"matches0": a.squeeze(), "matches1": b.squeeze()}

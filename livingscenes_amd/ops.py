@@ -140,6 +140,28 @@ def greedy_match(scores):
     return m0, m1
 
 
+def nn_match(scores):
+    """scores [n,m] -> mutual-nearest-neighbour (matches0 [n], matches1 [m]) int64 (matcher_new.py:89-98), one launch."""
+    S = _f32(scores)
+    n, m = S.shape
+    m0 = torch.empty(n, dtype=torch.int64, device=S.device)
+    m1 = torch.empty(m, dtype=torch.int64, device=S.device)
+    call(S.device, "ls_nn_match_f32", ptr(S), n, m, ptr(m0), ptr(m1), stream_ptr(S.device))
+    return m0, m1
+
+
+def sinkhorn_match(scores, score_divisor, alpha=1.0, iters=100, match_threshold=0.0):
+    """scores [n,m] -> (matches0 [n], matches1 [m]) int64: log-space optimal transport with a dustbin + mutual arg-maxes (matcher_new.py:20-71),
+    the whole loop in one launch."""
+    S = _f32(scores)
+    n, m = S.shape
+    m0 = torch.empty(n, dtype=torch.int64, device=S.device)
+    m1 = torch.empty(m, dtype=torch.int64, device=S.device)
+    call(S.device, "ls_sinkhorn_match_f32", ptr(S), n, m, float(score_divisor), float(alpha), int(iters), float(match_threshold), ptr(m0), ptr(m1),
+         stream_ptr(S.device))
+    return m0, m1
+
+
 def kabsch(x1, x2, weights=None, return_flags=False, raw_weights=False):
     """x1,x2 [b,n,3] -> R [b,3,3], t [b,3,1], res [b,n] (, status [b] int32: _lib.KABSCH_*).  raw_weights: use `weights` as
     they are instead of normalising them (pose_estimation.py:52-54)."""

@@ -62,6 +62,41 @@ def nn_matcher(desc0, desc1):
     return {"matches0": out0.squeeze(), "matches1": out1.squeeze()}
 
 
+def log_optimal_transport(scores, alpha, iters):
+    """matcher_new.py:12-40: couplings = [[scores, alpha], [alpha, alpha]] ([b, m+1, n+1]), log_mu / log_nu with the dustbin masses, `iters` iterations of
+    u = log_mu - logsumexp(Z + v, dim=2); v = log_nu - logsumexp(Z + u, dim=1); returns Z + u + v - norm."""
+    b, m, n = scores.shape
+    ms, ns = float(m), float(n)
+    Z = torch.full((b, m + 1, n + 1), float(alpha), dtype=scores.dtype)
+    Z[:, :m, :n] = scores
+    norm = -torch.tensor(ms + ns, dtype=scores.dtype).log()
+    log_mu = torch.cat([norm.expand(m), torch.tensor(ns, dtype=scores.dtype).log()[None] + norm])[None].expand(b, -1)
+    log_nu = torch.cat([norm.expand(n), torch.tensor(ms, dtype=scores.dtype).log()[None] + norm])[None].expand(b, -1)
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
+        v = log_nu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
+    return Z + u.unsqueeze(2) + v.unsqueeze(1) - norm
+
+
+def sinkhorn_matcher(desc0, desc1, desc_dim=256, match_threshold=0.0, iters=100):
+    """matcher_new.py:45-71. desc [1,D,n]: normalised descriptors, scores / sqrt(desc_dim), optimal transport with alpha = 1, mutual arg-maxes of the
+    inner block, exp(max0) > match_threshold."""
+    a = F.normalize(desc0, p=2, dim=1)
+    b = F.normalize(desc1, p=2, dim=1)
+    scores = torch.einsum("bdn,bdm->bnm", a, b) / desc_dim ** .5
+    Z = log_optimal_transport(scores, 1.0, iters)
+    max0, max1 = Z[:, :-1, :-1].max(2), Z[:, :-1, :-1].max(1)
+    i0, i1 = max0.indices, max1.indices
+    mutual0 = torch.arange(i0.shape[1])[None] == i1.gather(1, i0)
+    mutual1 = torch.arange(i1.shape[1])[None] == i0.gather(1, i1)
+    ms0 = torch.where(mutual0, max0.values.exp(), torch.zeros(()))
+    valid0 = mutual0 & (ms0 > match_threshold)
+    valid1 = mutual1 & valid0.gather(1, i1)
+    return {"matches0": torch.where(valid0, i0, torch.full_like(i0, -1)).squeeze(),
+            "matches1": torch.where(valid1, i1, torch.full_like(i1, -1)).squeeze(), "Z": Z[0]}
+
+
 def kabsch_residual_matrix(src_so3, tgt_so3):
     """res_mat of matcher_new.py:150-156 / :196-202: mean Kabsch residual between every pair."""
     n, m = src_so3.shape[0], tgt_so3.shape[0]

@@ -247,6 +247,39 @@ def test_all_matchers_vs_golden(golden):
         assert np.array_equal(r["matches0"].cpu().numpy(), g[f"{nm}_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g[f"{nm}_m1"])
 
 
+def test_assignment_matchers_vs_reference_fixture_and_oracle(golden):
+    """SURVEY 8 a-10b on the device: nn_matcher / sinkhorn_matcher = cosine scores + ONE launch each (ls_nn_match_f32 / ls_sinkhorn_match_f32: the coupling
+    matrix in LDS, 100 log-space iterations, mutual arg-maxes, threshold test) -- match assignments bit-exact against the reference's own outputs
+    (tests/golden/make_golden_assign.py: realistic 32 x 32, rectangular, 1 x 1, 1 x 3 (squeezed to 0-dim), exact ties, 64 x 50, D = 64) and against the
+    oracle on random shapes up to 150 x 120 (the dynamic-LDS path)."""
+    from livingscenes_amd import ops
+    from livingscenes_amd.lib_more import matcher_new as mn
+    from oracle import more
+    g = golden("matchers_assign")
+    d = _dev()
+    for name in g["names"]:
+        a, b = torch.from_numpy(g[f"{name}_a"]).to(d), torch.from_numpy(g[f"{name}_b"]).to(d)
+        r = mn.nn_matcher(a.T[None], b.T[None])
+        assert r["matches0"].dtype == torch.int64 and r["matches0"].shape == g[f"{name}_nn_m0"].shape and r["matches1"].shape == g[f"{name}_nn_m1"].shape
+        assert np.array_equal(r["matches0"].cpu().numpy(), g[f"{name}_nn_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g[f"{name}_nn_m1"]), name
+        r = mn.sinkhorn_matcher(a.T[None], b.T[None], desc_dim=a.shape[1])
+        assert r["matches0"].shape == g[f"{name}_sk_m0"].shape
+        assert np.array_equal(r["matches0"].cpu().numpy(), g[f"{name}_sk_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g[f"{name}_sk_m1"]), name
+        r = mn.sinkhorn_matcher(a.T[None], b.T[None], desc_dim=a.shape[1], match_threshold=float(g[f"{name}_sk_thr"]))
+        assert np.array_equal(r["matches0"].cpu().numpy(), g[f"{name}_skt_m0"]) and np.array_equal(r["matches1"].cpu().numpy(), g[f"{name}_skt_m1"]), name
+    gen = torch.Generator().manual_seed(5)
+    for n, m in ((2, 2), (7, 3), (33, 65), (64, 64), (100, 90), (150, 120)):
+        a = torch.randn(n, 256, generator=gen)
+        b = torch.cat([a[torch.randperm(n, generator=gen)[:min(n, m)]] + 0.4 * torch.randn(min(n, m), 256, generator=gen),
+                       torch.randn(max(m - n, 0), 256, generator=gen)], 0)[torch.randperm(m, generator=gen)]
+        for fn_ref, fn in ((more.nn_matcher, mn.nn_matcher), (more.sinkhorn_matcher, mn.sinkhorn_matcher)):
+            ref, r = fn_ref(a.T[None], b.T[None]), fn(a.T[None].to(d), b.T[None].to(d))
+            assert np.array_equal(r["matches0"].cpu().numpy(), ref["matches0"].numpy()) and np.array_equal(r["matches1"].cpu().numpy(), ref["matches1"].numpy()), (n, m)
+    # beyond the LDS of one workgroup: a clear error, nothing enqueued
+    with pytest.raises(Exception, match="LDS"):
+        ops.sinkhorn_match(torch.zeros(300, 300, device=d), 16.0)
+
+
 def test_more_solver_matching_registration_end2end(small_prior):
     """More_Solver mirror: _solve_object_matching (5 methods), _solve_pairwise_registration(optim=False) incl. ICP,
     _transform_latent and _solve_end2end vs the oracle pipeline (FPS -> encode -> Kabsch -> ICP) pair by pair."""

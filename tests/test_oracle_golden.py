@@ -131,6 +131,21 @@ def test_matchers(golden):
         assert np.array_equal(r["matches0"].numpy(), g[f"{nm}_m0"]) and np.array_equal(r["matches1"].numpy(), g[f"{nm}_m1"])
 
 
+def test_assignment_matchers(golden):
+    """nn_matcher / sinkhorn_matcher against the reference's own outputs (tests/golden/make_golden_assign.py): matches bit-exact, the
+    transport matrix within 1e-5 of its max-norm."""
+    g = golden("matchers_assign")
+    for name in g["names"]:
+        a, b = T(g[f"{name}_a"]), T(g[f"{name}_b"])
+        r = more.nn_matcher(a.T[None], b.T[None])
+        assert np.array_equal(r["matches0"].numpy(), g[f"{name}_nn_m0"]) and np.array_equal(r["matches1"].numpy(), g[f"{name}_nn_m1"]), name
+        r = more.sinkhorn_matcher(a.T[None], b.T[None], desc_dim=a.shape[1])
+        assert np.array_equal(r["matches0"].numpy(), g[f"{name}_sk_m0"]) and np.array_equal(r["matches1"].numpy(), g[f"{name}_sk_m1"]), name
+        close(r["Z"], g[f"{name}_sk_Z"], rtol_max=1e-5, what=f"{name} Z")
+        r = more.sinkhorn_matcher(a.T[None], b.T[None], desc_dim=a.shape[1], match_threshold=float(g[f"{name}_sk_thr"]))
+        assert np.array_equal(r["matches0"].numpy(), g[f"{name}_skt_m0"]) and np.array_equal(r["matches1"].numpy(), g[f"{name}_skt_m1"]), name
+
+
 def test_registration(golden):
     g = golden("registration")
     x1, x2 = T(g["kab_x1"]), T(g["kab_x2"])
