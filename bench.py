@@ -308,11 +308,14 @@ def main():
                          "44.8k, 24: 42.6k, 32: 34.6k)")
     args = ap.parse_args()
     if args.inflight <= 0:
-        # 12 in the steady state (480 steps: 8 -> 45.9k, 12 -> 47.5k); a short timed region is mostly ramp and drain of that pipeline and
-        # the shallower one wastes less of it (20 steps, three repetitions each: 8 -> 44.2 - 44.9k, 10 -> 42.8 - 43.3k, 12 -> 43.9 - 44.1k,
-        # 20 -> 42.8 - 43.0k)
-        # (round 5, after the latency work on the single step: 20 steps at 5 / 7 / 8 / 10 / 12 in flight = 52.2 / 45.5 / 54.3 / 53.2 / 55.0k -- 12 for every run length)
-        args.inflight = 12
+        # 12 in the steady state (480 steps: 8 -> 45.9k, 12 -> 47.5k in round 3; round 6: 12 -> 58.3 - 59.8k, 16 -> 53.8k).
+        # SHORT runs (the driver's 20 steps): 8.  Round 6 re-measured the 20-step protocol (median of 9 blocks, profiles/r6_final/
+        # bench_protocol_depths_*.txt): 6 / 8 / 10 / 12 in flight = 45.5 / 55.4 - 55.7 / 53.5 - 53.8 / 55.6 - 55.8k -- 8 and 12 are equal, and 8 is the depth
+        # the driver measured in rounds 1 - 4 without incident (37.9 -> 49.9k), while its one run at 12 (BENCH_r05) came back at 25.2k, a figure six
+        # repetitions of that exact protocol on fresh leases could not reproduce (53.7 - 55.0k, profiles/r6_final/r5_protocol_repro.txt).  What DOES halve a
+        # 20-step block is hardware-queue oversubscription (20 in flight on 24 queues: 28.6k, profiles/r6_final/streams_ab.txt): 8 steps x 3 streams on 16
+        # queues is the configuration furthest from that cliff at no cost.
+        args.inflight = 8 if args.steps < 48 else 12
 
     # --gpus N is the number of RANKS (one process per GPU).  Started plainly with N > 1 this re-executes itself under
     # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (does not return); started by a launcher it
