@@ -310,7 +310,7 @@ def main():
     if args.inflight <= 0:
         # 12 in the steady state (480 steps: 8 -> 45.9k, 12 -> 47.5k in round 3; round 6: 12 -> 58.3 - 59.8k, 16 -> 53.8k).
         # SHORT runs (the driver's 20 steps): 8.  Round 6 re-measured the 20-step protocol (median of 9 blocks, profiles/r6_final/
-        # bench_protocol_depths_*.txt): 6 / 8 / 10 / 12 in flight = 45.5 / 55.4 - 55.7 / 53.5 - 53.8 / 55.6 - 55.8k -- 8 and 12 are equal, and 8 is the depth
+        # bench_protocol_depths.txt): 6 / 8 / 10 / 12 in flight = 45.5 / 55.4 - 55.7 / 53.5 - 53.8 / 55.6 - 55.8k -- 8 and 12 are equal, and 8 is the depth
         # the driver measured in rounds 1 - 4 without incident (37.9 -> 49.9k), while its one run at 12 (BENCH_r05) came back at 25.2k, a figure six
         # repetitions of that exact protocol on fresh leases could not reproduce (53.7 - 55.0k, profiles/r6_final/r5_protocol_repro.txt).  What DOES halve a
         # 20-step block is hardware-queue oversubscription (20 in flight on 24 queues: 28.6k, profiles/r6_final/streams_ab.txt): 8 steps x 3 streams on 16

@@ -628,6 +628,14 @@ int edge_presplit_wq_launch(const float* Wq, int Co, int Cin, void* planes, hipS
     return LS_OK;
 }
 
+// Timing probe (round 6; WRONG results, dev builds only): -DLS_FQ_HALF_GATHER drops the gathers of the two `dir` column groups (the
+// neighbour's `lin` values stand in) -- the upper bound of what a half-width table could buy BEFORE paying for the per-edge C x C product that would have
+// to recompute the directions (profiles/r6_final/attn_halfwidth_ab.txt).
+#ifdef LS_FQ_HALF_GATHER
+#define LS_FQ_DIR(off, col, lin) (lin)
+#else
+#define LS_FQ_DIR(off, col, lin) ldrow(off, col)
+#endif
 template <int LPP, int CIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void edge_attn_fq_kernel(const float* __restrict__ T, int ldt, const float* __restrict__ cur,
                                                            const uint4* __restrict__ Wp, const int32_t* __restrict__ knn,
@@ -780,12 +788,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         constexpr int DP = 2;
         F43 py[DP], pd[DP];
 #pragma unroll
-        for (int d = 0; d < DP; ++d) { const unsigned o = noff(d); py[d] = ldrow(o, 2 * Co); pd[d] = ldrow(o, 3 * Co); }
+        for (int d = 0; d < DP; ++d) { const unsigned o = noff(d); py[d] = ldrow(o, 2 * Co); pd[d] = LS_FQ_DIR(o, 3 * Co, py[d]); }
         const F43 ql = lds43(0), qd = lds43(Co);
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
             F43 y = py[k % DP], kd = pd[k % DP];
-            if (k + DP < EK) { const unsigned o = noff(k + DP); py[k % DP] = ldrow(o, 2 * Co); pd[k % DP] = ldrow(o, 3 * Co); }
+            if (k + DP < EK) { const unsigned o = noff(k + DP); py[k % DP] = ldrow(o, 2 * Co); pd[k % DP] = LS_FQ_DIR(o, 3 * Co, py[k % DP]); }
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this neighbour's arithmetic (the scheduler would sink it to its first use)
             y = add43(y, ql);
             kd = add43(kd, qd);
@@ -820,11 +828,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         constexpr int DP = 2;
         F43 py[DP], pd[DP];
 #pragma unroll
-        for (int d = 0; d < DP; ++d) { const unsigned o = noff(d); py[d] = ldrow(o, 0); pd[d] = ldrow(o, Co); }
+        for (int d = 0; d < DP; ++d) { const unsigned o = noff(d); py[d] = ldrow(o, 0); pd[d] = LS_FQ_DIR(o, Co, py[d]); }
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
             F43 y = py[k % DP], kd = pd[k % DP];
-            if (k + DP < EK) { const unsigned o = noff(k + DP); py[k % DP] = ldrow(o, 0); pd[k % DP] = ldrow(o, Co); }
+            if (k + DP < EK) { const unsigned o = noff(k + DP); py[k % DP] = ldrow(o, 0); pd[k % DP] = LS_FQ_DIR(o, Co, py[k % DP]); }
             __builtin_amdgcn_sched_barrier(0);
             y = add43(y, ql);
             kd = add43(kd, qd);
