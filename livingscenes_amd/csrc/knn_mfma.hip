@@ -219,6 +219,9 @@ __global__ __launch_bounds__(64 * WPT) void knn_prep_f16_tile_kernel(const float
 // A query with more than KF_LCAP survivors (duplicates, non-finite rows) is finished by brute force over all candidates: slow, still exact.
 // The lists only ever hold canonical keys and a dropped candidate provably cannot enter them: bit-identical to the oracle by construction.
 // Hints are not used at all (they never influenced results).
+#ifndef LS_KF_PK
+#define LS_KF_PK 1
+#endif
 constexpr int KF_QT = 32;        // queries per workgroup (one 32-row MFMA operand)
 constexpr int KF_WAVES = 8;
 constexpr int KF_LCAP = 64;      // survivors per query that go through the flat exact phase (one 64-lane sorting pass)
@@ -227,7 +230,7 @@ constexpr int KF_MAXNS = KF_WAVES * 4 * 32;   // at most four tiles per wave
 template <int CC>
 struct KfLds {
     float qrows[KF_QT][3 * CC];          // the workgroup's query rows (fp32, x-major as in global memory)
-    float2 qn[KF_QT];                    // {|q'|^2, -2 iq} per query row (padding queries: {0, 0})
+    float qnx[KF_QT], qny[KF_QT];        // |q'|^2 and -2 iq per query row (padding queries: 0, 0); separate arrays: rows qr, qr + 1 are a register pair for the packed bounds
     unsigned hm[KF_QT][64];              // group minima of hi (bit patterns of non-negative floats)
     float T[KF_QT];
     int cnt[KF_QT];
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW, FMA)) void knn_fused_
         const int q = q0 + tid;
         const int r = q < Nd ? (dst_rows ? dst_rows[(size_t)b * Nd + q] : q) : 0;
         const float nq = nrm_dst[(size_t)b * dst_n + r], iq = isc_dst[(size_t)b * dst_n + r];
-        L.qn[tid] = q < Nd ? make_float2(nq, -2.0f * iq) : make_float2(0.f, 0.f);
+        L.qnx[tid] = q < Nd ? nq : 0.f;
+        L.qny[tid] = q < Nd ? -2.0f * iq : 0.f;
         L.cnt[tid] = 0;
     }
     for (int i = tid; i < KF_QT * 64; i += 64 * KF_WAVES) (&L.hm[0][0])[i] = 0x7F800000u;
@@ -345,12 +349,49 @@ __global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW, FMA)) void knn_fused_
     bool colv[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) colv[t] = (wave + KF_WAVES * t) < ntiles && (wave + KF_WAVES * t) * 32 + l31 < Ns;
+#if LS_KF_PK
+    {
+        // Round 6: the bounds of TWO accumulator rows per instruction on packed fp32 (rows r, r + 1 of a 32 x 32 accumulator are an aligned register pair and
+        // their query rows qr, qr + 1 adjacent LDS words): nn = |q'|^2 + |s'|^2, w = (-2 iq) ic, d^ = fma(S, w, nn), e = eps nn, hi = d^ + e, lo = d^ - e -- the
+        // same IEEE operations per element as the scalar form (so the same survivors), 6 packed instead of 12 scalar instructions per pair, and a padding
+        // column carries |s'|^2 = +inf instead of a select on the minimum: hi = +inf never wins, lo = NaN is masked by colv in the filter below.
+        const int slot = (wave & 1) * 32 + l31;
+        kf2_t cn2[TPW], ci2[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) { const float cn = colv[t] ? cns[t] : INFINITY; cn2[t] = kf2_t{cn, cn}; ci2[t] = kf2_t{cic[t], cic[t]}; }
+        const kf2_t eps2 = {eps, eps};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;       // r even: rows qr, qr + 1
+            const kf2_t qx = *reinterpret_cast<const kf2_t*>(&L.qnx[qr]), qy = *reinterpret_cast<const kf2_t*>(&L.qny[qr]);
+            float hm0 = INFINITY, hm1 = INFINITY;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const kf2_t nn = qx + cn2[t], w = qy * ci2[t];
+                const kf2_t sv = {S[t][r], S[t][r + 1]};
+                const kf2_t dh = __builtin_elementwise_fma(sv, w, nn), e = eps2 * nn;
+                const kf2_t hi = dh + e;
+                kf2_t lo = dh - e;
+                hm0 = fminf(hm0, hi.x); hm1 = fminf(hm1, hi.y);
+                asm volatile("" : "+v"(lo));      // (materialised here, as in the scalar form: sunk into the filter it keeps d^ and nn alive)
+                S[t][r] = lo.x; S[t][r + 1] = lo.y;
+            }
+            // ---- 2. threshold: (non-negative floats order like their bit patterns; +inf = "no candidate")
+            const float h0 = fmaxf(hm0, 0.0f), h1 = fmaxf(hm1, 0.0f);
+            if (h0 < INFINITY) atomicMin(&L.hm[qr][slot], __float_as_uint(h0));
+            if (h1 < INFINITY) atomicMin(&L.hm[qr + 1][slot], __float_as_uint(h1));
+#ifndef LS_KF_NOSB
+            if ((r & 3) == 2) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+#else
     {
         const int slot = (wave & 1) * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float2 qn = L.qn[qr];
+            const float2 qn = make_float2(L.qnx[qr], L.qny[qr]);
             float hmin = INFINITY;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
@@ -369,6 +410,7 @@ __global__ __launch_bounds__(64 * KF_WAVES, LS_KF_WPE(TPW, FMA)) void knn_fused_
 #endif
         }
     }
+#endif
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < KF_QT / KF_WAVES; ++u) {
