@@ -664,6 +664,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     const int32_t* ki = knn + (size_t)pid * EK;
     const int c4 = ll * 4;
 
+    uint4 wfh[2][KS], wfl[2][KS];
+    auto qload = [&](int cb) {
+#ifdef LS_FQ_SKIP_QGEMM      // timing probe (WRONG results): the three destination-side products skipped
+        return;
+#endif
+        const uint4* wt = Wp + (size_t)(cb / 32) * KS * 128 + lane;
+#pragma unroll
+        for (int u = 0; u < (MT == 2 ? 1 : 2); ++u) {      // (MT == 2: both M-tiles of a wave meet the same weight tile)
+            const int nt = MT == 2 ? wave : wave + 4 * u;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                wfh[u][ks] = wt[((size_t)(nt * KS + ks) * 2) * 64];
+                wfl[u][ks] = wt[((size_t)(nt * KS + ks) * 2 + 1) * 64];
+            }
+        }
+    };
+    qload(4 * Co);        // the q product's weight fragments travel while the rows are staged
     // ---- stage the destination points' feature rows (coalesced: a row is CIN * 4 contiguous bytes), split once for the three products
     for (int c = tid; c < MT * 32 * (CIN / 4); c += 256) {
         const int r = c / (CIN / 4), kq = c - r * (CIN / 4);
@@ -691,8 +708,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     __syncthreads();
 
     // ---- destination-side product for one phase: slab[row][0 .. 2 Co) = x_rows . Wq[cb .. cb + 2 Co)^T
-    auto qgemm = [&](int cb) {
-        const uint4* wt = Wp + (size_t)(cb / 32) * KS * 128 + lane;
+    // Round 6: the three products cost 15 / 27 / 44 us of a 99 / 108 / 82 us launch (probe: -DLS_FQ_SKIP_QGEMM, profiles/r6_final/attn_qgemm_ab.txt) although
+    // they are 72 MFMAs per wave: hipcc issued the weight-fragment loads of a phase two at a time with an s_waitcnt behind each pair -- four to five
+    // DEPENDENT L2 round trips per phase with every wave of the workgroup waiting.  Now a phase's fragments (2 tiles x KS steps x (hi, lo) x 16 bytes per lane:
+    // 32 - 64 registers, at a point where nothing else is live) are requested in ONE batch (qload), the MFMAs run behind a scheduling barrier (qmma), and the
+    // caller puts independent work between the two: the row staging in front of the q product, the q activation in front of the k product, the soft-max in
+    // front of the v product.  Same operands, same MFMA order: bit-identical.
+    auto qmma = [&](int cb) {
+#ifdef LS_FQ_SKIP_QGEMM
+        return;
+#endif
+        __builtin_amdgcn_sched_barrier(0);      // (the loads above stay above: left free, the scheduler sinks each pair to its first use again)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int mt = MT == 2 ? u : 0, nt = MT == 2 ? wave : wave + 4 * u;
@@ -704,8 +730,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
             for (int ks = 0; ks < KS; ++ks) {
                 const eh8_t ah = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(&a_pl[0][aoff + ks * 32]));
                 const eh8_t al = __builtin_bit_cast(eh8_t, *reinterpret_cast<const uint4*>(&a_pl[1][aoff + ks * 32]));
-                const eh8_t bh = __builtin_bit_cast(eh8_t, wt[((size_t)(nt * KS + ks) * 2) * 64]);
-                const eh8_t bl = __builtin_bit_cast(eh8_t, wt[((size_t)(nt * KS + ks) * 2 + 1) * 64]);
+                // (MT == 2: both M-tiles of a wave use the same weight tile -- its fragments are loaded once, u = 0)
+                const eh8_t bh = __builtin_bit_cast(eh8_t, wfh[MT == 2 ? 0 : u][ks]);
+                const eh8_t bl = __builtin_bit_cast(eh8_t, wfl[MT == 2 ? 0 : u][ks]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
@@ -731,8 +758,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     };
 
     // ---- A: q = cevn(VecLNA_Q(dst_f[n]))
-    qgemm(4 * Co);
+    qmma(4 * Co);
     __syncthreads();
+    qload(2 * Co);        // the k product's fragments travel under the q activation
     F43 qf = lds43(0);
     {
         const F43 kd = lds43(Co);
@@ -755,11 +783,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     // instead of a dependent index load in front of every row gather) and the rows of neighbours k+1, k+2 are in flight while
     // neighbour k is activated.  The rolled loop it replaces ran index load -> wait -> twelve row loads -> wait -> compute, two full
     // L2 round trips per pair of neighbours with nothing of one iteration overlapping the next (s_waitcnt vmcnt(0) at the loop top).
-    int nb[EK];
+    // (round 6: two 16-bit indices per register -- the sixteen indices live across both gather loops and the soft-max; eight registers less takes the
+    //  <32, 64> instance (layer 4, three workgroups per CU at 168 VGPRs) from seven spilled registers to one: 84.8 -> 82.4 us; the launch checks Ns < 65 536.
+    //  The same round measured the <16, 64> instance at THREE workgroups per CU -- A planes cut to the 48 real rows and XOR-swizzled, 54 272 bytes of LDS,
+    //  168 VGPRs with 7 spilled: 109.4 against 111.7 us alone, bench 59.4k against 59.9k -- occupancy is not what bounds layer 3 either; not kept.)
+    unsigned nb[EK / 2];
     {
         const int4* kp = reinterpret_cast<const int4*>(ki);
 #pragma unroll
-        for (int u = 0; u < EK / 4; ++u) { const int4 v = kp[u]; nb[4 * u] = v.x; nb[4 * u + 1] = v.y; nb[4 * u + 2] = v.z; nb[4 * u + 3] = v.w; }
+        for (int u = 0; u < EK / 4; ++u) { const int4 v = kp[u]; nb[2 * u] = (unsigned)v.x | ((unsigned)v.y << 16); nb[2 * u + 1] = (unsigned)v.z | ((unsigned)v.w << 16); }
     }
     // Row gathers as ONE uniform base + a 32-bit byte offset per neighbour (round 4): off = (instance row + neighbour) x row bytes + this lane's
     // column bytes by a single full-rate v_mad_u32_u24, the x / y / z rows and the column groups as scalar bases / immediates.  The 64-bit
@@ -768,7 +800,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     const unsigned row_bytes = 3u * (unsigned)ldt * 4u;
     const unsigned lane_off = (unsigned)c4 * 4u;
     const unsigned inst_row = (unsigned)b * (unsigned)Ns;
-    auto noff = [&](int k) { return __umul24(inst_row + (unsigned)nb[k], row_bytes) + lane_off; };
+    auto noff = [&](int k) { return __umul24(inst_row + ((k & 1) ? nb[k >> 1] >> 16 : nb[k >> 1] & 0xFFFFu), row_bytes) + lane_off; };
     auto ldrow = [&](unsigned off, int col) {   // rows x, y, z of table columns col .. col + 3 (+ this lane's column offset, inside `off`)
         asm volatile("" : "+v"(off));           // (keeps the zero-extension next to the loads: the scalar-base addressing mode, as in gemm.hip)
         F43 r;
@@ -777,7 +809,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         r.z = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T + 2 * ldt + col) + off);
         return r;
     };
-    qgemm(2 * Co);
+    qmma(2 * Co);
     __syncthreads();
     {
         // (DP = 3 / 4 -- 195 / 219 VGPRs, still two workgroups per CU -- measured in round 4: layers 2 / 3 / 4 at 120 / 114 / 81 and 120 / 113 / 82 us
@@ -806,9 +838,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     // (the row addresses are re-derived from the indices in phase C: sixteen 64-bit addresses kept alive across the soft-max cost
     //  more registers than the two instructions that rebuild each)
 #pragma unroll
-    for (int k = 0; k < EK; ++k) asm volatile("" : "+v"(nb[k]));
+    for (int k = 0; k < EK / 2; ++k) asm volatile("" : "+v"(nb[k]));
     __syncthreads();   // done with the k slab
-    qgemm(0);
+    qload(0);             // the v product's fragments travel under the soft-max
     float mx = -INFINITY, sum = 0.f;
 #pragma unroll 4
     for (int k = 0; k < EK; ++k) mx = fmaxf(mx, l_score[k][tid]);
@@ -818,6 +850,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
         l_score[k][tid] = ex;
         sum += ex;
     }
+    qmma(0);
     __syncthreads();
 
     // ---- C: V branch, weighted sum
@@ -862,7 +895,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
 // can this layer shape take the fused kernel?
 bool edge_attn_fq_supported(int Co, int Cin) { return (Co == 64 && (Cin == 32 || Cin == 64)) || (Co == 128 && Cin == 64); }
 bool edge_attn_fq_fits(int B, int Ns, int ldt) {   // the table is addressed by 32-bit byte offsets formed with a 24-bit multiply
-    return (unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24);
+    return (unsigned long long)B * Ns * 3ull * ldt * 4ull < (1ull << 32) && (unsigned long long)B * Ns < (1ull << 24) && 3ull * ldt * 4ull < (1ull << 24) &&
+           Ns < 65536;      // (+ neighbour indices packed two per register)
 }
 // points per workgroup of the fused kernel = rows of `colsum` per Nd / this many points (0: shape not served)
 int edge_attn_fq_points_per_wg(int Co) { return Co == 64 ? 16 : Co == 128 ? 8 : 0; }
