@@ -160,7 +160,7 @@ def roofline_entry(kind, layer, avg_s, cfg, B, N, bf16x3):
     else:
         # "mfma" = flops executed on the matrix cores; "valu" = fp32 vector-pipe flops (the VN activation / soft-max / distance arithmetic): both are
         # the contract's compute-bound class, named by the pipe that executes them ("mfma" was hard-coded)
-        e = dict(kernel=name, bound="mfma" if "MFMA" in fwhat.split(";")[0] else "valu", achieved=aflops / avg_s / 1e12, peak=fpeak, unit="TFLOP/s",
+        e = dict(kernel=name, bound="mfma" if fwhat.split(" ")[1:2] == ["MFMA"] else "valu", achieved=aflops / avg_s / 1e12, peak=fpeak, unit="TFLOP/s",
                  basis=fwhat + " / measured launch duration")
     e["frac"] = e["achieved"] / e["peak"]
     e["avg_launch_us"] = avg_s * 1e6
@@ -576,11 +576,11 @@ def main():
         for q in prof:
             fam[q["kind"]] = fam.get(q["kind"], 0.0) + q["total_ms"]
         dom_kind = max(fam, key=fam.get)
-        # ... and of its launches within 10 % of the family's longest, the one FURTHEST below its roofline (layers 2 and 3 of the attention family
-        # are within a few us of each other: picking by time alone flipped between them from run to run)
+        # ... and of its launches within 3 % of the family's longest, the one FURTHEST below its roofline (layers 2 and 3 of the attention family
+        # are within a microsecond or two of each other: picking by time alone flipped between them from run to run)
         dom_c = [q for q in prof if q["kind"] == dom_kind]
         dom_t = max(q["total_ms"] / q["launches"] for q in dom_c)
-        dom = min((q for q in dom_c if q["total_ms"] / q["launches"] >= 0.9 * dom_t),
+        dom = min((q for q in dom_c if q["total_ms"] / q["launches"] >= 0.97 * dom_t),
                   key=lambda q: roofline_entry(q["kind"], q["layer"], q["total_ms"] / q["launches"] * 1e-3, ecfg, B, N, bf16x3)["frac"])
         roof = roofline_entry(dom["kind"], dom["layer"], dom["total_ms"] / dom["launches"] * 1e-3, ecfg, B, N, bf16x3)
         if dom["kind"] == "knn":

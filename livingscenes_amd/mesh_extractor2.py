@@ -179,8 +179,12 @@ class Generator3D:
         """mesh_extractor2.py:161-214: pad with -1e6 (watertight), marching cubes at the logit threshold, undo the library's 0.5
         shift and the padding, normalise to the bounding box."""
         if self.with_normals or self.refinement_step > 0:
-            raise NotImplementedError("with_normals / refinement_step > 0 are off in every released configuration "
-                                      "(configs/more_3rscan.yaml:19-26, room4cates.yaml:32-39) and not implemented")
+            # Off in every released configuration (configs/more_3rscan.yaml:19-26, room4cates.yaml:32-39) -- and not runnable in the reference on this call
+            # path either: generate_from_latent hands the code DICT on as `c`, estimate_normals does `c.unsqueeze(0)` (mesh_extractor2.py:231: AttributeError
+            # on a dict) and refine_mesh starts with `self.model.eval()` (:257), an attribute Generator3D never sets (OccNet leftovers).  There is no reference
+            # behaviour to reproduce, so the switch is refused loudly instead of inventing one.
+            raise NotImplementedError("with_normals / refinement_step > 0: off in every released configuration and broken in the reference on the "
+                                      "generate_from_latent path (mesh_extractor2.py:231 c.unsqueeze on the code dict, :257 self.model) -- nothing to reproduce")
         n_x, n_y, n_z = occ_hat.shape
         box_size = 1 + self.padding
         threshold = np.log(self.threshold) - np.log(1.0 - self.threshold)
