@@ -248,3 +248,29 @@ def test_configs_sharded_gpus_2_runs_two_ranks():
     for a, b in zip(two, one):
         for k in ("scene_pairs", "instance_encodes", "registrations", "meshes", "instances"):
             assert a.get(k) == b.get(k), (k, a, b)
+
+
+def test_global_conv_is_reproducible_with_streams_in_flight():
+    """Run-time side of the packed-fp32 build guard on pointwise.hip (profiles/r6_final/pk_guard_ab.txt): a library whose glob_mean_gemv_kernel
+    holds compiler-formed v_pk_fma_f32 is bit-stable alone and WRONG with streams in flight (181 of 240 launches at layer 6, errors to 17 %).  The release
+    library must return the same bits from every one of 8 streams x 20 rounds, at the three kinds of global-conv layer (streaming 64-channel kernel, tiled
+    kernel with column sums absent, wide rows)."""
+    from livingscenes_amd.model_utils import Shape_Prior
+    dev = _dev()
+    ecfg, dcfg = synth.default_encoder_cfg(), synth.default_decoder_cfg()
+    sp = Shape_Prior.from_state(ecfg, dcfg, synth.make_encoder_weights(ecfg, 0), synth.make_decoder_weights(dcfg, 0), device=dev)
+    m = sp.hip_model()
+    g = torch.Generator().manual_seed(3)
+    feats = {2: torch.randn(64, 512, 3, 64, generator=g) * 0.1, 4: torch.randn(64, 128, 3, 128, generator=g) * 0.1, 6: torch.randn(64, 32, 3, 512, generator=g) * 0.1}
+    streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
+    for layer, f in feats.items():
+        f = f.to(dev)
+        ref = m.vn_lna_global(layer, f).clone()
+        torch.cuda.synchronize()
+        for _ in range(20):
+            outs = []
+            for st in streams:
+                with torch.cuda.stream(st):
+                    outs.append(m.vn_lna_global(layer, f))
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, ref) for o in outs), f"global conv of layer {layer} differs between streams"
