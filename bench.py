@@ -163,6 +163,11 @@ def roofline_entry(kind, layer, avg_s, cfg, B, N, bf16x3):
         e = dict(kernel=name, bound="mfma" if fwhat.split(" ")[1:2] == ["MFMA"] else "valu", achieved=aflops / avg_s / 1e12, peak=fpeak, unit="TFLOP/s",
                  basis=fwhat + " / measured launch duration")
     e["frac"] = e["achieved"] / e["peak"]
+    if e["bound"] == "valu":
+        # the contract's peak (MI355X_MICROARCH.md: 157.3 TFLOP/s vector fp32) counts packed v_pk_fma_f32; round 6 measured that wave64 packed fp32 buys no
+        # issue time on this chip (profiles/r6_final/pk_guard_ab.txt: half the instructions, same or longer kernels), so wave64 VALU code tops out at
+        # 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz = 78.6 TFLOP/s: `frac` stays on the contract's peak, this is the fraction of the reachable one
+        e["frac_of_nonpacked_valu_peak"] = e["achieved"] / (FP32_PEAK_TFLOPS / 2.0)
     e["avg_launch_us"] = avg_s * 1e6
     e["algorithmic_bytes_per_launch"], e["algorithmic_flops_per_launch"] = abytes, aflops
     pmc = committed_pmc(name)
